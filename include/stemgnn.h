@@ -1,0 +1,204 @@
+/*
+ * stemgnn.h — C ABI of the MI355X (gfx950) STEM-GNN hot-path library (libstemgnn_hip.so).
+ *
+ * Drop-in boundary for the encoder message-passing aggregation + vector-quantize
+ * pretraining path of GXG-CS/STEM-GNN.  The reference has no FFI of its own: the
+ * boundary it exposes is the Python nn.Module surface, and the device
+ * operations behind it are whatever PyTorch / PyG / torch-scatter dispatch to.  Each entry
+ * point below names the reference operation (file:line, relative to
+ * /root/reference/STEM-GNN) whose device work it replaces.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer (hipMalloc / PyTorch caching allocator) unless the
+ *    parameter name ends in _host; matrices are dense row-major fp32; indices as stated.
+ *  - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing
+ *    synchronises, allocates or frees (graph-capture safe).  Scratch comes from the caller
+ *    (`workspace`, sized by the matching *_workspace_bytes function).
+ *  - return value: STEMGNN_OK (0) or a negative STEMGNN_ERR_* code.  Shape / range
+ *    violations that can be seen on the host are rejected before any launch.
+ *  - inputs are borrowed and never written; outputs are fully overwritten unless documented
+ *    as in-place.
+ */
+#ifndef STEMGNN_H_
+#define STEMGNN_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STEMGNN_ABI_VERSION 1
+
+enum {
+  STEMGNN_OK = 0,
+  STEMGNN_ERR_INVALID_ARG = -1, /* null pointer, negative size, unsupported D / K / Dc */
+  STEMGNN_ERR_TOO_LARGE = -2,   /* N or E >= 2^31 - 1 (int32 CSR) */
+  STEMGNN_ERR_WORKSPACE = -3,   /* workspace too small */
+  STEMGNN_ERR_HIP = -4          /* a HIP runtime call failed; see stemgnn_last_hip_error() */
+};
+
+int stemgnn_abi_version(void);
+const char* stemgnn_status_string(int status);
+/* hipError_t (as int) of the last failing HIP call on the calling thread, 0 if none. */
+int stemgnn_last_hip_error(void);
+
+/* ------------------------------------------------------------------------------------
+ * Graph structure: int64 COO -> int32 CSR.
+ * Replaces the implicit per-call index handling of PyG's MessagePassing.propagate
+ * (model/encoder.py:82: index_select over edge_index[0], scatter over edge_index[1]).
+ * ------------------------------------------------------------------------------------ */
+
+/* Scratch bytes needed by stemgnn_csr_build for this problem size. */
+size_t stemgnn_csr_workspace_bytes(int64_t num_nodes, int64_t num_edges);
+
+/*
+ * Stable counting/radix sort of the edges by one endpoint.
+ *   edge_index [2, E] int64 row-major, row 0 = source, row 1 = target (PyG convention).
+ *   key_row    1: group by target  (CSR used by the forward aggregation, K1)
+ *              0: group by source  (transposed CSR used by the backward, K2)
+ *   rowptr [N+1]  segment offsets;  other [E] the opposite endpoint of each slot;
+ *   eid [E]       original edge position of each slot (stable: ascending inside a segment).
+ *   bad_count [1] number of edges with an endpoint outside [0, N); such edges are left
+ *                 out (rowptr[N] = E - bad) so no later kernel can index out of range.
+ */
+int stemgnn_csr_build(const int64_t* edge_index, int64_t num_edges, int64_t num_nodes, int key_row,
+                      int32_t* rowptr, int32_t* other, int32_t* eid, int32_t* bad_count,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* out[i] = table[index[i]] for int32 tables (edge-type id per CSR slot = xe[eid[slot]]). */
+int stemgnn_gather_i32(const int32_t* table, const int32_t* index, int64_t n, int32_t* out, void* stream);
+
+/* Same sort applied to arbitrary int32 keys in [0, num_keys): rowptr [num_keys+1], perm [n]. */
+int stemgnn_group_by_key(const int32_t* keys, int64_t n, int64_t num_keys, int32_t* rowptr, int32_t* perm,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * K1: MySAGEConv message + mean aggregation, forward.
+ * Replaces MessagePassing.propagate -> message -> MeanAggregation (model/encoder.py:82,
+ * 94-97):  agg[i] = (1/max(deg(i),1)) * sum_{slots of i} relu(x[src] + ea).
+ * Edge attribute source, exactly one of:
+ *   edge_attr != NULL : dense [E, D] rows addressed by ORIGINAL edge id (drop-in signature)
+ *   etab != NULL      : type table [T, D] + etype_slot [E] (type id per CSR slot)
+ *   both NULL         : no edge term (edge_attr=None branch, encoder.py:95)
+ * D must be a multiple of 4 and <= 2048; rows must be 16-byte aligned.
+ * ------------------------------------------------------------------------------------ */
+int stemgnn_sage_agg_fwd(const float* x, int64_t num_nodes, int64_t dim,
+                         const int32_t* rowptr, const int32_t* src, const int32_t* eid,
+                         const float* edge_attr, const float* etab, const int32_t* etype_slot, int64_t num_types,
+                         float* agg, void* stream);
+
+/*
+ * K2: backward of K1 w.r.t. x (PyG autograd: index_select backward = index_add,
+ * scatter-mean backward = gather / count).  Deterministic, no atomics:
+ *   gx[s] = sum_{slots of s in the by-source CSR} 1[x[s] + ea > 0] * g_agg[dst] * inv_deg[dst]
+ * inv_deg [N] = 1 / max(in-degree, 1) (stemgnn_inv_degree).
+ */
+int stemgnn_sage_agg_bwd(const float* g_agg, const float* x, int64_t num_nodes, int64_t dim,
+                         const int32_t* rowptr_t, const int32_t* dst_t, const int32_t* eid_t,
+                         const float* inv_deg,
+                         const float* edge_attr, const float* etab, const int32_t* etype_slot_t, int64_t num_types,
+                         float* g_x, void* stream);
+
+int stemgnn_inv_degree(const int32_t* rowptr, int64_t num_nodes, float* inv_deg, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * K4: BatchNorm1d (training statistics) + ReLU/LeakyReLU + Dropout
+ * (model/encoder.py:173,313-317).
+ * ------------------------------------------------------------------------------------ */
+size_t stemgnn_bn_workspace_bytes(int64_t num_rows, int64_t dim);
+
+/* Column mean / biased variance of y [N, D]; writes mean [D], rstd [D] = 1/sqrt(var+eps);
+ * when running_mean/var != NULL updates them in place with `momentum` (unbiased variance,
+ * torch.nn.BatchNorm1d semantics). */
+int stemgnn_bn_stats(const float* y, int64_t num_rows, int64_t dim, float eps,
+                     float* mean, float* rstd, float* running_mean, float* running_var, float momentum,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* out = dropout(act((y - mean) * rstd * gamma + beta)).
+ * act: 0 none, 1 relu / leaky-relu with `negative_slope`.  p = 0 disables dropout; the keep
+ * decision of element (r, c) is philox(seed, offset)[r*D + c] >= p, reproducible by
+ * stemgnn_dropout_keep_mask.  mean/rstd == NULL skips the normalisation (normalize='none'). */
+int stemgnn_bn_act_drop_fwd(const float* y, int64_t num_rows, int64_t dim,
+                            const float* mean, const float* rstd, const float* gamma, const float* beta,
+                            int act, float negative_slope, float p, uint64_t seed, uint64_t offset,
+                            float* out, void* stream);
+
+/* Backward: g_y [N, D], g_gamma [D], g_beta [D] from g_out, recomputing x_hat, the
+ * activation sign and the dropout mask.  */
+int stemgnn_bn_act_drop_bwd(const float* g_out, const float* y, int64_t num_rows, int64_t dim,
+                            const float* mean, const float* rstd, const float* gamma, const float* beta,
+                            int act, float negative_slope, float p, uint64_t seed, uint64_t offset,
+                            float* g_y, float* g_gamma, float* g_beta,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
+/* keep[i] (uint8) for i in [0, n): the mask the two kernels above use. */
+int stemgnn_dropout_keep_mask(int64_t n, float p, uint64_t seed, uint64_t offset, uint8_t* keep, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * K6+K7+K8: cosine-similarity codebook assignment, fused.
+ * Replaces l2norm (model/vq.py:891) + CosineSimCodebook.forward's einsum / argmax /
+ * one-hot / einsum (vq.py:650-657) + straight-through and commitment MSE
+ * (vq.py:931-937,1007-1009).  fp32 MFMA (v_mfma_f32_32x32x2_f32), exact fp32.
+ *   xp      [N, H*Dc]  project_in output, head h in columns [h*Dc, (h+1)*Dc)
+ *   embed   [H, K, Dc]
+ *   xn      [N, H*Dc]  optional (may be NULL): l2-normalised input
+ *   norm    [N, H]     ||xp_h|| before clamping at 1e-12 (saved for backward with xp)
+ *   ind     [N, H]     int64 arg-max code (lowest index wins ties)
+ *   quant   [N, H*Dc]  training: xn + (q - xn) (straight-through value); eval: q
+ *   sqerr   [1]        sum over all elements of (q - xn)^2 (commitment numerator)
+ * Dc must be a multiple of 4 and <= 1024, K <= 65536.
+ * ------------------------------------------------------------------------------------ */
+size_t stemgnn_vq_workspace_bytes(int64_t num_rows, int64_t heads, int64_t code_dim, int64_t codebook_size);
+
+int stemgnn_vq_assign_fwd(const float* xp, int64_t num_rows, int64_t heads, int64_t code_dim,
+                          const float* embed, int64_t codebook_size, int training,
+                          float* xn, float* norm, int64_t* ind, float* quant, float* sqerr,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
+/* g_xp = d/dxp [ <g_quant, quant> + g_loss * commit_weight * mean((q - xn)^2) ]
+ * (straight-through: d quant / d xn = I; q is constant; xn is recomputed from xp and norm).
+ * g_loss [1] device scalar, may be NULL (no commitment term). */
+int stemgnn_vq_assign_bwd(const float* g_quant, const float* g_loss, float commit_weight,
+                          const float* xp, const float* norm, const int64_t* ind, const float* embed,
+                          int64_t num_rows, int64_t heads, int64_t code_dim, int64_t codebook_size,
+                          float* g_xp, void* stream);
+
+/* K10: EMA statistics (vq.py:661-672): bins [H, K] = #rows per code, embed_sum [H, K, Dc]
+ * = sum of the normalised rows xp/max(norm,1e-12) per code.  Deterministic (sorted segment sums). */
+size_t stemgnn_vq_ema_workspace_bytes(int64_t num_rows, int64_t heads, int64_t code_dim, int64_t codebook_size);
+int stemgnn_vq_ema_stats(const float* xp, const float* norm, const int64_t* ind, int64_t num_rows, int64_t heads, int64_t code_dim,
+                         int64_t codebook_size, float* bins, float* embed_sum,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * K11: InnerProductDecoder edge scores (model/encoder.py:364-366):
+ *   out[e] = <z[u_e], z[v_e]>,  edge_index [2, E] int64.  Backward scatters with fp32
+ *   atomics into g_z (which must be zero-initialised by the caller).
+ * ------------------------------------------------------------------------------------ */
+int stemgnn_edge_dot_fwd(const float* z, int64_t num_nodes, int64_t dim, const int64_t* edge_index,
+                         int64_t num_edges, float* out, void* stream);
+int stemgnn_edge_dot_bwd(const float* g_out, const float* z, int64_t num_nodes, int64_t dim,
+                         const int64_t* edge_index, int64_t num_edges, float* g_z, void* stream);
+
+/* K12 feed: out[e] = concat(z[u_e], z[v_e]) ([E, 2D]); backward scatters g_out back
+ * (atomics; g_z zero-initialised by the caller).  (model/pt_model.py:80) */
+int stemgnn_edge_concat_fwd(const float* z, int64_t num_nodes, int64_t dim, const int64_t* edge_index,
+                            int64_t num_edges, float* out, void* stream);
+int stemgnn_edge_concat_bwd(const float* g_out, int64_t num_nodes, int64_t dim, const int64_t* edge_index,
+                            int64_t num_edges, float* g_z, void* stream);
+
+/* Row gather: out[i, :] = table[index[i], :] (host-side feature lookup of pretrain.py:33-38,
+ * moved to the device).  index int64, rows fp32. */
+int stemgnn_gather_rows(const float* table, int64_t num_table_rows, int64_t dim, const int64_t* index,
+                        int64_t n, float* out, void* stream);
+
+/* K14: teacher EMA (model/pt_model.py:104-106) on flat parameter buffers, in place:
+ *   teacher = teacher * decay + student * (1 - decay). */
+int stemgnn_ema_lerp(float* teacher, const float* student, int64_t n, float decay, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STEMGNN_H_ */

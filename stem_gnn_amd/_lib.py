@@ -1,0 +1,86 @@
+"""ctypes binding of libstemgnn_hip.so (the C ABI declared in include/stemgnn.h).
+
+There is no CPU or PyTorch fallback: if the HIP library has not been built the import
+fails loudly, and every op raises if handed a non-CUDA tensor.
+"""
+import ctypes
+import os
+import re
+from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_uint64, c_void_p
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libstemgnn_hip.so")
+HEADER_PATH = os.path.join(_PKG, "..", "include", "stemgnn.h")
+
+
+class StemGnnLibraryError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the gfx950 HIP library has not been built. "
+            "Run `python -m stem_gnn_amd.build` (or __graft_entry__.build()). "
+            "stem_gnn_amd has no CPU fallback.")
+    return ctypes.CDLL(LIB_PATH)
+
+
+lib = _load()
+
+P = c_void_p
+I64 = c_int64
+
+_SIGNATURES = {
+    "stemgnn_abi_version": (c_int, []),
+    "stemgnn_status_string": (c_char_p, [c_int]),
+    "stemgnn_last_hip_error": (c_int, []),
+    "stemgnn_csr_workspace_bytes": (c_size_t, [I64, I64]),
+    "stemgnn_csr_build": (c_int, [P, I64, I64, c_int, P, P, P, P, P, c_size_t, P]),
+    "stemgnn_gather_i32": (c_int, [P, P, I64, P, P]),
+    "stemgnn_group_by_key": (c_int, [P, I64, I64, P, P, P, c_size_t, P]),
+    "stemgnn_sage_agg_fwd": (c_int, [P, I64, I64, P, P, P, P, P, P, I64, P, P]),
+    "stemgnn_sage_agg_bwd": (c_int, [P, P, I64, I64, P, P, P, P, P, P, P, I64, P, P]),
+    "stemgnn_inv_degree": (c_int, [P, I64, P, P]),
+    "stemgnn_bn_workspace_bytes": (c_size_t, [I64, I64]),
+    "stemgnn_bn_stats": (c_int, [P, I64, I64, c_float, P, P, P, P, c_float, P, c_size_t, P]),
+    "stemgnn_bn_act_drop_fwd": (c_int, [P, I64, I64, P, P, P, P, c_int, c_float, c_float, c_uint64, c_uint64, P, P]),
+    "stemgnn_bn_act_drop_bwd": (c_int, [P, P, I64, I64, P, P, P, P, c_int, c_float, c_float, c_uint64, c_uint64,
+                                        P, P, P, P, c_size_t, P]),
+    "stemgnn_dropout_keep_mask": (c_int, [I64, c_float, c_uint64, c_uint64, P, P]),
+    "stemgnn_vq_workspace_bytes": (c_size_t, [I64, I64, I64, I64]),
+    "stemgnn_vq_assign_fwd": (c_int, [P, I64, I64, I64, P, I64, c_int, P, P, P, P, P, P, c_size_t, P]),
+    "stemgnn_vq_assign_bwd": (c_int, [P, P, c_float, P, P, P, P, I64, I64, I64, I64, P, P]),
+    "stemgnn_vq_ema_workspace_bytes": (c_size_t, [I64, I64, I64, I64]),
+    "stemgnn_vq_ema_stats": (c_int, [P, P, P, I64, I64, I64, I64, P, P, P, c_size_t, P]),
+    "stemgnn_edge_dot_fwd": (c_int, [P, I64, I64, P, I64, P, P]),
+    "stemgnn_edge_dot_bwd": (c_int, [P, P, I64, I64, P, I64, P, P]),
+    "stemgnn_edge_concat_fwd": (c_int, [P, I64, I64, P, I64, P, P]),
+    "stemgnn_edge_concat_bwd": (c_int, [P, I64, I64, P, I64, P, P]),
+    "stemgnn_gather_rows": (c_int, [P, I64, I64, P, I64, P, P]),
+    "stemgnn_ema_lerp": (c_int, [P, P, I64, c_float, P]),
+}
+
+
+def declared_symbols():
+    """Every function name include/stemgnn.h declares (used by the CPU export test)."""
+    with open(HEADER_PATH) as f:
+        text = f.read()
+    return sorted(set(re.findall(r"\b(stemgnn_[a-z0-9_]+)\s*\(", text)))
+
+
+for _name, (_res, _args) in _SIGNATURES.items():
+    _fn = getattr(lib, _name)  # AttributeError here = header / library mismatch: fail at import
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+if lib.stemgnn_abi_version() != 1:
+    raise ImportError("libstemgnn_hip.so ABI version mismatch; rebuild with python -m stem_gnn_amd.build")
+
+
+def check(status: int, what: str = ""):
+    if status != 0:
+        msg = lib.stemgnn_status_string(status).decode()
+        if status == -4:
+            msg += f" (hipError_t {lib.stemgnn_last_hip_error()})"
+        raise StemGnnLibraryError(f"{what or 'stemgnn call'} failed: {msg}")

@@ -1,0 +1,216 @@
+// K11 / K12 feed / feature lookup / K14: edge-wise gather kernels and small elementwise ops.
+//
+// Reference: InnerProductDecoder.forward (STEM-GNN/model/encoder.py:364-366:
+// (z[ei[0]] * z[ei[1]]).sum(1)), the cat([z[u], z[v]]) feeding topo_sem_recon_decoder
+// (model/pt_model.py:80), the host-side feature lookup node_text_feat[x] (pretrain.py:33-38)
+// and the teacher EMA loop (model/pt_model.py:104-106).  All HBM-bound row gathers:
+// one G-lane group per edge / row, 16-byte loads.
+#include "common.h"
+
+namespace stemgnn {
+namespace {
+
+constexpr int kBlock = 256;
+
+__device__ inline float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ inline void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+// valid endpoint pair or (-1): out-of-range edges produce 0 / are skipped (never fault).
+__device__ inline bool load_edge(const int64_t* __restrict__ ei, int64_t E, int64_t e, int64_t N, int64_t* u, int64_t* v) {
+  *u = ei[e];
+  *v = ei[E + e];
+  return *u >= 0 && *u < N && *v >= 0 && *v < N;
+}
+
+template <int G>
+__global__ void __launch_bounds__(kBlock)
+k_edge_dot_fwd(const float* __restrict__ z, int64_t N, int D, const int64_t* __restrict__ ei, int64_t E,
+               float* __restrict__ out) {
+  const int lane = threadIdx.x % G;
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * (kBlock / G) + threadIdx.x / G;
+  if (e >= E) return;
+  int64_t u, v;
+  const bool ok = load_edge(ei, E, e, N, &u, &v);
+  float acc = 0.f;
+  if (ok) {
+    const int nvec = D / 4;
+    for (int c = lane; c < nvec; c += G) {
+      const float4 a = ld4(z + u * D + 4 * c), b = ld4(z + v * D + 4 * c);
+      acc += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+    }
+  }
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, G);
+  if (lane == 0) out[e] = acc;
+}
+
+__device__ inline void atomic_add4(float* p, float4 v) {
+  atomicAdd(p + 0, v.x);
+  atomicAdd(p + 1, v.y);
+  atomicAdd(p + 2, v.z);
+  atomicAdd(p + 3, v.w);
+}
+
+template <int G>
+__global__ void __launch_bounds__(kBlock)
+k_edge_dot_bwd(const float* __restrict__ g_out, const float* __restrict__ z, int64_t N, int D,
+               const int64_t* __restrict__ ei, int64_t E, float* __restrict__ g_z) {
+  const int lane = threadIdx.x % G;
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * (kBlock / G) + threadIdx.x / G;
+  if (e >= E) return;
+  int64_t u, v;
+  if (!load_edge(ei, E, e, N, &u, &v)) return;
+  const float g = g_out[e];
+  const int nvec = D / 4;
+  for (int c = lane; c < nvec; c += G) {
+    const float4 a = ld4(z + u * D + 4 * c), b = ld4(z + v * D + 4 * c);
+    atomic_add4(g_z + u * D + 4 * c, make_float4(g * b.x, g * b.y, g * b.z, g * b.w));
+    atomic_add4(g_z + v * D + 4 * c, make_float4(g * a.x, g * a.y, g * a.z, g * a.w));
+  }
+}
+
+template <int G>
+__global__ void __launch_bounds__(kBlock)
+k_edge_concat_fwd(const float* __restrict__ z, int64_t N, int D, const int64_t* __restrict__ ei, int64_t E,
+                  float* __restrict__ out) {
+  const int lane = threadIdx.x % G;
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * (kBlock / G) + threadIdx.x / G;
+  if (e >= E) return;
+  int64_t u, v;
+  const bool ok = load_edge(ei, E, e, N, &u, &v);
+  const int nvec = D / 4;
+  float* o = out + e * 2 * D;
+  for (int c = lane; c < nvec; c += G) {
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    st4(o + 4 * c, ok ? ld4(z + u * D + 4 * c) : zero);
+    st4(o + D + 4 * c, ok ? ld4(z + v * D + 4 * c) : zero);
+  }
+}
+
+template <int G>
+__global__ void __launch_bounds__(kBlock)
+k_edge_concat_bwd(const float* __restrict__ g_out, int64_t N, int D, const int64_t* __restrict__ ei, int64_t E,
+                  float* __restrict__ g_z) {
+  const int lane = threadIdx.x % G;
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * (kBlock / G) + threadIdx.x / G;
+  if (e >= E) return;
+  int64_t u, v;
+  if (!load_edge(ei, E, e, N, &u, &v)) return;
+  const int nvec = D / 4;
+  const float* g = g_out + e * 2 * D;
+  for (int c = lane; c < nvec; c += G) {
+    atomic_add4(g_z + u * D + 4 * c, ld4(g + 4 * c));
+    atomic_add4(g_z + v * D + 4 * c, ld4(g + D + 4 * c));
+  }
+}
+
+template <int G>
+__global__ void __launch_bounds__(kBlock)
+k_gather_rows(const float* __restrict__ table, int64_t R, int D, const int64_t* __restrict__ index, int64_t n,
+              float* __restrict__ out) {
+  const int lane = threadIdx.x % G;
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * (kBlock / G) + threadIdx.x / G;
+  if (i >= n) return;
+  const int64_t r = index[i];
+  const bool ok = r >= 0 && r < R;
+  const int nvec = D / 4;
+  for (int c = lane; c < nvec; c += G)
+    st4(out + i * D + 4 * c, ok ? ld4(table + r * D + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f));
+}
+
+__global__ void __launch_bounds__(kBlock) k_ema_lerp(float* __restrict__ t, const float* __restrict__ s, int64_t n,
+                                                     float decay) {
+  const float w = 1.0f - decay;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * kBlock)
+    t[i] = t[i] * decay + s[i] * w;  // param_k * decay + param_q * (1 - decay), pt_model.py:106
+}
+
+inline bool dim_ok(int64_t D) { return D > 0 && D % 4 == 0 && D <= 16384; }
+
+inline unsigned groups_grid(int64_t items, int G) {
+  const int per = kBlock / G;
+  return static_cast<unsigned>((items + per - 1) / per);
+}
+
+#define STEMGNN_EDGE_DISPATCH(KERNEL, ITEMS, ...)                                                   \
+  do {                                                                                             \
+    if (D / 4 <= 16) KERNEL<16><<<groups_grid(ITEMS, 16), kBlock, 0, st>>>(__VA_ARGS__);            \
+    else if (D / 4 <= 32) KERNEL<32><<<groups_grid(ITEMS, 32), kBlock, 0, st>>>(__VA_ARGS__);       \
+    else KERNEL<64><<<groups_grid(ITEMS, 64), kBlock, 0, st>>>(__VA_ARGS__);                        \
+    STEMGNN_LAUNCH_CHECK();                                                                        \
+  } while (0)
+
+}  // namespace
+}  // namespace stemgnn
+
+using namespace stemgnn;
+
+extern "C" {
+
+int stemgnn_edge_dot_fwd(const float* z, int64_t N, int64_t D, const int64_t* edge_index, int64_t E, float* out,
+                         void* stream_) {
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  if (N < 0 || E < 0 || !dim_ok(D)) return STEMGNN_ERR_INVALID_ARG;
+  if (!fits_i32(E)) return STEMGNN_ERR_TOO_LARGE;
+  if (E == 0) return STEMGNN_OK;
+  if (!z || !edge_index || !out) return STEMGNN_ERR_INVALID_ARG;
+  STEMGNN_EDGE_DISPATCH(k_edge_dot_fwd, E, z, N, static_cast<int>(D), edge_index, E, out);
+  return STEMGNN_OK;
+}
+
+int stemgnn_edge_dot_bwd(const float* g_out, const float* z, int64_t N, int64_t D, const int64_t* edge_index,
+                         int64_t E, float* g_z, void* stream_) {
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  if (N < 0 || E < 0 || !dim_ok(D)) return STEMGNN_ERR_INVALID_ARG;
+  if (!fits_i32(E)) return STEMGNN_ERR_TOO_LARGE;
+  if (E == 0) return STEMGNN_OK;
+  if (!g_out || !z || !edge_index || !g_z) return STEMGNN_ERR_INVALID_ARG;
+  STEMGNN_EDGE_DISPATCH(k_edge_dot_bwd, E, g_out, z, N, static_cast<int>(D), edge_index, E, g_z);
+  return STEMGNN_OK;
+}
+
+int stemgnn_edge_concat_fwd(const float* z, int64_t N, int64_t D, const int64_t* edge_index, int64_t E, float* out,
+                            void* stream_) {
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  if (N < 0 || E < 0 || !dim_ok(D)) return STEMGNN_ERR_INVALID_ARG;
+  if (!fits_i32(E)) return STEMGNN_ERR_TOO_LARGE;
+  if (E == 0) return STEMGNN_OK;
+  if (!z || !edge_index || !out) return STEMGNN_ERR_INVALID_ARG;
+  STEMGNN_EDGE_DISPATCH(k_edge_concat_fwd, E, z, N, static_cast<int>(D), edge_index, E, out);
+  return STEMGNN_OK;
+}
+
+int stemgnn_edge_concat_bwd(const float* g_out, int64_t N, int64_t D, const int64_t* edge_index, int64_t E,
+                            float* g_z, void* stream_) {
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  if (N < 0 || E < 0 || !dim_ok(D)) return STEMGNN_ERR_INVALID_ARG;
+  if (!fits_i32(E)) return STEMGNN_ERR_TOO_LARGE;
+  if (E == 0) return STEMGNN_OK;
+  if (!g_out || !edge_index || !g_z) return STEMGNN_ERR_INVALID_ARG;
+  STEMGNN_EDGE_DISPATCH(k_edge_concat_bwd, E, g_out, N, static_cast<int>(D), edge_index, E, g_z);
+  return STEMGNN_OK;
+}
+
+int stemgnn_gather_rows(const float* table, int64_t R, int64_t D, const int64_t* index, int64_t n, float* out,
+                        void* stream_) {
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  if (R < 0 || n < 0 || !dim_ok(D)) return STEMGNN_ERR_INVALID_ARG;
+  if (n == 0) return STEMGNN_OK;
+  if (!table || !index || !out) return STEMGNN_ERR_INVALID_ARG;
+  STEMGNN_EDGE_DISPATCH(k_gather_rows, n, table, R, static_cast<int>(D), index, n, out);
+  return STEMGNN_OK;
+}
+
+int stemgnn_ema_lerp(float* teacher, const float* student, int64_t n, float decay, void* stream_) {
+  if (n < 0) return STEMGNN_ERR_INVALID_ARG;
+  if (n == 0) return STEMGNN_OK;
+  if (!teacher || !student) return STEMGNN_ERR_INVALID_ARG;
+  int64_t g = (n + kBlock - 1) / kBlock;
+  if (g > 4096) g = 4096;
+  k_ema_lerp<<<static_cast<unsigned>(g), kBlock, 0, static_cast<hipStream_t>(stream_)>>>(teacher, student, n, decay);
+  STEMGNN_LAUNCH_CHECK();
+  return STEMGNN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,423 @@
+// K6 + K7 + K8 (+ K10): cosine-similarity codebook assignment for gfx950, fused.
+//
+// Reference (STEM-GNN/model/vq.py): l2norm of the per-head vectors (:891), then
+// CosineSimCodebook.forward (:623-688): sim = einsum('h n d, h c d -> h n c') (:650),
+// argmax (:652, gumbel_sample with stochastic=False, :78), one-hot (:79) and a second
+// einsum against the codebook (:657); VectorQuantize.forward adds the straight-through
+// estimator (:937) and the commitment MSE (:1007-1009).  The reference materialises
+// sim [H, N, K] and a same-size one-hot in HBM and spends a second 2*H*N*K*Dc-flop GEMM on
+// the one-hot product.
+//
+// Here one kernel per call: a 128-row x (32*CG)-code tile of sim is accumulated in MFMA
+// registers (v_mfma_f32_32x32x2_f32: exact fp32, as the reference forces fp32 at
+// vq.py:623,634), reduced to a running arg-max per row in registers, and the winning code
+// row is gathered in the epilogue.  Nothing of size [H, N, K] ever reaches memory.
+// Bound: fp32 MFMA (2*H*N*K*Dc flop at 157 TFLOP/s) for K*Dc large, else HBM
+// (read xp, write quant: 2*N*H*Dc*4 B).
+//
+// MFMA operand mapping (32x32x2 f32): A[i][k] <- codebook rows (i = code), B[k][j] <- data
+// rows (j = row), so C[i][j] keeps the data row on the lane (j = lane & 31) and the 16 code
+// rows of the lane's half in registers: the arg-max over codes is a per-lane scan plus one
+// cross-half exchange.  Ties resolve to the lowest code index (torch.argmax semantics).
+#include "common.h"
+
+namespace stemgnn {
+namespace {
+
+constexpr int kBlock = 256;          // 4 waves; wave w owns data rows [32w, 32w+32) of the tile
+constexpr int kRowsPerBlock = 128;
+constexpr int kKC = 32;              // k-chunk staged in LDS per step
+constexpr int kPad = 4;              // row padding (floats): 36-dword stride -> conflict-free ds_read_b128
+constexpr int kLd = kKC + kPad;
+constexpr float kNormEps = 1e-12f;   // F.normalize eps (vq.py:28-29)
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+__device__ inline float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ inline void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+template <int CG>
+__global__ void __launch_bounds__(kBlock)
+k_vq_assign(const float* __restrict__ xp, int64_t N, int H, int Dc, const float* __restrict__ embed, int K,
+            int training, float* __restrict__ xn_out, float* __restrict__ norm_out, int64_t* __restrict__ ind_out,
+            float* __restrict__ quant, float* __restrict__ sq_partial) {
+  __shared__ __attribute__((aligned(16))) float sA[32 * CG * kLd];
+  __shared__ __attribute__((aligned(16))) float sB[kRowsPerBlock * kLd];
+  __shared__ float s_inv[kRowsPerBlock];
+  __shared__ float s_red[kBlock / kWave];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int h = blockIdx.y;
+  const int64_t row0 = static_cast<int64_t>(blockIdx.x) * kRowsPerBlock;
+  const int64_t HD = static_cast<int64_t>(H) * Dc;
+  const int nvec = Dc / 4;
+  const float* xph = xp + h * Dc;
+  const float* emb = embed + static_cast<int64_t>(h) * K * Dc;
+
+  // ---- prologue: row norms of this tile (2 lanes... one half-wave per row, 8 rows per pass)
+  {
+    const int sub = tid & 31, rsel = tid >> 5;  // 8 half-waves
+    for (int r = rsel; r < kRowsPerBlock; r += 8) {
+      const int64_t row = row0 + r;
+      float ss = 0.f;
+      if (row < N) {
+        const float* p = xph + row * HD;
+        for (int c = sub; c < nvec; c += 32) {
+          const float4 v = ld4(p + 4 * c);
+          ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
+      }
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 32);
+      if (sub == 0) {
+        const float nrm = sqrtf(ss);
+        s_inv[r] = row < N ? 1.0f / fmaxf(nrm, kNormEps) : 0.f;
+        if (row < N) norm_out[row * H + h] = nrm;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- main loop over code groups x k-chunks, register-prefetched staging
+  const int kchunks = (Dc + kKC - 1) / kKC;
+  const int groups = (K + 32 * CG - 1) / (32 * CG);
+  const int steps = groups * kchunks;
+
+  float4 ra[CG], rb[4];
+  auto fetch = [&](int step) {
+    const int g = step / kchunks, kc = step % kchunks;
+    const int k0 = kc * kKC;
+    // A: 32*CG code rows x 32 floats = CG*256 float4 -> CG per thread
+#pragma unroll
+    for (int t = 0; t < CG; ++t) {
+      const int idx = t * kBlock + tid;      // float4 index in the chunk
+      const int cr = idx >> 3, cc = idx & 7; // 8 float4 per row
+      const int code = g * 32 * CG + cr;
+      const int k = k0 + 4 * cc;
+      ra[t] = (code < K && k < Dc) ? ld4(emb + static_cast<int64_t>(code) * Dc + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // B: 128 data rows x 32 floats = 1024 float4 -> 4 per thread, scaled by 1/norm
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int idx = t * kBlock + tid;
+      const int r = idx >> 3, cc = idx & 7;
+      const int64_t row = row0 + r;
+      const int k = k0 + 4 * cc;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < N && k < Dc) v = ld4(xph + row * HD + k);
+      rb[t] = v;
+    }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int t = 0; t < CG; ++t) {
+      const int idx = t * kBlock + tid;
+      st4(sA + (idx >> 3) * kLd + 4 * (idx & 7), ra[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int idx = t * kBlock + tid;
+      const int r = idx >> 3;
+      const float s = s_inv[r];
+      st4(sB + r * kLd + 4 * (idx & 7), make_float4(rb[t].x * s, rb[t].y * s, rb[t].z * s, rb[t].w * s));
+    }
+  };
+
+  float best_val = -INFINITY;
+  int best_idx = 0;
+  const int hi = lane >> 5, lj = lane & 31;
+  floatx16 acc[CG];
+
+  fetch(0);
+  for (int step = 0; step < steps; ++step) {
+    const int g = step / kchunks, kc = step % kchunks;
+    if (kc == 0) {
+#pragma unroll
+      for (int t = 0; t < CG; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    }
+    stash();
+    __syncthreads();
+    if (step + 1 < steps) fetch(step + 1);
+    // 4 micro-steps of 8 k each: half 0 takes k 0..3, half 1 takes k 4..7 of the micro-step
+#pragma unroll
+    for (int ms = 0; ms < kKC / 8; ++ms) {
+      const int ko = ms * 8 + hi * 4;
+      const float4 b = ld4(sB + (wave * 32 + lj) * kLd + ko);
+      float4 a[CG];
+#pragma unroll
+      for (int t = 0; t < CG; ++t) a[t] = ld4(sA + (t * 32 + lj) * kLd + ko);
+#pragma unroll
+      for (int t = 0; t < CG; ++t) {
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].x, b.x, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].y, b.y, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].z, b.z, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].w, b.w, acc[t], 0, 0, 0);
+      }
+    }
+    if (kc == kchunks - 1) {
+      // running arg-max: codes ascend with (t, r) inside a lane; strict '>' keeps the lowest index
+#pragma unroll
+      for (int t = 0; t < CG; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int code = g * 32 * CG + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          const float v = acc[t][r];
+          if (code < K && v > best_val) { best_val = v; best_idx = code; }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // combine the two lane halves (same data row, disjoint code subsets)
+  {
+    const float ov = __shfl_xor(best_val, 32, 64);
+    const int oi = __shfl_xor(best_idx, 32, 64);
+    if (ov > best_val || (ov == best_val && oi < best_idx)) { best_val = ov; best_idx = oi; }
+  }
+  if (hi == 0) {
+    const int64_t row = row0 + wave * 32 + lj;
+    if (row < N) ind_out[row * H + h] = static_cast<int64_t>(best_idx);
+  }
+
+  // ---- epilogue: gather the winning code rows, straight-through value, commitment partial
+  float sq = 0.f;
+  for (int it = 0; it * 64 < 32 * nvec; ++it) {  // wave-uniform trip count: every lane takes part in the shuffle
+    const int idx = it * 64 + lane;
+    const int r = idx / nvec, c = idx - r * nvec;
+    const int code = __shfl(best_idx, r & 31, 64);
+    const int64_t row = row0 + wave * 32 + r;
+    if (r < 32 && row < N) {
+      const float s = s_inv[wave * 32 + r];
+      const float4 xv = ld4(xph + row * HD + 4 * c);
+      const float4 q = ld4(emb + static_cast<int64_t>(code) * Dc + 4 * c);
+      const float4 n = make_float4(xv.x * s, xv.y * s, xv.z * s, xv.w * s);
+      const float4 d = make_float4(q.x - n.x, q.y - n.y, q.z - n.z, q.w - n.w);
+      sq += d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
+      float4 o = q;
+      if (training) o = make_float4(n.x + d.x, n.y + d.y, n.z + d.z, n.w + d.w);  // x + (q - x), vq.py:937
+      st4(quant + row * HD + h * Dc + 4 * c, o);
+      if (xn_out) st4(xn_out + row * HD + h * Dc + 4 * c, n);
+    }
+  }
+  sq = wave_sum(sq);
+  if (lane == 0) s_red[wave] = sq;
+  __syncthreads();
+  if (tid == 0) {
+    float t = 0.f;
+    for (int w = 0; w < kBlock / kWave; ++w) t += s_red[w];
+    sq_partial[static_cast<int64_t>(blockIdx.y) * gridDim.x + blockIdx.x] = t;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) k_sum_partials(const float* __restrict__ partial, int64_t n,
+                                                         float* __restrict__ out) {
+  __shared__ double red[kBlock];
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += kBlock) s += partial[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = kBlock / 2; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = static_cast<float>(red[0]);
+}
+
+// Backward: one G-lane group per (row, head).
+template <int G>
+__global__ void __launch_bounds__(kBlock)
+k_vq_assign_bwd(const float* __restrict__ g_quant, const float* __restrict__ g_loss, float coef,
+                const float* __restrict__ xp, const float* __restrict__ norm, const int64_t* __restrict__ ind,
+                const float* __restrict__ embed, int64_t N, int H, int Dc, int K, float* __restrict__ g_xp) {
+  constexpr int kGroups = kBlock / G;
+  const int lane = threadIdx.x % G;
+  const int64_t item = static_cast<int64_t>(blockIdx.x) * kGroups + threadIdx.x / G;  // row * H + h
+  if (item >= N * H) return;
+  const int64_t row = item / H;
+  const int h = static_cast<int>(item - row * H);
+  const int nvec = Dc / 4;
+  const int64_t off = row * static_cast<int64_t>(H) * Dc + static_cast<int64_t>(h) * Dc;
+  const float nrm = norm[item];
+  const bool clamped = nrm < kNormEps;
+  const float inv = 1.0f / fmaxf(nrm, kNormEps);
+  const float s = g_loss ? g_loss[0] * coef : 0.f;
+  int64_t code = ind[item];
+  if (code < 0 || code >= K) code = 0;
+  const float* q = embed + (static_cast<int64_t>(h) * K + code) * Dc;
+  float dot = 0.f;
+  for (int c = lane; c < nvec; c += G) {
+    const float4 xv = ld4(xp + off + 4 * c), gq = ld4(g_quant + off + 4 * c), qv = ld4(q + 4 * c);
+    const float4 n = make_float4(xv.x * inv, xv.y * inv, xv.z * inv, xv.w * inv);
+    const float4 gx = make_float4(gq.x + s * (n.x - qv.x), gq.y + s * (n.y - qv.y), gq.z + s * (n.z - qv.z),
+                                  gq.w + s * (n.w - qv.w));
+    dot += gx.x * n.x + gx.y * n.y + gx.z * n.z + gx.w * n.w;
+  }
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) dot += __shfl_xor(dot, o, G);
+  if (clamped) dot = 0.f;  // x / eps branch of F.normalize: plain scaling
+  for (int c = lane; c < nvec; c += G) {
+    const float4 xv = ld4(xp + off + 4 * c), gq = ld4(g_quant + off + 4 * c), qv = ld4(q + 4 * c);
+    const float4 n = make_float4(xv.x * inv, xv.y * inv, xv.z * inv, xv.w * inv);
+    const float4 gx = make_float4(gq.x + s * (n.x - qv.x), gq.y + s * (n.y - qv.y), gq.z + s * (n.z - qv.z),
+                                  gq.w + s * (n.w - qv.w));
+    st4(g_xp + off + 4 * c, make_float4((gx.x - n.x * dot) * inv, (gx.y - n.y * dot) * inv,
+                                        (gx.z - n.z * dot) * inv, (gx.w - n.w * dot) * inv));
+  }
+}
+
+// ---- K10 helpers -----------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_code_keys(const int64_t* __restrict__ ind, int64_t NH, int H, int K,
+                                                      int32_t* __restrict__ keys) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= NH) return;
+  const int h = static_cast<int>(i % H);
+  int64_t c = ind[i];
+  keys[i] = (c >= 0 && c < K) ? static_cast<int32_t>(h * K + c) : static_cast<int32_t>(H) * K;  // invalid -> sentinel
+}
+
+// One half-wave per (head, code) segment: ordered sum of the member rows' normalised vectors.
+__global__ void __launch_bounds__(kBlock)
+k_code_sums(const float* __restrict__ xp, const float* __restrict__ norm, const int32_t* __restrict__ rowptr,
+            const int32_t* __restrict__ perm, int H, int Dc, int K, float* __restrict__ bins,
+            float* __restrict__ embed_sum) {
+  constexpr int G = 32;
+  const int lane = threadIdx.x % G;
+  const int seg = blockIdx.x * (kBlock / G) + threadIdx.x / G;
+  if (seg >= H * K) return;
+  const int h = seg / K;
+  const int nvec = Dc / 4;
+  const int beg = rowptr[seg], end = rowptr[seg + 1];
+  if (lane == 0) bins[seg] = static_cast<float>(end - beg);
+  for (int c = lane; c < nvec; c += G) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = beg; s < end; ++s) {
+      const int item = perm[s];  // row * H + h
+      const int64_t row = item / H;
+      const float inv = 1.0f / fmaxf(norm[item], kNormEps);
+      const float4 v = ld4(xp + row * static_cast<int64_t>(H) * Dc + static_cast<int64_t>(h) * Dc + 4 * c);
+      acc.x += v.x * inv; acc.y += v.y * inv; acc.z += v.z * inv; acc.w += v.w * inv;
+    }
+    st4(embed_sum + static_cast<int64_t>(seg) * Dc + 4 * c, acc);
+  }
+}
+
+inline bool vq_dims_ok(int64_t N, int64_t H, int64_t Dc, int64_t K) {
+  return N >= 0 && H > 0 && H <= 65535 && Dc > 0 && Dc % 4 == 0 && Dc <= 4096 && K > 0 && K <= 65536;
+}
+
+inline int64_t row_blocks(int64_t N) { return (N + kRowsPerBlock - 1) / kRowsPerBlock; }
+
+}  // namespace
+}  // namespace stemgnn
+
+using namespace stemgnn;
+
+extern "C" {
+
+size_t stemgnn_vq_workspace_bytes(int64_t N, int64_t H, int64_t Dc, int64_t K) {
+  if (!vq_dims_ok(N, H, Dc, K)) return 0;
+  return static_cast<size_t>(row_blocks(N < 1 ? 1 : N) * H) * sizeof(float) + 512;
+}
+
+int stemgnn_vq_assign_fwd(const float* xp, int64_t N, int64_t H, int64_t Dc, const float* embed, int64_t K,
+                          int training, float* xn, float* norm, int64_t* ind, float* quant, float* sqerr,
+                          void* workspace, size_t workspace_bytes, void* stream_) {
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  if (!vq_dims_ok(N, H, Dc, K)) return STEMGNN_ERR_INVALID_ARG;
+  if (!fits_i32(N) || !fits_i32(N * H)) return STEMGNN_ERR_TOO_LARGE;
+  if (!sqerr) return STEMGNN_ERR_INVALID_ARG;
+  if (N == 0) {
+    STEMGNN_HIP_TRY(hipMemsetAsync(sqerr, 0, sizeof(float), st));
+    return STEMGNN_OK;
+  }
+  if (!xp || !embed || !norm || !ind || !quant || !workspace) return STEMGNN_ERR_INVALID_ARG;
+  if (workspace_bytes < stemgnn_vq_workspace_bytes(N, H, Dc, K)) return STEMGNN_ERR_WORKSPACE;
+  float* partial = reinterpret_cast<float*>(align_up(reinterpret_cast<uintptr_t>(workspace), 256));
+  const int64_t rb = row_blocks(N);
+  dim3 grid(static_cast<unsigned>(rb), static_cast<unsigned>(H));
+  const int Hi = static_cast<int>(H), Dci = static_cast<int>(Dc), Ki = static_cast<int>(K);
+  if (K <= 32)
+    k_vq_assign<1><<<grid, kBlock, 0, st>>>(xp, N, Hi, Dci, embed, Ki, training, xn, norm, ind, quant, partial);
+  else if (K <= 64)
+    k_vq_assign<2><<<grid, kBlock, 0, st>>>(xp, N, Hi, Dci, embed, Ki, training, xn, norm, ind, quant, partial);
+  else
+    k_vq_assign<4><<<grid, kBlock, 0, st>>>(xp, N, Hi, Dci, embed, Ki, training, xn, norm, ind, quant, partial);
+  STEMGNN_LAUNCH_CHECK();
+  k_sum_partials<<<1, kBlock, 0, st>>>(partial, rb * H, sqerr);
+  STEMGNN_LAUNCH_CHECK();
+  return STEMGNN_OK;
+}
+
+int stemgnn_vq_assign_bwd(const float* g_quant, const float* g_loss, float commit_weight, const float* xp,
+                          const float* norm, const int64_t* ind, const float* embed, int64_t N, int64_t H,
+                          int64_t Dc, int64_t K, float* g_xp, void* stream_) {
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  if (!vq_dims_ok(N, H, Dc, K)) return STEMGNN_ERR_INVALID_ARG;
+  if (!fits_i32(N * H)) return STEMGNN_ERR_TOO_LARGE;
+  if (N == 0) return STEMGNN_OK;
+  if (!g_quant || !xp || !norm || !ind || !embed || !g_xp) return STEMGNN_ERR_INVALID_ARG;
+  // d/dxn of commit_weight * mean((q - xn)^2) = commit_weight * 2 (xn - q) / (N*H*Dc)
+  const float coef = commit_weight * 2.0f / static_cast<float>(static_cast<double>(N) * H * Dc);
+  const int64_t items = N * H;
+  if (Dc / 4 <= 32) {
+    const int groups = kBlock / 32;
+    k_vq_assign_bwd<32><<<static_cast<unsigned>((items + groups - 1) / groups), kBlock, 0, st>>>(
+        g_quant, g_loss, coef, xp, norm, ind, embed, N, static_cast<int>(H), static_cast<int>(Dc),
+        static_cast<int>(K), g_xp);
+  } else {
+    const int groups = kBlock / 64;
+    k_vq_assign_bwd<64><<<static_cast<unsigned>((items + groups - 1) / groups), kBlock, 0, st>>>(
+        g_quant, g_loss, coef, xp, norm, ind, embed, N, static_cast<int>(H), static_cast<int>(Dc),
+        static_cast<int>(K), g_xp);
+  }
+  STEMGNN_LAUNCH_CHECK();
+  return STEMGNN_OK;
+}
+
+size_t stemgnn_vq_ema_workspace_bytes(int64_t N, int64_t H, int64_t Dc, int64_t K) {
+  if (!vq_dims_ok(N, H, Dc, K)) return 0;
+  const int64_t items = (N < 1 ? 1 : N) * H;
+  size_t keys = align_up(static_cast<size_t>(items) * sizeof(int32_t), 256);
+  size_t rowptr = align_up(static_cast<size_t>(H * K + 2) * sizeof(int32_t), 256);
+  return 2 * keys + rowptr + stemgnn_csr_workspace_bytes(H * K, items) + 512;
+}
+
+int stemgnn_vq_ema_stats(const float* xp, const float* norm, const int64_t* ind, int64_t N, int64_t H, int64_t Dc,
+                         int64_t K, float* bins, float* embed_sum, void* workspace, size_t workspace_bytes,
+                         void* stream_) {
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  if (!vq_dims_ok(N, H, Dc, K) || !bins || !embed_sum) return STEMGNN_ERR_INVALID_ARG;
+  if (!fits_i32(N * H) || !fits_i32(H * K)) return STEMGNN_ERR_TOO_LARGE;
+  if (N == 0) {
+    STEMGNN_HIP_TRY(hipMemsetAsync(bins, 0, sizeof(float) * H * K, st));
+    STEMGNN_HIP_TRY(hipMemsetAsync(embed_sum, 0, sizeof(float) * H * K * Dc, st));
+    return STEMGNN_OK;
+  }
+  if (!xp || !norm || !ind || !workspace) return STEMGNN_ERR_INVALID_ARG;
+  if (workspace_bytes < stemgnn_vq_ema_workspace_bytes(N, H, Dc, K)) return STEMGNN_ERR_WORKSPACE;
+  const int64_t items = N * H;
+  uintptr_t base = align_up(reinterpret_cast<uintptr_t>(workspace), 256);
+  size_t keys_b = align_up(static_cast<size_t>(items) * sizeof(int32_t), 256);
+  size_t rowptr_b = align_up(static_cast<size_t>(H * K + 2) * sizeof(int32_t), 256);
+  int32_t* keys = reinterpret_cast<int32_t*>(base);
+  int32_t* perm = reinterpret_cast<int32_t*>(base + keys_b);
+  int32_t* rowptr = reinterpret_cast<int32_t*>(base + 2 * keys_b);
+  void* sort_ws = reinterpret_cast<void*>(base + 2 * keys_b + rowptr_b);
+  size_t sort_ws_bytes = workspace_bytes - (base - reinterpret_cast<uintptr_t>(workspace)) - 2 * keys_b - rowptr_b;
+  k_code_keys<<<static_cast<unsigned>((items + kBlock - 1) / kBlock), kBlock, 0, st>>>(ind, items, static_cast<int>(H),
+                                                                                       static_cast<int>(K), keys);
+  STEMGNN_LAUNCH_CHECK();
+  int rc = stemgnn_group_by_key(keys, items, H * K, rowptr, perm, sort_ws, sort_ws_bytes, stream_);
+  if (rc != STEMGNN_OK) return rc;
+  const int segs = static_cast<int>(H * K);
+  k_code_sums<<<(segs + 7) / 8, kBlock, 0, st>>>(xp, norm, rowptr, perm, static_cast<int>(H), static_cast<int>(Dc),
+                                                 static_cast<int>(K), bins, embed_sum);
+  STEMGNN_LAUNCH_CHECK();
+  return STEMGNN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,370 @@
+"""Encoder-side modules with the reference's class names, constructor signatures, forward
+signatures and state-dict keys (reference STEM-GNN/model/encoder.py), computing through the
+gfx950 HIP kernels.
+
+    MySAGEConv            encoder.py:17-106
+    MixtureSageLayer      encoder.py:109-129
+    Encoder               encoder.py:132-333
+    InnerProductDecoder   encoder.py:336-380
+
+``edge_index`` may be the reference's int64 [2, E] tensor or a prebuilt
+``stem_gnn_amd.graph.GraphStructure``; ``edge_attr`` may be the reference's dense [E, D]
+tensor, ``None``, or an ``EdgeTypeAttr`` (type table + per-edge type id) which keeps the
+[E, D] expansion out of HBM.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Tuple, Union
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch import Tensor
+
+from .. import ops
+from ..graph import EdgeTypeAttr, GraphStructure, as_graph
+
+EdgeAttr = Union[Tensor, EdgeTypeAttr, None]
+
+
+def _pyg_linear_reset(lin: nn.Linear) -> None:
+    """torch_geometric.nn.dense.linear.Linear.reset_parameters with the default initialisers
+    (PyG 2.3.0): weight ~ U(-1/sqrt(fan_in), 1/sqrt(fan_in)) (kaiming_uniform, a=sqrt(5)),
+    bias ~ U(-1/sqrt(fan_in), 1/sqrt(fan_in))."""
+    bound = 1.0 / math.sqrt(lin.in_features) if lin.in_features > 0 else 0.0
+    with torch.no_grad():
+        lin.weight.uniform_(-bound, bound)
+        if lin.bias is not None:
+            lin.bias.uniform_(-bound, bound)
+
+
+def _split_edge_attr(edge_attr: EdgeAttr):
+    """-> (dense [E, D] or None, type table or None, type ids or None)"""
+    if edge_attr is None:
+        return None, None, None
+    if isinstance(edge_attr, EdgeTypeAttr):
+        return None, edge_attr.table, edge_attr.etype
+    return edge_attr.contiguous(), None, None
+
+
+def aggregate(x: Tensor, edge_index, edge_attr: EdgeAttr = None, num_nodes: Optional[int] = None) -> Tensor:
+    """mean_{j->i} relu(x_j + xe_ji): MySAGEConv.propagate/message (encoder.py:82,94-97)."""
+    n = x.size(0) if num_nodes is None else num_nodes
+    dense, etab, etype = _split_edge_attr(edge_attr)
+    graph = as_graph(edge_index, n, etype)
+    if dense is not None and dense.requires_grad:
+        raise NotImplementedError("edge_attr is data in the reference path; gradients w.r.t. it are not provided")
+    return ops.SageAggFn.apply(x, graph, dense, etab)
+
+
+class MySAGEConv(nn.Module):
+    """out = lin_l(mean_{j->i} relu(x_j + xe_ji)) + lin_r(x_i)  (encoder.py:72-92).
+
+    Only the configuration the reference instantiates is supported (encoder.py:193:
+    aggr='mean', normalize=False, root_weight=True, project=False)."""
+
+    def __init__(self, in_channels: Union[int, Tuple[int, int]], out_channels: int, aggr: Optional[str] = "mean",
+                 normalize: bool = False, root_weight: bool = True, project: bool = False, bias: bool = True,
+                 **kwargs):
+        super().__init__()
+        if aggr != "mean":
+            raise NotImplementedError("MySAGEConv: only aggr='mean' (the reference's setting) is implemented")
+        if project:
+            raise NotImplementedError("MySAGEConv: project=True is never used by the reference")
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.normalize = normalize
+        self.root_weight = root_weight
+        self.project = project
+        self.aggr = aggr
+        if isinstance(in_channels, int):
+            in_channels = (in_channels, in_channels)
+        self.lin_l = nn.Linear(in_channels[0], out_channels, bias=bias)
+        if self.root_weight:
+            self.lin_r = nn.Linear(in_channels[1], out_channels, bias=False)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        _pyg_linear_reset(self.lin_l)
+        if self.root_weight:
+            _pyg_linear_reset(self.lin_r)
+
+    def forward(self, x: Union[Tensor, Tuple[Tensor, Optional[Tensor]]], edge_index, edge_attr: EdgeAttr = None,
+                size=None) -> Tensor:
+        if isinstance(x, Tensor):
+            x = (x, x)
+        if size is not None and (size[0] != size[1] or size[0] != x[0].size(0)):
+            raise NotImplementedError("bipartite propagation is not used by the reference path")
+        out = aggregate(x[0], edge_index, edge_attr)
+        out = self.lin_l(out)
+        x_r = x[1]
+        if self.root_weight and x_r is not None:
+            out = out + self.lin_r(x_r)
+        if self.normalize:
+            out = F.normalize(out, p=2.0, dim=-1)
+        return out
+
+    def __repr__(self) -> str:
+        return f"{self.__class__.__name__}({self.in_channels}, {self.out_channels}, aggr={self.aggr})"
+
+
+class MixtureSageLayer(nn.Module):
+    """K-expert SAGE layer (encoder.py:109-129).  NOTE the reversed direction: row =
+    edge_index[0] receives the mean of x[col] with no edge term and no relu (encoder.py:123-124),
+    i.e. the mean aggregation over the transposed graph without edge attributes."""
+
+    def __init__(self, in_dim: int, out_dim: int, num_experts: int, residual: bool = True):
+        super().__init__()
+        self.in_dim, self.out_dim, self.num_experts = in_dim, out_dim, num_experts
+        self.residual = residual and (in_dim == out_dim)
+        self.weights = nn.Parameter(torch.empty(num_experts, in_dim * 2, out_dim))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        nn.init.xavier_uniform_(self.weights)
+
+    def forward(self, x: Tensor, edge_index, edge_attr: EdgeAttr = None) -> Tensor:
+        ei = edge_index.edge_index if isinstance(edge_index, GraphStructure) else edge_index
+        flipped = _flipped_graph(ei, x.size(0))
+        # scatter_mean(x[col], row) == mean aggregation of relu-free messages over the flipped graph;
+        # x >= 0 is not guaranteed, so the relu-free form is obtained as mean(relu(x)) - mean(relu(-x)).
+        agg = ops.SageAggFn.apply(x, flipped, None, None) - ops.SageAggFn.apply(-x, flipped, None, None)
+        combined = torch.cat([agg, x], dim=-1)
+        outputs = torch.einsum("nd,kdo->nko", combined, self.weights)
+        if self.residual:
+            outputs = outputs + x.unsqueeze(1)
+        return outputs
+
+
+def _flipped_graph(edge_index: Tensor, num_nodes: int) -> GraphStructure:
+    cache = getattr(edge_index, "_stemgnn_flipped", None)
+    if cache is not None and cache[0] == edge_index._version and cache[1].num_nodes == num_nodes:
+        return cache[1]
+    g = GraphStructure(edge_index.flip(0).contiguous(), num_nodes)
+    try:
+        edge_index._stemgnn_flipped = (edge_index._version, g)
+    except AttributeError:
+        pass
+    return g
+
+
+class Encoder(nn.Module):
+    """Layer stack + BatchNorm1d + activation + dropout (+ optional soft MoE routing)
+    (encoder.py:132-333).  backbone='sage' only: the other backbones are stock PyG layers the
+    reference never selects by default (config/pretrain.yaml:5)."""
+
+    def __init__(self, input_dim, hidden_dim, activation, num_layers, backbone="sage", normalize="none",
+                 dropout=0.0, moe=False, num_experts=3, tau=1.0, moe_layers="all"):
+        super().__init__()
+        if backbone != "sage":
+            raise NotImplementedError(f"backbone={backbone!r}: only 'sage' is implemented on the HIP path")
+        self.input_dim = input_dim
+        self.hidden_dim = hidden_dim
+        self.num_layers = num_layers
+        self.backbone = backbone
+        self.normalize = normalize
+        self.moe = moe and num_experts > 1
+        self.num_experts = num_experts
+        self.tau = tau
+        self.moe_layers = moe_layers
+
+        self.activation = activation()
+        if isinstance(self.activation, nn.ReLU):
+            self._act_code, self._slope = 1, 0.0
+        elif isinstance(self.activation, nn.LeakyReLU):
+            self._act_code, self._slope = 1, float(self.activation.negative_slope)
+        else:
+            raise NotImplementedError("activation must be nn.ReLU or nn.LeakyReLU (reference pretrain.py:85)")
+        self.layers = nn.ModuleList()
+        self.norms = nn.ModuleList()
+        self.dropout = nn.Dropout(dropout)
+        self.env_encoders = nn.ModuleList()
+        self._last_env_reg: Optional[Tensor] = None
+        self._moe_usage: Optional[list] = None
+        self._router_cache: Optional[list] = None
+        self._cache_router = False
+        self.last_dropout_keys: List[Tuple[int, int]] = []  # (seed, offset) per fused dropout of the last call
+
+        self.moe_layer_flags = self._build_moe_layer_flags()
+        dims = [input_dim] + [hidden_dim] * num_layers
+        for layer_idx, (in_dim, out_dim) in enumerate(zip(dims[:-1], dims[1:])):
+            if self.moe_layer_flags[layer_idx]:
+                self.layers.append(MixtureSageLayer(in_dim, out_dim, self.num_experts, residual=True))
+                self.env_encoders.append(nn.Linear(in_dim, self.num_experts))
+            else:
+                self.layers.append(self._build_conv(in_dim, out_dim))
+            self.norms.append(nn.BatchNorm1d(out_dim))
+        self.reset_parameters()
+
+    def _build_moe_layer_flags(self):
+        if not self.moe:
+            return [False] * self.num_layers
+        if self.moe_layers == "all":
+            return [True] * self.num_layers
+        if self.moe_layers == "last":
+            flags = [False] * self.num_layers
+            if self.num_layers > 0:
+                flags[-1] = True
+            return flags
+        if self.moe_layers == "none":
+            return [False] * self.num_layers
+        raise ValueError(f"Unsupported moe_layers setting: {self.moe_layers}")
+
+    def _build_conv(self, in_dim, out_dim):
+        return MySAGEConv(in_dim, out_dim, aggr="mean", normalize=False, root_weight=True)
+
+    def _reg_loss(self, weights, logits):
+        log_pi = logits - torch.logsumexp(logits, dim=-1, keepdim=True)
+        return torch.mean(torch.sum(weights * log_pi, dim=-1))
+
+    def reset_parameters(self):
+        for layer in self.layers:
+            layer.reset_parameters()
+        for norm in self.norms:
+            norm.reset_parameters()
+        for enc in self.env_encoders:
+            enc.reset_parameters()
+        self._last_env_reg = None
+        self._moe_usage = None
+
+    # -- router bookkeeping (encoder.py:219-277) ------------------------------------------
+    def enable_router_cache(self, flag: bool = True):
+        self._cache_router = flag
+        self._router_cache = [] if flag else None
+
+    def get_router_cache(self, reset: bool = True):
+        out = self._router_cache or []
+        if reset:
+            self._router_cache = [] if self._cache_router else None
+        return out
+
+    def _update_moe_usage(self, env_idx, weights):
+        weights = weights.detach()
+        if self._moe_usage is None:
+            self._moe_usage = [{"sum_prob": torch.zeros(self.num_experts, device=weights.device, dtype=weights.dtype),
+                                "sum_top1": torch.zeros(self.num_experts, device=weights.device, dtype=weights.dtype),
+                                "count": 0} for f in self.moe_layer_flags if f]
+        stats = self._moe_usage[env_idx]
+        stats["sum_prob"] += weights.sum(dim=0)
+        top1 = F.one_hot(weights.argmax(dim=-1), num_classes=self.num_experts).type_as(weights)
+        stats["sum_top1"] += top1.sum(dim=0)
+        stats["count"] += weights.size(0)
+
+    def get_moe_usage(self, reset=True):
+        if not self.moe or self._moe_usage is None:
+            return []
+        usage, env_idx = [], 0
+        for layer_idx, flag in enumerate(self.moe_layer_flags):
+            if not flag:
+                continue
+            stats = self._moe_usage[env_idx]
+            denom = max(stats["count"], 1)
+            usage.append({"layer": layer_idx,
+                          "avg_prob": (stats["sum_prob"] / denom).detach().cpu().tolist(),
+                          "top1_frac": (stats["sum_top1"] / denom).detach().cpu().tolist()})
+            env_idx += 1
+        if reset:
+            self._moe_usage = None
+        return usage
+
+    # -- forward --------------------------------------------------------------------------
+    def forward(self, x, edge_index, edge_attr=None):
+        return self.encode(x, edge_index, edge_attr)
+
+    def _norm_act_drop(self, i: int, z: Tensor, last: bool) -> Tensor:
+        """norms[i] -> activation -> dropout (encoder.py:313-317) as ONE fused op."""
+        use_bn = self.normalize != "none"
+        norm = self.norms[i]
+        act = 0 if last else self._act_code
+        p = 0.0 if (last or not self.training) else float(self.dropout.p)
+        if use_bn and not self.training:
+            # eval-mode BN uses running statistics: a per-column affine map, done with torch ops
+            z = F.batch_norm(z, norm.running_mean, norm.running_var, norm.weight, norm.bias, False, 0.0, norm.eps)
+            use_bn = False
+        if not use_bn and act == 0 and p == 0.0:
+            return z
+        seed, offset = (0, 0)
+        if p > 0.0:
+            seed, offset = ops.next_dropout_key()
+            self.last_dropout_keys.append((seed, offset))
+        if use_bn:
+            momentum = norm.momentum
+            if norm.track_running_stats:
+                norm.num_batches_tracked.add_(1)
+                if momentum is None:
+                    momentum = 1.0 / float(norm.num_batches_tracked)
+            rm = norm.running_mean if norm.track_running_stats else None
+            rv = norm.running_var if norm.track_running_stats else None
+            return ops.BnActDropFn.apply(z, norm.weight, norm.bias, rm, rv, True, momentum, norm.eps, act,
+                                         self._slope, p, seed, offset)
+        return ops.BnActDropFn.apply(z, None, None, None, None, False, 0.0, 0.0, act, self._slope, p, seed, offset)
+
+    def encode(self, x, edge_index, edge_attr=None):
+        z = x
+        env_idx = 0
+        env_reg_total: Optional[Tensor] = None
+        env_layers = 0
+        self._last_env_reg = None
+        self.last_dropout_keys = []
+        dense, etab, etype = _split_edge_attr(edge_attr)
+        graph = as_graph(edge_index, x.size(0), etype)  # one structure build shared by all layers
+
+        for i in range(self.num_layers):
+            layer = self.layers[i]
+            if isinstance(layer, MixtureSageLayer):
+                logits = self.env_encoders[env_idx](z)
+                if self.training:
+                    weights = F.gumbel_softmax(logits, tau=self.tau, dim=-1)
+                    reg = self._reg_loss(weights, logits)
+                    env_reg_total = reg if env_reg_total is None else env_reg_total + reg
+                    env_layers += 1
+                else:
+                    weights = F.softmax(logits, dim=-1)
+                if self._cache_router:
+                    if self._router_cache is None:
+                        self._router_cache = []
+                    self._router_cache.append(weights.detach())
+                self._update_moe_usage(env_idx, weights)
+                expert_outputs = layer(z, graph, edge_attr)
+                z = torch.sum(weights.unsqueeze(-1) * expert_outputs, dim=1)
+                env_idx += 1
+            else:
+                z = layer(z, graph, edge_attr)
+            z = self._norm_act_drop(i, z, last=(i == self.num_layers - 1))
+
+        if env_reg_total is not None and self.training and env_layers > 0:
+            self._last_env_reg = env_reg_total / env_layers
+        else:
+            self._last_env_reg = z.new_zeros(1)
+        return z
+
+    def get_env_reg(self, reset=True):
+        if self._last_env_reg is None:
+            reg = torch.zeros(1, device=next(self.parameters()).device)
+        else:
+            reg = self._last_env_reg
+        if reset:
+            self._last_env_reg = None
+        return reg
+
+
+class InnerProductDecoder(nn.Module):
+    """sigma(<lin(z)_u, lin(z)_v>) per edge (encoder.py:336-366)."""
+
+    def __init__(self, hidden_dim=None, output_dim=None):
+        super().__init__()
+        self.proj_z = False
+        if hidden_dim is not None:
+            self.proj_z = True
+            self.lin = nn.Linear(hidden_dim, output_dim)
+
+    def forward(self, z: Tensor, edge_index: Tensor, sigmoid: bool = True) -> Tensor:
+        z = self.lin(z) if self.proj_z else z
+        value = ops.EdgeDotFn.apply(z, edge_index)
+        return torch.sigmoid(value) if sigmoid else value
+
+    def forward_all(self, z: Tensor, sigmoid: bool = True) -> Tensor:
+        z = self.lin(z) if self.proj_z else z
+        adj = torch.matmul(z, z.t())
+        return torch.sigmoid(adj) if sigmoid else adj

@@ -1,0 +1,181 @@
+"""PretrainModel with the reference's interface (reference STEM-GNN/model/pt_model.py:11-142):
+encoder + vq + three decoders + EMA teacher (``sem_encoder``) + ``sem_projector``; the four
+reconstruction losses, the commitment loss and the MoE regulariser.
+
+Random draws inside ``forward`` (edge sub-sampling permutations, negative edges) are taken on
+the device and recorded in ``self.last_draws`` so a parity test can replay exactly the same
+step through the CPU oracle.  They can also be injected through ``draws=``.
+"""
+from __future__ import annotations
+
+from copy import deepcopy
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch import Tensor
+
+from .. import ops
+from ..graph import EdgeTypeAttr, GraphStructure
+from ..utils.graph_utils import negative_sampling
+
+EPS = 1e-15  # pt_model.py:8
+
+
+def _edge_index_of(ei) -> Tensor:
+    return ei.edge_index if isinstance(ei, GraphStructure) else ei
+
+
+def _flat_param_views(module: nn.Module):
+    """Re-home every parameter of `module` as a view into one flat fp32 buffer (so the teacher
+    EMA is a single kernel over contiguous memory).  Returns the flat buffer."""
+    params = list(module.parameters())
+    total = sum(p.numel() for p in params)
+    if total == 0:
+        return None
+    flat = torch.empty(total, dtype=params[0].dtype, device=params[0].device)
+    off = 0
+    for p in params:
+        n = p.numel()
+        flat[off:off + n].copy_(p.data.reshape(-1))
+        p.data = flat[off:off + n].view_as(p.data)
+        off += n
+    return flat
+
+
+class PretrainModel(nn.Module):
+    def __init__(self, encoder, vq, feat_recon_decoder, topo_recon_decoder, topo_sem_recon_decoder):
+        super().__init__()
+        self.encoder = encoder
+        self.vq = vq
+        self.feat_recon_decoder = feat_recon_decoder
+        self.topo_recon_decoder = topo_recon_decoder
+        self.topo_sem_recon_decoder = topo_sem_recon_decoder
+        self.sem_encoder = deepcopy(self.encoder)  # pt_model.py:22
+        self.sem_projector = nn.Linear(self.encoder.hidden_dim, self.encoder.hidden_dim)
+        self._flat_student: Optional[Tensor] = None
+        self._flat_teacher: Optional[Tensor] = None
+        self.last_draws: Dict[str, Tensor] = {}
+
+    @property
+    def get_encoder(self):
+        return self.encoder
+
+    @property
+    def get_vq(self):
+        return self.vq
+
+    def save_encoder(self, path):
+        torch.save(self.encoder.state_dict(), path)
+
+    def save_vq(self, path):
+        torch.save(self.vq.state_dict(), path)
+
+    # -- losses ---------------------------------------------------------------------------
+    def feat_recon(self, z):
+        return self.feat_recon_decoder(z)
+
+    def feat_recon_loss(self, z, x, bs=None):
+        return F.mse_loss(self.feat_recon(z[:bs]), x[:bs])  # pt_model.py:42-43
+
+    def _sample_edges(self, num_edges: int, ratio: float, device, key: str, draws) -> Optional[Tensor]:
+        """randperm(E)[:max(int(E*ratio),1)] (pt_model.py:51-57, 72-78), drawn on the device."""
+        if ratio == 1.0:
+            return None
+        if draws is not None and key in draws:
+            perm = draws[key]
+        else:
+            k = max(int(num_edges * ratio), 1)
+            perm = torch.randperm(num_edges, device=device)[:k]
+        self.last_draws[key] = perm
+        return perm
+
+    def topo_recon_loss(self, z, pos_edge_index, neg_edge_index=None, ratio=1.0, draws=None):
+        if ratio == 0.0:
+            return torch.tensor(0.0, device=z.device)
+        pos_edge_index = _edge_index_of(pos_edge_index)
+        perm = self._sample_edges(pos_edge_index.size(1), ratio, z.device, "topo_perm", draws)
+        if perm is not None:
+            pos_edge_index = pos_edge_index[:, perm]
+        if neg_edge_index is None:
+            if draws is not None and "neg_edge_index" in draws:
+                neg_edge_index = draws["neg_edge_index"]
+            else:
+                neg_edge_index = negative_sampling(pos_edge_index, z.size(0))  # pt_model.py:60
+        self.last_draws["neg_edge_index"] = neg_edge_index
+        pos_loss = -torch.log(self.topo_recon_decoder(z, pos_edge_index, sigmoid=True) + EPS).mean()
+        neg_loss = -torch.log(1 - self.topo_recon_decoder(z, neg_edge_index, sigmoid=True) + EPS).mean()
+        return pos_loss + neg_loss
+
+    def topo_sem_recon_loss(self, z, edge_index, edge_attr, ratio=1.0, draws=None):
+        if ratio == 0.0:
+            return torch.tensor(0.0, device=z.device)
+        edge_index = _edge_index_of(edge_index)
+        perm = self._sample_edges(edge_index.size(1), ratio, z.device, "topo_sem_perm", draws)
+        if perm is not None:
+            edge_index = edge_index[:, perm]
+            edge_attr = edge_attr[perm]
+        target = edge_attr.dense() if isinstance(edge_attr, EdgeTypeAttr) else edge_attr
+        zz = ops.EdgeConcatFn.apply(z, edge_index.contiguous())  # cat([z[u], z[v]]), pt_model.py:80
+        return F.mse_loss(self.topo_sem_recon_decoder(zz), target)
+
+    def sem_recon_loss(self, g, quantize, eta=1.0, bs=None):
+        orig_x, orig_edge_index, orig_edge_attr = g[0], g[1], g[2]
+        with torch.no_grad():  # .detach() in the reference (pt_model.py:93); teacher stays in train mode
+            z = self.sem_encoder(orig_x, orig_edge_index, orig_edge_attr)
+        h = self.sem_projector(quantize)
+        z = F.normalize(z[:bs], dim=-1, p=2)
+        h = F.normalize(h[:bs], dim=-1, p=2)
+        loss = (1 - (z * h).sum(dim=-1)).pow_(eta)
+        return loss.mean()
+
+    @torch.no_grad()
+    def ema_update_sem_encoder(self, decay=0.99):
+        """param_k = param_k * decay + param_q * (1 - decay) over encoder parameters
+        (pt_model.py:104-106), as one kernel over flat parameter buffers."""
+        if self._flat_student is None or not self._flat_ok():
+            self._flat_student = _flat_param_views(self.encoder)
+            self._flat_teacher = _flat_param_views(self.sem_encoder)
+        if self._flat_student is not None:
+            ops.ema_lerp_(self._flat_teacher, self._flat_student, decay)
+
+    def _flat_ok(self) -> bool:
+        """The flat views are stale if someone re-assigned .data (e.g. .to(device), load_state_dict
+        keeps them valid because it copies in place)."""
+        p = next(self.encoder.parameters(), None)
+        return p is None or (p.data_ptr() == self._flat_student.data_ptr() and p.device == self._flat_student.device)
+
+    def encode(self, x, edge_index, edge_attr=None):
+        return self.encoder(x, edge_index, edge_attr)
+
+    def quantize(self, x, edge_index, edge_attr=None):
+        z = self.encoder(x, edge_index, edge_attr)
+        quantize, indices, commit_loss, _ = self.vq(z)
+        return z, quantize, indices, commit_loss
+
+    def forward(self, aug_g, g, topo_recon_ratio=1.0, bs=None, no_codebook=False, draws=None):
+        x, edge_index, edge_attr = aug_g[0], aug_g[1], aug_g[2]
+        orig_x, orig_edge_index, orig_edge_attr = g[0], g[1], g[2]
+        self.last_draws = {}
+        z, quantize, indices, commit_loss = self.quantize(x, edge_index, edge_attr)
+        env_reg_loss = self.encoder.get_env_reg()
+        if no_codebook:
+            query = z
+            commit_loss = torch.tensor(0.0, device=z.device)
+        else:
+            query = quantize
+        feat_recon_loss = self.feat_recon_loss(query, orig_x, bs=bs)
+        topo_recon_loss = self.topo_recon_loss(query, orig_edge_index, ratio=topo_recon_ratio, draws=draws)
+        topo_sem_recon_loss = self.topo_sem_recon_loss(query, orig_edge_index, orig_edge_attr,
+                                                       ratio=topo_recon_ratio, draws=draws)
+        sem_recon_loss = self.sem_recon_loss(g, query, eta=1.0, bs=bs)
+        losses = {
+            "feat_recon_loss": feat_recon_loss,
+            "topo_recon_loss": topo_recon_loss,
+            "topo_sem_recon_loss": topo_sem_recon_loss,
+            "sem_recon_loss": sem_recon_loss,
+            "commit_loss": commit_loss,
+            "env_reg_loss": env_reg_loss,
+        }
+        return z, quantize, indices, losses

@@ -1,0 +1,369 @@
+"""Tensor-level wrappers over the C ABI (stem_gnn_amd/_lib.py) and the autograd Functions
+built on them.  PyTorch is plumbing here: device memory, the current HIP stream and
+autograd bookkeeping.  Every op requires CUDA (ROCm) tensors and raises otherwise; there
+is no eager/CPU fallback.
+"""
+from __future__ import annotations
+
+import threading
+from ctypes import c_void_p
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from ._lib import check, lib
+
+
+def _stream() -> c_void_p:
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: Optional[Tensor]) -> Optional[c_void_p]:
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def _req(t: Tensor, dtype, name: str, ndim: Optional[int] = None) -> Tensor:
+    if not isinstance(t, Tensor):
+        raise RuntimeError(f"{name}: expected a torch.Tensor, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a CUDA (ROCm) tensor; stem_gnn_amd has no CPU path")
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if ndim is not None and t.dim() != ndim:
+        raise RuntimeError(f"{name}: expected {ndim} dims, got shape {tuple(t.shape)}")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name}: expected a contiguous tensor")
+    if t.data_ptr() % 16 != 0 and t.numel() > 0:
+        raise RuntimeError(f"{name}: expected 16-byte aligned storage")
+    return t
+
+
+def _workspace(nbytes: int, device) -> Tensor:
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+# ----------------------------------------------------------------------------------------
+# dropout RNG keys: the keep mask is a pure function of (seed, offset, element index)
+# ----------------------------------------------------------------------------------------
+class _DropoutKeys(threading.local):
+    def __init__(self):
+        self.seed = None
+        self.counter = 0
+
+
+_keys = _DropoutKeys()
+
+
+def manual_seed(seed: int) -> None:
+    """Seed the Philox stream used by the fused dropout (and reset its call counter)."""
+    _keys.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    _keys.counter = 0
+
+
+def next_dropout_key() -> Tuple[int, int]:
+    if _keys.seed is None:
+        manual_seed(torch.initial_seed())
+    _keys.counter += 1
+    return _keys.seed, _keys.counter
+
+
+def dropout_keep_mask(n: int, p: float, seed: int, offset: int, device) -> Tensor:
+    """The boolean keep mask the fused BN/act/dropout kernels use for (seed, offset)."""
+    keep = torch.empty(n, dtype=torch.uint8, device=device)
+    check(lib.stemgnn_dropout_keep_mask(n, float(p), seed, offset, _p(keep), _stream()), "dropout_keep_mask")
+    return keep.bool()
+
+
+# ----------------------------------------------------------------------------------------
+# graph structure
+# ----------------------------------------------------------------------------------------
+def csr_build(edge_index: Tensor, num_nodes: int, key_row: int):
+    """int64 COO [2, E] -> (rowptr [N+1], other [E], eid [E], bad_count [1]) int32, grouped by
+    edge_index[key_row], stable in edge order."""
+    _req(edge_index, torch.int64, "edge_index", 2)
+    if edge_index.size(0) != 2:
+        raise RuntimeError(f"edge_index: expected shape [2, E], got {tuple(edge_index.shape)}")
+    E, N, dev = edge_index.size(1), int(num_nodes), edge_index.device
+    rowptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
+    other = torch.empty(E, dtype=torch.int32, device=dev)
+    eid = torch.empty(E, dtype=torch.int32, device=dev)
+    bad = torch.empty(1, dtype=torch.int32, device=dev)
+    nbytes = lib.stemgnn_csr_workspace_bytes(N, E)
+    ws = _workspace(nbytes, dev)
+    check(lib.stemgnn_csr_build(_p(edge_index), E, N, key_row, _p(rowptr), _p(other), _p(eid), _p(bad), _p(ws),
+                                ws.numel(), _stream()), "csr_build")
+    return rowptr, other, eid, bad
+
+
+def gather_i32(table: Tensor, index: Tensor) -> Tensor:
+    _req(table, torch.int32, "table", 1)
+    _req(index, torch.int32, "index", 1)
+    out = torch.empty_like(index)
+    check(lib.stemgnn_gather_i32(_p(table), _p(index), index.numel(), _p(out), _stream()), "gather_i32")
+    return out
+
+
+def inv_degree(rowptr: Tensor) -> Tensor:
+    _req(rowptr, torch.int32, "rowptr", 1)
+    n = rowptr.numel() - 1
+    out = torch.empty(n, dtype=torch.float32, device=rowptr.device)
+    check(lib.stemgnn_inv_degree(_p(rowptr), n, _p(out), _stream()), "inv_degree")
+    return out
+
+
+# ----------------------------------------------------------------------------------------
+# K1 / K2
+# ----------------------------------------------------------------------------------------
+def sage_agg_fwd(x: Tensor, graph, edge_attr: Optional[Tensor], etab: Optional[Tensor]) -> Tensor:
+    _req(x, torch.float32, "x", 2)
+    N, D = x.shape
+    if N != graph.num_nodes:
+        raise RuntimeError(f"x has {N} rows but the graph structure was built for {graph.num_nodes} nodes")
+    etype_slot = None
+    T = 0
+    if edge_attr is not None:
+        _req(edge_attr, torch.float32, "edge_attr", 2)
+        if tuple(edge_attr.shape) != (graph.num_edges, D):
+            raise RuntimeError(f"edge_attr: expected shape {(graph.num_edges, D)}, got {tuple(edge_attr.shape)}")
+    if etab is not None:
+        _req(etab, torch.float32, "edge_type_table", 2)
+        if etab.size(1) != D:
+            raise RuntimeError("edge_type_table: feature dim mismatch")
+        T = etab.size(0)
+        etype_slot = graph.etype_slot
+        if etype_slot is None:
+            raise RuntimeError("graph structure has no edge types; build it with edge_type=...")
+    agg = torch.empty_like(x)
+    check(lib.stemgnn_sage_agg_fwd(_p(x), N, D, _p(graph.rowptr), _p(graph.src), _p(graph.eid), _p(edge_attr),
+                                   _p(etab), _p(etype_slot), T, _p(agg), _stream()), "sage_agg_fwd")
+    return agg
+
+
+def sage_agg_bwd(g_agg: Tensor, x: Tensor, graph, edge_attr: Optional[Tensor], etab: Optional[Tensor]) -> Tensor:
+    _req(g_agg, torch.float32, "g_agg", 2)
+    N, D = x.shape
+    graph.ensure_transpose()
+    T = 0 if etab is None else etab.size(0)
+    g_x = torch.empty_like(x)
+    check(lib.stemgnn_sage_agg_bwd(_p(g_agg), _p(x), N, D, _p(graph.rowptr_t), _p(graph.dst_t), _p(graph.eid_t),
+                                   _p(graph.inv_deg), _p(edge_attr), _p(etab),
+                                   _p(graph.etype_slot_t if etab is not None else None), T, _p(g_x), _stream()),
+          "sage_agg_bwd")
+    return g_x
+
+
+class SageAggFn(torch.autograd.Function):
+    """agg = mean_{j->i} relu(x_j + ea_ji)  (reference model/encoder.py:82,94-97)."""
+
+    @staticmethod
+    def forward(ctx, x, graph, edge_attr, etab):
+        x = x.contiguous()
+        agg = sage_agg_fwd(x, graph, edge_attr, etab)
+        ctx.graph = graph
+        ctx.save_for_backward(x, edge_attr, etab)
+        return agg
+
+    @staticmethod
+    def backward(ctx, g_agg):
+        x, edge_attr, etab = ctx.saved_tensors
+        g_x = None
+        if ctx.needs_input_grad[0]:
+            g_x = sage_agg_bwd(g_agg.contiguous(), x, ctx.graph, edge_attr, etab)
+        return g_x, None, None, None
+
+
+# ----------------------------------------------------------------------------------------
+# K4
+# ----------------------------------------------------------------------------------------
+def bn_stats(y: Tensor, eps: float, running_mean: Optional[Tensor], running_var: Optional[Tensor],
+             momentum: float) -> Tuple[Tensor, Tensor]:
+    _req(y, torch.float32, "y", 2)
+    N, D = y.shape
+    mean = torch.empty(D, dtype=torch.float32, device=y.device)
+    rstd = torch.empty_like(mean)
+    ws = _workspace(lib.stemgnn_bn_workspace_bytes(N, D), y.device)
+    check(lib.stemgnn_bn_stats(_p(y), N, D, float(eps), _p(mean), _p(rstd), _p(running_mean), _p(running_var),
+                               float(momentum), _p(ws), ws.numel(), _stream()), "bn_stats")
+    return mean, rstd
+
+
+class BnActDropFn(torch.autograd.Function):
+    """dropout(act(batch_norm(y))) with training statistics (reference model/encoder.py:313-317)."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, running_mean, running_var, use_bn, momentum, eps, act, slope, p, seed, offset):
+        y = y.contiguous()
+        _req(y, torch.float32, "y", 2)
+        N, D = y.shape
+        mean = rstd = None
+        if use_bn:
+            if N <= 1:
+                raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(y.shape)}")
+            mean, rstd = bn_stats(y, eps, running_mean, running_var, momentum)
+        out = torch.empty_like(y)
+        g = gamma if use_bn else None
+        b = beta if use_bn else None
+        check(lib.stemgnn_bn_act_drop_fwd(_p(y), N, D, _p(mean), _p(rstd), _p(g), _p(b), int(act), float(slope),
+                                          float(p), seed, offset, _p(out), _stream()), "bn_act_drop_fwd")
+        ctx.save_for_backward(y, mean, rstd, g, b)
+        ctx.cfg = (int(act), float(slope), float(p), seed, offset)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        y, mean, rstd, gamma, beta = ctx.saved_tensors
+        act, slope, p, seed, offset = ctx.cfg
+        N, D = y.shape
+        g_out = g_out.contiguous()
+        g_y = torch.empty_like(y)
+        g_gamma = g_beta = None
+        ws = None
+        if mean is not None:
+            g_gamma = torch.empty_like(gamma)
+            g_beta = torch.empty_like(beta)
+            ws = _workspace(lib.stemgnn_bn_workspace_bytes(N, D), y.device)
+        check(lib.stemgnn_bn_act_drop_bwd(_p(g_out), _p(y), N, D, _p(mean), _p(rstd), _p(gamma), _p(beta), act, slope, p,
+                                          seed, offset, _p(g_y), _p(g_gamma), _p(g_beta), _p(ws),
+                                          0 if ws is None else ws.numel(), _stream()), "bn_act_drop_bwd")
+        return (g_y, g_gamma, g_beta) + (None,) * 10
+
+
+# ----------------------------------------------------------------------------------------
+# K6-K8, K10
+# ----------------------------------------------------------------------------------------
+class VqAssignFn(torch.autograd.Function):
+    """(quant, ind, mse) = cosine-codebook assignment of xp [N, H*Dc] against embed [H, K, Dc]
+    (reference model/vq.py:891, 650-657, 931-937, 1007).  mse = mean((q - xn)^2) carries the
+    commitment gradient; embed receives no gradient through this op (q is detached in the
+    reference: vq.py:931-937 with VectorQuantize.learnable_codebook == False)."""
+
+    @staticmethod
+    def forward(ctx, xp, embed, heads, training):
+        xp = xp.contiguous()
+        embed_c = embed.detach().contiguous()
+        _req(xp, torch.float32, "xp", 2)
+        _req(embed_c, torch.float32, "embed", 3)
+        N = xp.size(0)
+        H, K, Dc = embed_c.shape
+        if H != heads or xp.size(1) != H * Dc:
+            raise RuntimeError(f"xp shape {tuple(xp.shape)} does not match codebook {tuple(embed_c.shape)}")
+        dev = xp.device
+        norm = torch.empty(N, H, dtype=torch.float32, device=dev)
+        ind = torch.empty(N, H, dtype=torch.int64, device=dev)
+        quant = torch.empty_like(xp)
+        sqerr = torch.empty(1, dtype=torch.float32, device=dev)
+        ws = _workspace(lib.stemgnn_vq_workspace_bytes(N, H, Dc, K), dev)
+        check(lib.stemgnn_vq_assign_fwd(_p(xp), N, H, Dc, _p(embed_c), K, int(bool(training)), None, _p(norm), _p(ind),
+                                        _p(quant), _p(sqerr), _p(ws), ws.numel(), _stream()), "vq_assign_fwd")
+        ctx.save_for_backward(xp, norm, ind, embed_c)
+        ctx.mark_non_differentiable(ind)
+        numel = max(N * H * Dc, 1)
+        return quant, ind, sqerr / float(numel)
+
+    @staticmethod
+    def backward(ctx, g_quant, _g_ind, g_mse):
+        xp, norm, ind, embed = ctx.saved_tensors
+        N = xp.size(0)
+        H, K, Dc = embed.shape
+        if g_quant is None:
+            g_quant = torch.zeros_like(xp)
+        g_quant = g_quant.contiguous()
+        g_loss = None if g_mse is None else g_mse.contiguous().float()
+        g_xp = torch.empty_like(xp)
+        check(lib.stemgnn_vq_assign_bwd(_p(g_quant), _p(g_loss), 1.0, _p(xp), _p(norm), _p(ind), _p(embed), N, H, Dc, K,
+                                        _p(g_xp), _stream()), "vq_assign_bwd")
+        return g_xp, None, None, None
+
+
+def vq_ema_stats(xp: Tensor, norm: Tensor, ind: Tensor, codebook_size: int) -> Tuple[Tensor, Tensor]:
+    """bins [H, K], embed_sum [H, K, Dc] of the normalised rows per assigned code (vq.py:661-672)."""
+    _req(xp, torch.float32, "xp", 2)
+    _req(norm, torch.float32, "norm", 2)
+    _req(ind, torch.int64, "ind", 2)
+    N, H = norm.shape
+    Dc = xp.size(1) // H
+    K = int(codebook_size)
+    dev = xp.device
+    bins = torch.empty(H, K, dtype=torch.float32, device=dev)
+    embed_sum = torch.empty(H, K, Dc, dtype=torch.float32, device=dev)
+    ws = _workspace(lib.stemgnn_vq_ema_workspace_bytes(N, H, Dc, K), dev)
+    check(lib.stemgnn_vq_ema_stats(_p(xp), _p(norm), _p(ind), N, H, Dc, K, _p(bins), _p(embed_sum), _p(ws), ws.numel(),
+                                   _stream()), "vq_ema_stats")
+    return bins, embed_sum
+
+
+def vq_norms(xp: Tensor, heads: int) -> Tensor:
+    n = xp.size(0)
+    return xp.view(n, heads, -1).norm(dim=-1)
+
+
+# ----------------------------------------------------------------------------------------
+# K11 / K12 / lookups / K14
+# ----------------------------------------------------------------------------------------
+class EdgeDotFn(torch.autograd.Function):
+    """out[e] = <z[u_e], z[v_e]> (reference model/encoder.py:365)."""
+
+    @staticmethod
+    def forward(ctx, z, edge_index):
+        z = z.contiguous()
+        _req(z, torch.float32, "z", 2)
+        ei = _req(edge_index.contiguous(), torch.int64, "edge_index", 2)
+        E = ei.size(1)
+        out = torch.empty(E, dtype=torch.float32, device=z.device)
+        check(lib.stemgnn_edge_dot_fwd(_p(z), z.size(0), z.size(1), _p(ei), E, _p(out), _stream()), "edge_dot_fwd")
+        ctx.save_for_backward(z, ei)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        z, ei = ctx.saved_tensors
+        g_z = torch.zeros_like(z)
+        check(lib.stemgnn_edge_dot_bwd(_p(g_out.contiguous()), _p(z), z.size(0), z.size(1), _p(ei), ei.size(1),
+                                       _p(g_z), _stream()), "edge_dot_bwd")
+        return g_z, None
+
+
+class EdgeConcatFn(torch.autograd.Function):
+    """out[e] = cat(z[u_e], z[v_e]) (reference model/pt_model.py:80)."""
+
+    @staticmethod
+    def forward(ctx, z, edge_index):
+        z = z.contiguous()
+        _req(z, torch.float32, "z", 2)
+        ei = _req(edge_index.contiguous(), torch.int64, "edge_index", 2)
+        E, D = ei.size(1), z.size(1)
+        out = torch.empty(E, 2 * D, dtype=torch.float32, device=z.device)
+        check(lib.stemgnn_edge_concat_fwd(_p(z), z.size(0), D, _p(ei), E, _p(out), _stream()), "edge_concat_fwd")
+        ctx.save_for_backward(ei)
+        ctx.shape = (z.size(0), D)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        (ei,) = ctx.saved_tensors
+        N, D = ctx.shape
+        g_z = torch.zeros(N, D, dtype=torch.float32, device=g_out.device)
+        check(lib.stemgnn_edge_concat_bwd(_p(g_out.contiguous()), N, D, _p(ei), ei.size(1), _p(g_z), _stream()),
+              "edge_concat_bwd")
+        return g_z, None
+
+
+def gather_rows(table: Tensor, index: Tensor) -> Tensor:
+    """out[i] = table[index[i]] (device-side node_text_feat[x] of reference pretrain.py:33-38)."""
+    _req(table, torch.float32, "table", 2)
+    _req(index, torch.int64, "index", 1)
+    out = torch.empty(index.numel(), table.size(1), dtype=torch.float32, device=table.device)
+    check(lib.stemgnn_gather_rows(_p(table), table.size(0), table.size(1), _p(index), index.numel(), _p(out), _stream()),
+          "gather_rows")
+    return out
+
+
+def ema_lerp_(teacher_flat: Tensor, student_flat: Tensor, decay: float) -> None:
+    """teacher = teacher * decay + student * (1 - decay), in place (reference pt_model.py:104-106)."""
+    _req(teacher_flat, torch.float32, "teacher", 1)
+    _req(student_flat, torch.float32, "student", 1)
+    if teacher_flat.numel() != student_flat.numel():
+        raise RuntimeError("ema_lerp_: size mismatch")
+    check(lib.stemgnn_ema_lerp(_p(teacher_flat), _p(student_flat), teacher_flat.numel(), float(decay), _stream()),
+          "ema_lerp")

@@ -1,0 +1,147 @@
+"""Host side of the pretraining hot path, mirroring reference STEM-GNN/pretrain.py:25-167 with
+the same parameter names (config/pretrain.yaml), running every device operation through the
+gfx950 kernels.  Differences from the reference's host loop, all outside the arithmetic:
+
+* features stay resident on the device; a batch is (node ids, edge_index, edge type ids) and the
+  [N, D] / [E, D] expansions of pretrain.py:33-38 happen on the device (the edge one never:
+  edge attributes stay a (type table, type id) pair);
+* losses are not ``.item()``-ed per step (8 host syncs per step in pretrain.py:68-77); they are
+  returned as device tensors and logged by the caller at its own cadence.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+from torch.optim import AdamW
+
+from . import ops
+from .graph import EdgeTypeAttr
+from .model.encoder import Encoder, InnerProductDecoder
+from .model.pt_model import PretrainModel
+from .model.vq import VectorQuantize
+from .utils.graph_utils import dropout_adj, mask_feature
+from .utils.others import get_scheduler, seed_everything
+
+
+def default_params() -> Dict:
+    """reference config/pretrain.yaml:1-29 (+ argparse defaults utils/args.py:4-58)."""
+    return dict(seed=42, input_dim=768, hidden_dim=768, num_layers=2, activation="relu", backbone="sage",
+                normalize="batch", dropout=0.15, code_dim=768, codebook_size=128, codebook_head=4,
+                codebook_decay=0.8, commit_weight=10, ortho_reg_weight=1, ortho_reg_max_codes=32,
+                pretrain_epochs=50, pretrain_lr=1e-4, pretrain_weight_decay=1e-5, pretrain_batch_size=1024,
+                feat_p=0.2, edge_p=0.2, topo_recon_ratio=0.1, feat_lambda=100, topo_lambda=0.01,
+                topo_sem_lambda=100, sem_lambda=1, sem_encoder_decay=0.99, use_schedular=True, lamda_env=0.0,
+                moe=False, moe_layers="none", moe_experts=3, moe_tau=1.0)
+
+
+def build_model(params: Dict, device) -> PretrainModel:
+    """Model construction of reference pretrain.py:91-130."""
+    act = nn.ReLU if params["activation"] == "relu" else nn.LeakyReLU
+    encoder = Encoder(input_dim=params["input_dim"], hidden_dim=params["hidden_dim"], activation=act,
+                      num_layers=params["num_layers"], backbone=params["backbone"], normalize=params["normalize"],
+                      dropout=params["dropout"], moe=params.get("moe", False),
+                      num_experts=params.get("moe_experts", 3), tau=params.get("moe_tau", 1.0),
+                      moe_layers=params.get("moe_layers", "none"))
+    vq = VectorQuantize(dim=params["hidden_dim"], codebook_size=params["codebook_size"],
+                        codebook_dim=params["code_dim"], heads=params["codebook_head"],
+                        separate_codebook_per_head=True, decay=params["codebook_decay"],
+                        commitment_weight=params["commit_weight"], use_cosine_sim=True,
+                        orthogonal_reg_weight=params["ortho_reg_weight"],
+                        orthogonal_reg_max_codes=params["ortho_reg_max_codes"],
+                        orthogonal_reg_active_codes_only=False, kmeans_init=False, ema_update=False)
+    model = PretrainModel(encoder=encoder, vq=vq,
+                          feat_recon_decoder=nn.Linear(params["hidden_dim"], params["input_dim"]),
+                          topo_recon_decoder=InnerProductDecoder(hidden_dim=params["hidden_dim"],
+                                                                 output_dim=params["hidden_dim"]),
+                          topo_sem_recon_decoder=nn.Linear(params["hidden_dim"] * 2, params["hidden_dim"]))
+    return model.to(device)
+
+
+def build_optimizer(model: nn.Module, params: Dict):
+    """reference pretrain.py:134-136: AdamW over ALL parameters (sem_encoder's never get grads)."""
+    opt = AdamW(model.parameters(), lr=params["pretrain_lr"], weight_decay=params["pretrain_weight_decay"])
+    sched = get_scheduler(opt, params["use_schedular"], params["pretrain_epochs"])
+    return opt, sched
+
+
+def total_loss(losses: Dict[str, torch.Tensor], params: Dict) -> torch.Tensor:
+    """reference pretrain.py:51-58."""
+    return (params["feat_lambda"] * losses["feat_recon_loss"] + params["topo_lambda"] * losses["topo_recon_loss"]
+            + params["topo_sem_lambda"] * losses["topo_sem_recon_loss"] + params["sem_lambda"] * losses["sem_recon_loss"]
+            + losses["commit_loss"] + params.get("lamda_env", 0.0) * losses["env_reg_loss"])
+
+
+def pretrain_step(model: PretrainModel, optimizer, scheduler, params: Dict, x, edge_index, edge_attr, bs: int,
+                  draws: Optional[Dict] = None, record_draws: bool = True, no_codebook: bool = False,
+                  grad_sync=None):
+    """One iteration of reference pretrain.py:41-66 on device-resident inputs.
+
+    x [N, D] fp32; edge_index int64 [2, E]; edge_attr dense [E, D], EdgeTypeAttr or None.
+    Returns (loss, losses dict, draws).  With ``record_draws`` the dropout keep masks are
+    materialised into ``draws`` (test aid: the kernels themselves never store a mask).
+    ``grad_sync`` (optional callable) runs between backward and clipping (DDP all-reduce)."""
+    draws_in = draws or {}
+    graph = [x, edge_index, edge_attr]
+    aug_x, fmask = mask_feature(x, p=params["feat_p"], keep=draws_in.get("feat_keep"))  # pretrain.py:41
+    aug_edge_index, aug_edge_attr = dropout_adj(edge_index, edge_attr, p=params["edge_p"], force_undirected=True,
+                                                num_nodes=x.size(0), keep=draws_in.get("edge_keep"))  # :42-44
+    aug_graph = [aug_x, aug_edge_index, aug_edge_attr]
+
+    z, quantize, indices, losses = model(aug_graph, graph, params["topo_recon_ratio"], bs=bs,
+                                         no_codebook=no_codebook, draws=draws_in)
+    loss = total_loss(losses, params)
+
+    optimizer.zero_grad(set_to_none=True)
+    loss.backward()
+    if grad_sync is not None:
+        grad_sync()
+    nn.utils.clip_grad_norm_(model.parameters(), 1.0)  # pretrain.py:62
+    optimizer.step()
+    if scheduler:
+        scheduler.step()
+    model.ema_update_sem_encoder(decay=params["sem_encoder_decay"])  # pretrain.py:66
+
+    out_draws = {}
+    if record_draws:
+        n, d = x.shape
+        out_draws = dict(model.last_draws)
+        out_draws["feat_keep"] = fmask.view(-1) if params["feat_p"] > 0 else torch.ones(d, dtype=torch.bool, device=x.device)
+        if params["edge_p"] > 0:
+            out_draws["edge_keep"] = dropout_adj.last_keep
+        else:
+            out_draws["edge_keep"] = torch.ones(edge_index.size(1), dtype=torch.bool, device=x.device)
+        p = params["dropout"]
+        out_draws["student_dropout"] = [ops.dropout_keep_mask(n * d, p, s, o, x.device).view(n, d)
+                                        for (s, o) in model.encoder.last_dropout_keys]
+        out_draws["teacher_dropout"] = [ops.dropout_keep_mask(n * d, p, s, o, x.device).view(n, d)
+                                        for (s, o) in model.sem_encoder.last_dropout_keys]
+        if model.vq.last_ortho_ids is not None:
+            out_draws["ortho_ids"] = model.vq.last_ortho_ids
+    return loss.detach(), {k: v.detach() for k, v in losses.items()}, out_draws
+
+
+def pretrain(model, loader, optimizer, params, scheduler=None, no_codebook=False, log_fn=None, grad_sync=None):
+    """reference pretrain.py:25-79.  ``loader`` yields batches with attributes
+    ``batch_size``, ``x`` (node ids into ``node_text_feat``) or features, ``edge_index``, ``xe``,
+    ``node_text_feat`` [*, D], ``edge_text_feat`` [T, D] — the NeighborLoader batch contract
+    (reference dataset/process_datasets.py:92-108).  Feature tables should live on the device."""
+    model.train()
+    device = next(model.parameters()).device
+    last = None
+    for data in loader:
+        bs = data.batch_size
+        ntf = data.node_text_feat.to(device)
+        if data.x.size(0) != ntf.size(0) or data.x.dtype == torch.int64:
+            x = ops.gather_rows(ntf, data.x.to(device).long().contiguous())  # node_text_feat[data.x]
+        else:
+            x = ntf
+        edge_index = data.edge_index.to(device)
+        edge_attr = EdgeTypeAttr(data.edge_text_feat.to(device), data.xe.to(device))  # edge_text_feat[xe], lazily
+        loss, losses, _ = pretrain_step(model, optimizer, scheduler, params, x, edge_index, edge_attr, bs,
+                                        record_draws=False, no_codebook=no_codebook, grad_sync=grad_sync)
+        last = (loss, losses)
+        if log_fn is not None:
+            log_fn(loss, losses)
+    return last

@@ -1,0 +1,235 @@
+"""GPU parity tests at module level (run with -m gpu): VectorQuantize against the reference's
+golden vectors (tests/golden/vq_*.pt, produced by importing the reference's model/vq.py) and
+against the CPU oracle at larger sizes; Encoder and the full pretraining step against the CPU
+oracle with the random draws of the HIP run replayed."""
+import glob
+import os
+
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+
+from oracle import stem_oracle as O  # noqa: E402  (checker only)
+
+FIXTURES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "vq_*.pt")))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def assert_indices_match(ind, ref, gap, tol=1e-5):
+    """Bit-exact wherever the reference's top-2 similarity gap exceeds `tol`; a near-tie may
+    resolve either way because the fp32 summation order of the MFMA chain differs from ATen's
+    GEMM (SURVEY §7 'VQ arg-max exactness')."""
+    ind, ref, gap = ind.reshape(-1), ref.reshape(-1), gap.reshape(-1)
+    diff = ind != ref
+    assert not bool((diff & (gap > tol)).any()), f"{int((diff & (gap > tol)).sum())} index mismatches beyond ties"
+    return int(diff.sum())
+
+
+def build_vq(N, D, H, K, Dc, ortho_max, ema, dev):
+    from stem_gnn_amd.model.vq import VectorQuantize
+    return VectorQuantize(dim=D, codebook_size=K, codebook_dim=Dc, heads=H, separate_codebook_per_head=True,
+                          decay=0.8, commitment_weight=10, use_cosine_sim=True, orthogonal_reg_weight=1,
+                          orthogonal_reg_max_codes=ortho_max, orthogonal_reg_active_codes_only=False,
+                          kmeans_init=False, ema_update=bool(ema)).to(dev)
+
+
+@pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p) for p in FIXTURES])
+def test_vq_matches_reference_golden(dev, path):
+    fx = torch.load(path, weights_only=True)
+    N, D, H, K, Dc, ortho_max, ema, seed = fx["meta"].tolist()
+    vq = build_vq(N, D, H, K, Dc, ortho_max, ema, dev)
+    state = {k[len("state0."):]: v for k, v in fx.items() if k.startswith("state0.")}
+    vq.load_state_dict(state)  # the reference's exact key / shape contract
+    vq.train()
+    z = fx["z"].to(dev).requires_grad_(True)
+    # replay the reference's randperm draw for the orthogonal loss
+    orig_randperm = torch.randperm
+    try:
+        if K > ortho_max:
+            torch.randperm = lambda n, device=None, **kw: fx["ortho_ids"].to(device) if n == K else orig_randperm(n, device=device, **kw)
+        q, ind, loss, oq = vq(z)
+    finally:
+        torch.randperm = orig_randperm
+    assert ind.dtype == torch.int64 and tuple(ind.shape) == tuple(fx["train.embed_ind"].shape)
+    flips = assert_indices_match(ind.cpu(), fx["train.embed_ind"], fx["top2_gap"])
+    if flips == 0:
+        torch.testing.assert_close(oq.detach().cpu(), fx["train.orig_quantize"], rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(q.detach().cpu(), fx["train.quantize"], rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(loss.detach().cpu(), fx["train.loss"], rtol=1e-4, atol=1e-5)
+        w = torch.linspace(-1.0, 1.0, q.numel()).view_as(q).to(dev)
+        (loss.sum() + (q * w).sum()).backward()
+        torch.testing.assert_close(z.grad.cpu(), fx["train.grad_z"], rtol=1e-3, atol=1e-5)
+        for pn, p in vq.named_parameters():
+            key = "train.grad." + pn
+            if key in fx:
+                torch.testing.assert_close(p.grad.cpu(), fx[key], rtol=1e-3, atol=1e-5)
+        if ema:
+            for k, v in vq.state_dict().items():
+                if k.startswith("_codebook."):
+                    torch.testing.assert_close(v.cpu(), fx["post." + k], rtol=1e-4, atol=1e-5)
+    # eval mode on the initial state
+    vq2 = build_vq(N, D, H, K, Dc, ortho_max, ema, dev)
+    vq2.load_state_dict(state)
+    vq2.eval()
+    with torch.no_grad():
+        q2, ind2, loss2, oq2 = vq2(fx["z"].to(dev))
+    flips2 = assert_indices_match(ind2.cpu(), fx["eval.embed_ind"], fx["top2_gap"])
+    if flips2 == 0:
+        torch.testing.assert_close(q2.cpu(), fx["eval.quantize"], rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(oq2.cpu(), fx["eval.orig_quantize"], rtol=1e-4, atol=1e-5)
+    assert float(loss2) == 0.0
+
+
+@pytest.mark.parametrize("N,D,H,K,Dc", [(1, 32, 2, 8, 16), (127, 32, 4, 33, 32), (129, 64, 4, 128, 64),
+                                        (1000, 128, 4, 512, 128), (300, 96, 2, 200, 100), (260, 768, 4, 128, 768)])
+def test_vq_vs_oracle_sizes(dev, N, D, H, K, Dc):
+    """Ragged tiles (N not a multiple of 128, K not a multiple of 32, Dc not a multiple of 32)."""
+    torch.manual_seed(N + K)
+    ovq = O.OracleVectorQuantize(D, K, Dc, H, commitment_weight=10.0, orthogonal_reg_weight=1.0,
+                                 orthogonal_reg_max_codes=32, ema_update=False)
+    vq = build_vq(N, D, H, K, Dc, 32, False, dev)
+    vq.load_state_dict(ovq.state_dict())
+    z = torch.randn(N, D)
+    ids = torch.randperm(K)[:32] if K > 32 else None
+    ovq.train(); vq.train()
+    zr = z.clone().requires_grad_(True)
+    qr, ir, lr, oqr = ovq(zr, ortho_ids=ids)
+    with torch.no_grad():
+        x = torch.nn.functional.normalize(ovq.project_in(z).view(N, H, Dc), dim=-1)
+        sim = torch.einsum("nhd,hcd->nhc", x, ovq._codebook.embed)
+        top2 = sim.topk(2, dim=-1).values
+        gap = top2[..., 0] - top2[..., 1]
+    zg = z.to(dev).requires_grad_(True)
+    orig_randperm = torch.randperm
+    try:
+        if ids is not None:
+            torch.randperm = lambda n, device=None, **kw: ids.to(device)
+        qg, ig, lg, oqg = vq(zg)
+    finally:
+        torch.randperm = orig_randperm
+    flips = assert_indices_match(ig.cpu(), ir, gap)
+    if flips == 0:
+        torch.testing.assert_close(qg.detach().cpu(), qr.detach(), rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(lg.detach().cpu(), lr.detach(), rtol=1e-4, atol=1e-5)
+        w = torch.randn(N, D)
+        (lr.sum() + (qr * w).sum()).backward()
+        (lg.sum() + (qg * w.to(dev)).sum()).backward()
+        torch.testing.assert_close(zg.grad.cpu(), zr.grad, rtol=1e-3, atol=1e-5)
+
+
+def test_vq_tie_breaks_to_lowest_index(dev):
+    """Duplicate code rows: the arg-max must return the lowest index (torch.argmax semantics)."""
+    from stem_gnn_amd import ops
+    H, K, Dc, N = 2, 70, 32, 200
+    torch.manual_seed(1)
+    embed = torch.nn.functional.normalize(torch.randn(H, K, Dc), dim=-1)
+    embed[:, 40] = embed[:, 3]    # same half of the MFMA tile
+    embed[:, 69] = embed[:, 5]    # different code tile
+    embed[:, 36] = embed[:, 33]   # other lane half (rows 4..7 live in the upper half)
+    xp = torch.randn(N, H * Dc)
+    xp[:50, :Dc] = embed[0, 3] * 2.0
+    xp[50:100, :Dc] = embed[0, 5] * 0.5
+    xp[100:150, Dc:] = embed[1, 33] * 3.0
+    quant, ind, mse = ops.VqAssignFn.apply(xp.to(dev), embed.to(dev), H, True)
+    ind = ind.cpu()
+    assert (ind[:50, 0] == 3).all() and (ind[50:100, 0] == 5).all() and (ind[100:150, 1] == 33).all()
+
+
+def make_models(D, L, H, K, Dc, dev, dropout=0.15, seed=0):
+    from stem_gnn_amd.model.encoder import Encoder, InnerProductDecoder
+    from stem_gnn_amd.model.pt_model import PretrainModel
+    from stem_gnn_amd.model.vq import VectorQuantize
+    torch.manual_seed(seed)
+    om = O.build_oracle_model(D, L, H, K, Dc, dropout=dropout)
+    enc = Encoder(D, D, nn.ReLU, L, backbone="sage", normalize="batch", dropout=dropout)
+    vq = VectorQuantize(dim=D, codebook_size=K, codebook_dim=Dc, heads=H, separate_codebook_per_head=True, decay=0.8,
+                        commitment_weight=10, use_cosine_sim=True, orthogonal_reg_weight=1,
+                        orthogonal_reg_max_codes=32, kmeans_init=False, ema_update=False)
+    gm = PretrainModel(enc, vq, nn.Linear(D, D), InnerProductDecoder(D, D), nn.Linear(2 * D, D))
+    gm.load_state_dict(om.state_dict())  # identical parameter names/shapes by construction
+    return om, gm.to(dev)
+
+
+@pytest.mark.parametrize("attr", ["dense", "table", "none"])
+def test_encoder_fwd_bwd_vs_oracle(dev, attr):
+    from stem_gnn_amd import ops
+    from stem_gnn_amd.graph import EdgeTypeAttr
+    N, E, D, L = 500, 4000, 64, 3
+    om, gm = make_models(D, L, 4, 64, D, dev)
+    torch.manual_seed(5)
+    x = torch.randn(N, D)
+    ei = torch.randint(0, N, (2, E))
+    table, et = torch.randn(6, D), torch.randint(0, 6, (E,))
+    ea_cpu = None if attr == "none" else table[et]
+    ea_gpu = None if attr == "none" else (ea_cpu.to(dev) if attr == "dense" else EdgeTypeAttr(table.to(dev), et.to(dev)))
+    oe, ge = om.encoder, gm.encoder
+    oe.train(); ge.train()
+    xg = x.to(dev).requires_grad_(True)
+    zg = ge(xg, ei.to(dev), ea_gpu)
+    masks = [ops.dropout_keep_mask(N * D, 0.15, s, o, dev).view(N, D).cpu() for (s, o) in ge.last_dropout_keys]
+    assert len(masks) == L - 1
+    xr = x.clone().requires_grad_(True)
+    zr = oe(xr, ei, ea_cpu, dropout_masks=masks)
+    torch.testing.assert_close(zg.detach().cpu(), zr.detach(), rtol=1e-4, atol=1e-4)
+    w = torch.randn(N, D)
+    (zr * w).sum().backward()
+    (zg * w.to(dev)).sum().backward()
+    torch.testing.assert_close(xg.grad.cpu(), xr.grad, rtol=1e-3, atol=1e-4)
+    for (n1, p1), (n2, p2) in zip(oe.named_parameters(), ge.named_parameters()):
+        assert n1 == n2
+        torch.testing.assert_close(p2.grad.cpu(), p1.grad, rtol=1e-3, atol=2e-4, msg=lambda m: f"{n1}: {m}")
+    for (n1, b1), (n2, b2) in zip(oe.named_buffers(), ge.named_buffers()):
+        assert n1 == n2
+        torch.testing.assert_close(b2.cpu().float(), b1.float(), rtol=1e-4, atol=1e-5)
+    # eval mode
+    oe.eval(); ge.eval()
+    with torch.no_grad():
+        torch.testing.assert_close(ge(x.to(dev), ei.to(dev), ea_gpu).cpu(), oe(x, ei, ea_cpu), rtol=1e-4, atol=1e-4)
+
+
+def test_pretrain_steps_loss_parity(dev):
+    """Several full pretraining steps (augment -> forward -> backward -> clip -> AdamW ->
+    scheduler -> EMA teacher): the HIP path's loss curve against the CPU oracle replaying the
+    HIP run's random draws.  Tolerance 1e-4 relative on every loss term (north_star)."""
+    from stem_gnn_amd import ops
+    from stem_gnn_amd.graph import EdgeTypeAttr
+    from stem_gnn_amd.pretrain import pretrain_step, default_params
+    from stem_gnn_amd.utils.others import get_scheduler
+    N, E, D, L, H, K = 600, 5000, 64, 2, 4, 64
+    bs = 200
+    om, gm = make_models(D, L, H, K, D, dev)
+    params = default_params()
+    params.update(pretrain_lr=1e-3)
+    torch.manual_seed(11)
+    x = torch.nn.functional.normalize(torch.randn(N, D), dim=-1)
+    half = torch.randint(0, N, (2, E // 2))
+    ei = torch.cat([half, half.flip(0)], dim=1)[:, torch.randperm(E)]
+    table = torch.nn.functional.normalize(torch.randn(4, D), dim=-1)
+    et = torch.randint(0, 4, (E,))
+    opt_o = torch.optim.AdamW(om.parameters(), lr=params["pretrain_lr"], weight_decay=params["pretrain_weight_decay"])
+    opt_g = torch.optim.AdamW(gm.parameters(), lr=params["pretrain_lr"], weight_decay=params["pretrain_weight_decay"])
+    sch_o, sch_g = get_scheduler(opt_o, True, 50), get_scheduler(opt_g, True, 50)
+    xg, eig = x.to(dev), ei.to(dev)
+    eag = EdgeTypeAttr(table.to(dev), et.to(dev))
+    ops.manual_seed(99)
+    for step in range(4):
+        loss_g, losses_g, draws = pretrain_step(gm, opt_g, sch_g, params, xg, eig, eag, bs)
+        cpu_draws = {}
+        for k, v in draws.items():
+            cpu_draws[k] = [m.cpu() for m in v] if isinstance(v, list) else v.cpu()
+        loss_o, losses_o, ind_o = O.pretrain_step(om, opt_o, sch_o, params, x, ei, table[et], bs, cpu_draws)
+        for k in losses_o:
+            torch.testing.assert_close(losses_g[k].cpu().reshape(-1), losses_o[k].reshape(-1), rtol=1e-4, atol=1e-5,
+                                       msg=lambda m: f"step {step} {k}: {m}")
+        torch.testing.assert_close(loss_g.cpu().reshape(-1), loss_o.reshape(-1), rtol=1e-4, atol=1e-5)
+    # parameters after 4 optimiser steps and the EMA teacher
+    for (n1, p1), (n2, p2) in zip(om.named_parameters(), gm.named_parameters()):
+        assert n1 == n2
+        torch.testing.assert_close(p2.detach().cpu(), p1.detach(), rtol=2e-3, atol=2e-4, msg=lambda m: f"{n1}: {m}")
