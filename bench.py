@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""Headline benchmark: pretrain edges/sec (fwd+bwd) on the 1M-node / 20M-edge synthetic graph
+(BASELINE.json metric), one process per GPU.
+
+    python bench.py --gpus 1 --steps 30 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one full pretraining iteration of reference pretrain.py:41-66 (augment -> student
+forward -> VQ -> 4 reconstruction losses incl. the teacher forward -> backward -> clip ->
+AdamW -> cosine LR -> EMA teacher) on one neighbour-sampled mini-batch (fan-out [10,10], 1024
+seeds per rank) whose inputs are already resident in HBM.  value = sum over ranks and steps of
+the un-augmented batch graph's edge count / max-over-ranks wall time.  fp32 throughout.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (num_nodes, num_edges, dim, edge types, full_batch)
+    "c4": dict(nodes=1_000_000, edges=20_000_000, dim=128, types=4, full_batch=False,
+               desc="C4: 1M-node/20M-edge synthetic Graph-U, neighbour-sampled [10,10], 1024 seeds/rank"),
+    "c2": dict(nodes=100_000, edges=1_000_000, dim=128, types=4, full_batch=True,
+               desc="C2: 100k-node/1M-edge synthetic Graph-U, full batch"),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch-size", type=int, default=1024)
+    ap.add_argument("--codebook-size", type=int, default=128)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(params, batch_cpu, bs, budget_s):
+    """The CPU oracle (restated reference path) timed on this box's host cores: same step,
+    same batch shape, fp32.  kind = "port" (the reference's PyG path cannot run here)."""
+    from oracle import stem_oracle as O
+    x, ei, table, et = batch_cpu
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    D = x.size(1)
+    torch.manual_seed(42)
+    om = O.build_oracle_model(D, params["num_layers"], params["codebook_head"], params["codebook_size"],
+                              params["code_dim"], dropout=params["dropout"])
+    opt = torch.optim.AdamW(om.parameters(), lr=params["pretrain_lr"], weight_decay=params["pretrain_weight_decay"])
+    n, e = x.size(0), ei.size(1)
+    ea = table[et]
+    g = torch.Generator().manual_seed(0)
+
+    def draws():
+        keep = torch.rand(e, generator=g) >= params["edge_p"]
+        es = max(int(e * params["topo_recon_ratio"]), 1)
+        return {
+            "feat_keep": torch.rand(D, generator=g) >= params["feat_p"],
+            "edge_keep": keep,
+            "student_dropout": [torch.rand(n, D, generator=g) >= params["dropout"] for _ in range(params["num_layers"] - 1)],
+            "teacher_dropout": [torch.rand(n, D, generator=g) >= params["dropout"] for _ in range(params["num_layers"] - 1)],
+            "topo_perm": torch.randperm(e, generator=g)[:es],
+            "neg_edge_index": torch.randint(0, n, (2, es), generator=g),
+            "topo_sem_perm": torch.randperm(e, generator=g)[:es],
+            "ortho_ids": torch.randperm(params["codebook_size"], generator=g)[:params["ortho_reg_max_codes"]],
+        }
+
+    O.pretrain_step(om, opt, None, params, x, ei, ea, bs, draws())  # warm-up (allocator, thread pool)
+    t0 = time.perf_counter()
+    steps = 0
+    while True:
+        O.pretrain_step(om, opt, None, params, x, ei, ea, bs, draws())
+        steps += 1
+        if time.perf_counter() - t0 >= budget_s or steps >= 50:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": e * steps / dt, "unit": "edges/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} full pretrain steps of the CPU oracle on one batch ({n} nodes, {e} edges, D={D}), "
+                      f"{dt:.1f} s, torch {torch.__version__} fp32, {cores} threads"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+
+    from stem_gnn_amd import ops
+    from stem_gnn_amd.data.sampler import NeighborLoader, NeighborSampler
+    from stem_gnn_amd.data.synthetic import make_graph
+    from stem_gnn_amd.graph import EdgeTypeAttr, set_validation
+    from stem_gnn_amd.pretrain import build_model, build_optimizer, default_params, pretrain_step
+    from stem_gnn_amd.utils.others import seed_everything
+
+    wl = WORKLOADS[args.workload]
+    D = wl["dim"]
+    params = default_params()
+    params.update(input_dim=D, hidden_dim=D, code_dim=D, codebook_size=args.codebook_size,
+                  pretrain_batch_size=args.batch_size)
+    seed_everything(params["seed"])
+
+    # ---- data: identical synthetic graph on every rank (replicated structure + features)
+    g = make_graph(wl["nodes"], wl["edges"], D, wl["types"], kind="U", device=dev, graph_seed=1234, feat_seed=0)
+    total = args.steps + args.warmup
+    batches = []
+    if wl["full_batch"]:
+        x = g.node_text_feat
+        for _ in range(total):
+            batches.append((x, g.edge_index, g.xe, wl["nodes"]))
+    else:
+        sampler = NeighborSampler(g.edge_index, g.xe, g.num_nodes, g.x, g.node_text_feat, g.edge_text_feat,
+                                  [10] * params["num_layers"], seed=100 + rank)
+        loader = NeighborLoader(sampler, torch.arange(g.num_nodes, device=dev), args.batch_size, shuffle=True,
+                                rank=rank, world_size=world, seed=7)
+        it = iter(loader)
+        for _ in range(total):
+            b = next(it)
+            x = ops.gather_rows(g.node_text_feat, b.x.contiguous())  # node_text_feat[data.x], on device
+            batches.append((x, b.edge_index, b.xe, b.batch_size))
+    torch.cuda.synchronize()
+
+    # ---- model
+    model = build_model(params, dev)
+    for p in model.sem_encoder.parameters():
+        p.requires_grad_(False)  # never receives gradients (pt_model.py:93 detach); keeps DDP bucketing exact
+    opt, sched = build_optimizer(model, params)
+    fwd = None
+    if world > 1:
+        ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], broadcast_buffers=False,
+                                                        gradient_as_bucket_view=True)
+        fwd = ddp
+    set_validation(False)  # batches come from our own sampler: skip the per-build device->host range check
+    model.train()
+
+    def step(i):
+        x, ei, xe, bs = batches[i]
+        return pretrain_step(model, opt, sched, params, x, ei, EdgeTypeAttr(g.edge_text_feat, xe), bs,
+                             record_draws=False, forward_fn=fwd)
+
+    for i in range(args.warmup):
+        step(i)
+    ops.k1_timer.reset(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, total):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    recs = ops.k1_timer.records
+    ops.k1_timer.reset(False)
+
+    edges = float(sum(batches[i][1].size(1) for i in range(args.warmup, total)))
+    stat = torch.tensor([dt, edges], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = stat[:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        esum = stat[1:].clone()
+        dist.all_reduce(esum, op=dist.ReduceOp.SUM)
+        dt, edges = float(tmax), float(esum)
+
+    if rank == 0:
+        k1_bytes = sum(r[0] for r in recs)
+        k1_ms = sum(r[1].elapsed_time(r[2]) for r in recs)
+        achieved = k1_bytes / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
+        peak = 8000.0  # MI355X HBM3E spec, GB/s (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+        nb = batches[args.warmup]
+        out = {
+            "metric": "pretrain edges/sec (fwd+bwd) on 1M-node/20M-edge synthetic graph, 1/2/4/8 GPUs",
+            "value": edges / dt, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": wl["desc"], "nodes": wl["nodes"], "edges": wl["edges"], "feat_dim": D,
+                       "layers": params["num_layers"], "vq_heads": params["codebook_head"],
+                       "codebook_size": params["codebook_size"], "code_dim": params["code_dim"],
+                       "seeds_per_rank": nb[3], "batch_nodes": int(nb[0].size(0)), "batch_edges": int(nb[1].size(1)),
+                       "parallelism": f"dp{world}", "edge_attr": "type-indexed (4E + T*D*4 bytes)"},
+            "roofline": {"bound": "hbm", "kernel": "k_sage_agg_fwd (K1, type-indexed edge attr)",
+                         "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
+                         "traffic": None, "launches": len(recs),
+                         "avg_launch_us": (k1_ms * 1e3 / len(recs)) if recs else None,
+                         "algorithmic_bytes_per_launch": (k1_bytes / len(recs)) if recs else None},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            x, ei, xe, bs = batches[args.warmup]
+            out["cpu_baseline"] = cpu_baseline(params, (x.cpu(), ei.cpu(), g.edge_text_feat.cpu(), xe.cpu()), bs,
+                                               args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

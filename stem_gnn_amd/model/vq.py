@@ -212,8 +212,9 @@ class VectorQuantize(nn.Module):
         if not cb._initted_host:
             with torch.no_grad():
                 cb.init_embed_(l2norm(xp.detach().view(n, h, dc).permute(1, 0, 2)))
-        quant, embed_ind, mse = ops.VqAssignFn.apply(xp, cb.embed, h, self.training)
-        if self.training and cb.ema_update and not freeze_codebook:
+        will_ema = self.training and cb.ema_update and not freeze_codebook
+        quant, embed_ind, mse = ops.VqAssignFn.apply(xp, cb.embed, h, self.training, will_ema)
+        if will_ema:
             cb.ema_update_(xp.detach().contiguous(), embed_ind)
         loss = torch.zeros(1, device=x.device, requires_grad=self.training)  # vq.py:983
         if self.training:

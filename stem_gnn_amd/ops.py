@@ -115,6 +115,29 @@ def inv_degree(rowptr: Tensor) -> Tensor:
 # ----------------------------------------------------------------------------------------
 # K1 / K2
 # ----------------------------------------------------------------------------------------
+class KernelTimer:
+    """Brackets every K1-forward launch with HIP events on the launch stream (bench.py's
+    roofline leg).  Records (algorithmic bytes, start event, end event) per launch."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = []
+
+    def reset(self, enabled: bool):
+        self.enabled = enabled
+        self.records = []
+
+
+k1_timer = KernelTimer()
+
+
+def k1_algorithmic_bytes(N: int, E: int, D: int, mode: str, T: int = 0) -> int:
+    """SURVEY.md §8d: E*D*4 (source rows) + A + 4E (src ids) + 4(N+1) (rowptr) + N*D*4 (output);
+    A = E*D*4 + 4E (dense rows + edge ids) | 4E + T*D*4 (type ids + table) | 0."""
+    a = {"dense": E * D * 4 + 4 * E, "table": 4 * E + T * D * 4, "none": 0}[mode]
+    return E * D * 4 + a + 4 * E + 4 * (N + 1) + N * D * 4
+
+
 def sage_agg_fwd(x: Tensor, graph, edge_attr: Optional[Tensor], etab: Optional[Tensor]) -> Tensor:
     _req(x, torch.float32, "x", 2)
     N, D = x.shape
@@ -122,6 +145,8 @@ def sage_agg_fwd(x: Tensor, graph, edge_attr: Optional[Tensor], etab: Optional[T
         raise RuntimeError(f"x has {N} rows but the graph structure was built for {graph.num_nodes} nodes")
     etype_slot = None
     T = 0
+    if graph.num_edges == 0:
+        edge_attr = etab = None  # no edges: the edge term is never read
     if edge_attr is not None:
         _req(edge_attr, torch.float32, "edge_attr", 2)
         if tuple(edge_attr.shape) != (graph.num_edges, D):
@@ -135,8 +160,15 @@ def sage_agg_fwd(x: Tensor, graph, edge_attr: Optional[Tensor], etab: Optional[T
         if etype_slot is None:
             raise RuntimeError("graph structure has no edge types; build it with edge_type=...")
     agg = torch.empty_like(x)
+    if k1_timer.enabled:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
     check(lib.stemgnn_sage_agg_fwd(_p(x), N, D, _p(graph.rowptr), _p(graph.src), _p(graph.eid), _p(edge_attr),
                                    _p(etab), _p(etype_slot), T, _p(agg), _stream()), "sage_agg_fwd")
+    if k1_timer.enabled:
+        ev1.record()
+        mode = "dense" if edge_attr is not None else ("table" if etab is not None else "none")
+        k1_timer.records.append((k1_algorithmic_bytes(N, graph.num_edges, D, mode, T), ev0, ev1))
     return agg
 
 
@@ -144,6 +176,8 @@ def sage_agg_bwd(g_agg: Tensor, x: Tensor, graph, edge_attr: Optional[Tensor], e
     _req(g_agg, torch.float32, "g_agg", 2)
     N, D = x.shape
     graph.ensure_transpose()
+    if graph.num_edges == 0:
+        edge_attr = etab = None
     T = 0 if etab is None else etab.size(0)
     g_x = torch.empty_like(x)
     check(lib.stemgnn_sage_agg_bwd(_p(g_agg), _p(x), N, D, _p(graph.rowptr_t), _p(graph.dst_t), _p(graph.eid_t),
@@ -239,9 +273,13 @@ class VqAssignFn(torch.autograd.Function):
     reference: vq.py:931-937 with VectorQuantize.learnable_codebook == False)."""
 
     @staticmethod
-    def forward(ctx, xp, embed, heads, training):
+    def forward(ctx, xp, embed, heads, training, snapshot_embed=False):
         xp = xp.contiguous()
         embed_c = embed.detach().contiguous()
+        if snapshot_embed:
+            # the EMA update rewrites `embed` in place right after this op (vq.py:682) while the
+            # backward still needs the codes that were actually assigned
+            embed_c = embed_c.clone()
         _req(xp, torch.float32, "xp", 2)
         _req(embed_c, torch.float32, "embed", 3)
         N = xp.size(0)
@@ -273,7 +311,7 @@ class VqAssignFn(torch.autograd.Function):
         g_xp = torch.empty_like(xp)
         check(lib.stemgnn_vq_assign_bwd(_p(g_quant), _p(g_loss), 1.0, _p(xp), _p(norm), _p(ind), _p(embed), N, H, Dc, K,
                                         _p(g_xp), _stream()), "vq_assign_bwd")
-        return g_xp, None, None, None
+        return g_xp, None, None, None, None
 
 
 def vq_ema_stats(xp: Tensor, norm: Tensor, ind: Tensor, codebook_size: int) -> Tuple[Tensor, Tensor]:

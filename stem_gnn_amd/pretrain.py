@@ -75,13 +75,15 @@ def total_loss(losses: Dict[str, torch.Tensor], params: Dict) -> torch.Tensor:
 
 def pretrain_step(model: PretrainModel, optimizer, scheduler, params: Dict, x, edge_index, edge_attr, bs: int,
                   draws: Optional[Dict] = None, record_draws: bool = True, no_codebook: bool = False,
-                  grad_sync=None):
+                  grad_sync=None, forward_fn=None):
     """One iteration of reference pretrain.py:41-66 on device-resident inputs.
 
     x [N, D] fp32; edge_index int64 [2, E]; edge_attr dense [E, D], EdgeTypeAttr or None.
     Returns (loss, losses dict, draws).  With ``record_draws`` the dropout keep masks are
     materialised into ``draws`` (test aid: the kernels themselves never store a mask).
-    ``grad_sync`` (optional callable) runs between backward and clipping (DDP all-reduce)."""
+    ``grad_sync`` (optional callable) runs between backward and clipping (explicit all-reduce);
+    ``forward_fn`` replaces ``model.__call__`` (e.g. the DistributedDataParallel wrapper, whose
+    hooks overlap the RCCL gradient all-reduce with backward)."""
     draws_in = draws or {}
     graph = [x, edge_index, edge_attr]
     aug_x, fmask = mask_feature(x, p=params["feat_p"], keep=draws_in.get("feat_keep"))  # pretrain.py:41
@@ -89,8 +91,8 @@ def pretrain_step(model: PretrainModel, optimizer, scheduler, params: Dict, x, e
                                                 num_nodes=x.size(0), keep=draws_in.get("edge_keep"))  # :42-44
     aug_graph = [aug_x, aug_edge_index, aug_edge_attr]
 
-    z, quantize, indices, losses = model(aug_graph, graph, params["topo_recon_ratio"], bs=bs,
-                                         no_codebook=no_codebook, draws=draws_in)
+    z, quantize, indices, losses = (forward_fn or model)(aug_graph, graph, params["topo_recon_ratio"], bs=bs,
+                                                         no_codebook=no_codebook, draws=draws_in)
     loss = total_loss(losses, params)
 
     optimizer.zero_grad(set_to_none=True)

@@ -161,7 +161,9 @@ def test_bn_act_dropout_fwd_bwd(dev, n, d, use_bn, act, p, slope):
                                 rvg if use_bn else None, use_bn, 0.1, 1e-5, act, slope, p, seed, offset)
     (out * w.to(dev)).sum().backward()
     torch.testing.assert_close(out.detach().cpu(), t.detach(), rtol=1e-4, atol=1e-5)
-    torch.testing.assert_close(yg.grad.cpu(), yr.grad, rtol=1e-4, atol=2e-5)
+    # N == 2 is degenerate for batch norm (x_hat = +-1, rstd ~ 1/|dy|): the backward is a
+    # cancellation of O(rstd) terms, so the absolute error scales with rstd there
+    torch.testing.assert_close(yg.grad.cpu(), yr.grad, rtol=1e-4, atol=2e-5 if n > 2 else 2e-4)
     if use_bn:
         torch.testing.assert_close(gg.grad.cpu(), gr.grad, rtol=1e-4, atol=1e-4)
         torch.testing.assert_close(bg.grad.cpu(), br.grad, rtol=1e-4, atol=1e-4)
