@@ -116,6 +116,12 @@ int stemgnn_bn_stats(const float* y, int64_t num_rows, int64_t dim, float eps,
                      float* mean, float* rstd, float* running_mean, float* running_var, float momentum,
                      void* workspace, size_t workspace_bytes, void* stream);
 
+/* Same finalisation from per-block column partials [blocks][2][D] (sum, sum of squares) that a
+ * producer kernel already wrote (stemgnn_linear_fwd's fused statistics). */
+int stemgnn_bn_stats_from_partials(const float* partial, int64_t blocks, int64_t num_rows, int64_t dim, float eps,
+                                   float* mean, float* rstd, float* running_mean, float* running_var,
+                                   float momentum, void* stream);
+
 /* out = dropout(act((y - mean) * rstd * gamma + beta)).
  * act: 0 none, 1 relu / leaky-relu with `negative_slope`.  p = 0 disables dropout; the keep
  * decision of element (r, c) is philox(seed, offset)[r*D + c] >= p, reproducible by
@@ -135,6 +141,30 @@ int stemgnn_bn_act_drop_bwd(const float* g_out, const float* y, int64_t num_rows
 
 /* keep[i] (uint8) for i in [0, n): the mask the two kernels above use. */
 int stemgnn_dropout_keep_mask(int64_t n, float p, uint64_t seed, uint64_t offset, uint8_t* keep, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * K3 / K5: dense projections on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, exact fp32).
+ * Replaces lin_l(agg) + lin_r(x) (model/encoder.py:83-87), project_in / project_out
+ * (model/vq.py:881,1041) and the decoders' nn.Linear (model/pt_model.py:42,80,94).
+ * All matrices dense row-major fp32; K1, K2, N multiples of 4.
+ * ------------------------------------------------------------------------------------ */
+
+/* y [M, N] = x1 [M, K1] w1[N, K1]^T (+ x2 [M, K2] w2 [N, K2]^T when K2 > 0) + bias [N] (NULL: none).
+ * stats_partial (may be NULL): receives per-row-block column sums / sums of squares of y,
+ * [ceil(M/128)][2][N]; *stats_blocks_host (host pointer, may be NULL) = ceil(M/128). */
+size_t stemgnn_linear_stats_partial_bytes(int64_t num_rows, int64_t out_dim);
+int stemgnn_linear_fwd(const float* x1, const float* w1, int64_t k1, const float* x2, const float* w2, int64_t k2,
+                       const float* bias, int64_t num_rows, int64_t out_dim, float* y, float* stats_partial,
+                       int64_t* stats_blocks_host, void* stream);
+
+/* dw [N, K] = dy [M, N]^T x [M, K];  db [N] = column sums of dy (NULL: skip).  Deterministic
+ * two-stage reduction over row splits (no atomics). */
+size_t stemgnn_linear_bwd_weight_workspace_bytes(int64_t num_rows, int64_t out_dim, int64_t in_dim);
+int stemgnn_linear_bwd_weight(const float* dy, const float* x, int64_t num_rows, int64_t out_dim, int64_t in_dim,
+                              float* dw, float* db, void* workspace, size_t workspace_bytes, void* stream);
+
+/* out [cols, rows] = in [rows, cols]^T (weights; backward-data = stemgnn_linear_fwd on w^T). */
+int stemgnn_transpose(const float* in, int64_t rows, int64_t cols, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * K6+K7+K8: cosine-similarity codebook assignment, fused.

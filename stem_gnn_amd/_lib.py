@@ -44,6 +44,12 @@ _SIGNATURES = {
     "stemgnn_inv_degree": (c_int, [P, I64, P, P]),
     "stemgnn_bn_workspace_bytes": (c_size_t, [I64, I64]),
     "stemgnn_bn_stats": (c_int, [P, I64, I64, c_float, P, P, P, P, c_float, P, c_size_t, P]),
+    "stemgnn_bn_stats_from_partials": (c_int, [P, I64, I64, I64, c_float, P, P, P, P, c_float, P]),
+    "stemgnn_linear_stats_partial_bytes": (c_size_t, [I64, I64]),
+    "stemgnn_linear_fwd": (c_int, [P, P, I64, P, P, I64, P, I64, I64, P, P, P, P]),
+    "stemgnn_linear_bwd_weight_workspace_bytes": (c_size_t, [I64, I64, I64]),
+    "stemgnn_linear_bwd_weight": (c_int, [P, P, I64, I64, I64, P, P, P, c_size_t, P]),
+    "stemgnn_transpose": (c_int, [P, I64, I64, P, P]),
     "stemgnn_bn_act_drop_fwd": (c_int, [P, I64, I64, P, P, P, P, c_int, c_float, c_float, c_uint64, c_uint64, P, P]),
     "stemgnn_bn_act_drop_bwd": (c_int, [P, P, I64, I64, P, P, P, P, c_int, c_float, c_float, c_uint64, c_uint64,
                                         P, P, P, P, c_size_t, P]),

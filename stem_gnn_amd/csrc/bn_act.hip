@@ -12,7 +12,9 @@ namespace stemgnn {
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kMaxPartialBlocks = 1024;
+constexpr int kMaxPartialBlocks = 512;
+constexpr int kFinCols = 16;    // finalize: 16 columns x 16 partial slices per 256-thread block
+constexpr int kFinSlices = kBlock / kFinCols;
 
 __device__ inline float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ inline void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
@@ -92,6 +94,7 @@ k_col_partials(const float* __restrict__ y, const float* __restrict__ g_out, int
         if (mean) { m = ld4(mean + 4 * c); rs = ld4(rstd + 4 * c); }
         if (gamma) { ga = ld4(gamma + 4 * c); be = ld4(beta + 4 * c); }
       }
+#pragma unroll 4
       for (int64_t r = r0 + ry; r < r1; r += ty) {
         const float4 v = ld4(y + r * D + 4 * c);
         if (MODE == 0) {
@@ -132,18 +135,40 @@ k_col_partials(const float* __restrict__ y, const float* __restrict__ g_out, int
   }
 }
 
-// One thread per column: combine block partials in fp64.
+// Combine block partials in fp64: 16 columns x 16 slices per block, LDS tree over the slices.
+__device__ inline void reduce_partials(const float* __restrict__ partial, int blocks, int D, int c, int slice,
+                                       double* s_out, double* q_out) {
+  __shared__ double red_s[kBlock], red_q[kBlock];
+  double s = 0.0, q = 0.0;
+  if (c < D) {
+    for (int b = slice; b < blocks; b += kFinSlices) {
+      s += partial[(static_cast<int64_t>(b) * 2) * D + c];
+      q += partial[(static_cast<int64_t>(b) * 2 + 1) * D + c];
+    }
+  }
+  red_s[threadIdx.x] = s;
+  red_q[threadIdx.x] = q;
+  __syncthreads();
+  for (int o = kFinSlices / 2; o > 0; o >>= 1) {
+    if (slice < o) {
+      red_s[threadIdx.x] += red_s[threadIdx.x + o * kFinCols];
+      red_q[threadIdx.x] += red_q[threadIdx.x + o * kFinCols];
+    }
+    __syncthreads();
+  }
+  *s_out = red_s[threadIdx.x];
+  *q_out = red_q[threadIdx.x];
+}
+
 __global__ void __launch_bounds__(kBlock)
 k_stats_finalize(const float* __restrict__ partial, int blocks, int64_t N, int D, float eps,
                  float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ running_mean,
                  float* __restrict__ running_var, float momentum) {
-  const int c = blockIdx.x * kBlock + threadIdx.x;
-  if (c >= D) return;
-  double s = 0.0, q = 0.0;
-  for (int b = 0; b < blocks; ++b) {
-    s += partial[(static_cast<int64_t>(b) * 2) * D + c];
-    q += partial[(static_cast<int64_t>(b) * 2 + 1) * D + c];
-  }
+  const int cl = threadIdx.x % kFinCols, slice = threadIdx.x / kFinCols;
+  const int c = blockIdx.x * kFinCols + cl;
+  double s, q;
+  reduce_partials(partial, blocks, D, c, slice, &s, &q);
+  if (slice != 0 || c >= D) return;
   const double n = static_cast<double>(N);
   const double m = s / n;
   double var = q / n - m * m;
@@ -160,13 +185,11 @@ k_stats_finalize(const float* __restrict__ partial, int blocks, int64_t N, int D
 __global__ void __launch_bounds__(kBlock)
 k_grad_finalize(const float* __restrict__ partial, int blocks, int D, float* __restrict__ g_gamma,
                 float* __restrict__ g_beta) {
-  const int c = blockIdx.x * kBlock + threadIdx.x;
-  if (c >= D) return;
-  double s = 0.0, q = 0.0;
-  for (int b = 0; b < blocks; ++b) {
-    s += partial[(static_cast<int64_t>(b) * 2) * D + c];
-    q += partial[(static_cast<int64_t>(b) * 2 + 1) * D + c];
-  }
+  const int cl = threadIdx.x % kFinCols, slice = threadIdx.x / kFinCols;
+  const int c = blockIdx.x * kFinCols + cl;
+  double s, q;
+  reduce_partials(partial, blocks, D, c, slice, &s, &q);
+  if (slice != 0 || c >= D) return;
   g_beta[c] = static_cast<float>(s);
   g_gamma[c] = static_cast<float>(q);
 }
@@ -276,8 +299,21 @@ int stemgnn_bn_stats(const float* y, int64_t N, int64_t D, float eps, float* mea
   k_col_partials<0><<<blocks, kBlock, 0, st>>>(y, nullptr, N, static_cast<int>(D), g.tx, g.ty, nullptr, nullptr,
                                                nullptr, nullptr, ep, partial);
   STEMGNN_LAUNCH_CHECK();
-  k_stats_finalize<<<static_cast<int>((D + kBlock - 1) / kBlock), kBlock, 0, st>>>(
+  k_stats_finalize<<<static_cast<int>((D + kFinCols - 1) / kFinCols), kBlock, 0, st>>>(
       partial, blocks, N, static_cast<int>(D), eps, mean, rstd, running_mean, running_var, momentum);
+  STEMGNN_LAUNCH_CHECK();
+  return STEMGNN_OK;
+}
+
+int stemgnn_bn_stats_from_partials(const float* partial, int64_t blocks, int64_t N, int64_t D, float eps, float* mean,
+                                   float* rstd, float* running_mean, float* running_var, float momentum,
+                                   void* stream_) {
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  if (!dims_ok(N, D) || N == 0 || blocks <= 0 || blocks > (1 << 24) || !partial || !mean || !rstd)
+    return STEMGNN_ERR_INVALID_ARG;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return STEMGNN_ERR_INVALID_ARG;
+  k_stats_finalize<<<static_cast<int>((D + kFinCols - 1) / kFinCols), kBlock, 0, st>>>(
+      partial, static_cast<int>(blocks), N, static_cast<int>(D), eps, mean, rstd, running_mean, running_var, momentum);
   STEMGNN_LAUNCH_CHECK();
   return STEMGNN_OK;
 }
@@ -320,7 +356,7 @@ int stemgnn_bn_act_drop_bwd(const float* g_out, const float* y, int64_t N, int64
     k_col_partials<1><<<blocks, kBlock, 0, st>>>(y, g_out, N, static_cast<int>(D), g.tx, g.ty, mean, rstd, gamma, beta,
                                                  ep, partial);
     STEMGNN_LAUNCH_CHECK();
-    k_grad_finalize<<<static_cast<int>((D + kBlock - 1) / kBlock), kBlock, 0, st>>>(partial, blocks,
+    k_grad_finalize<<<static_cast<int>((D + kFinCols - 1) / kFinCols), kBlock, 0, st>>>(partial, blocks,
                                                                                    static_cast<int>(D), gg, gb);
     STEMGNN_LAUNCH_CHECK();
     sum_gb = gb;

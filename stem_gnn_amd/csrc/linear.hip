@@ -1,0 +1,376 @@
+// K3 / K5: dense per-layer projections on the fp32 matrix cores of gfx950.
+//
+// Reference: MySAGEConv's lin_l(agg) + lin_r(x) (STEM-GNN/model/encoder.py:83-87),
+// VectorQuantize.project_in / project_out (model/vq.py:881,1041) and the decoders' nn.Linear
+// layers (model/pt_model.py:42,80,94; model/encoder.py:364).  The reference leaves these to
+// ATen/cuBLAS plus separate bias-add, add and bias-gradient reduction kernels.  The activations
+// here are tall and skinny (M ~ 1e5 rows, N, K in {128, 256, 512}), a shape the vendor GEMM
+// library serves badly on this chip (12-30 TFLOP/s for the weight-gradient product), so the
+// three products are hand-written around v_mfma_f32_32x32x2_f32 (exact fp32; the reference runs
+// fp32 without autocast):
+//
+//   forward     Y[M,N]  = X1[M,K1] W1[N,K1]^T (+ X2[M,K2] W2[N,K2]^T) + b      (fused K-concat)
+//                         optional per-column sum / sum-of-squares partials of Y (BatchNorm stats)
+//   backward-W  dW[N,K] = dY[M,N]^T X[M,K],  db[N] = colsum(dY)   (split over M, two-stage,
+//                         deterministic: no atomics)
+//   backward-X  dX[M,K] = dY[M,N] W[N,K]  = forward with the transposed weight
+//
+// Tiling: 256-thread block = 4 waves in a 2x2 grid, 128x128 output tile, each wave 64x64 =
+// 2x2 MFMA tiles (64 accumulator registers); K (or M for backward-W) is consumed in chunks of
+// 32 staged through LDS with register prefetch of the next chunk.  MFMA-bound:
+// 2*M*N*K flop at 157 TFLOP/s vs (M*K + M*N)*4 bytes of HBM traffic.
+#include "common.h"
+
+namespace stemgnn {
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kBM = 128, kBN = 128, kKC = 32;
+constexpr int kLd = kKC + 4;  // 36-dword row stride: conflict-free ds_read_b128 of 32 rows x 16 B
+constexpr int kMaxSplits = 512;
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+__device__ inline float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ inline void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ inline float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// C-tile register r of lane (lj, hi) is row (r&3) + 8*(r>>2) + 4*hi, column lj.
+__device__ inline int acc_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+// ---------------------------------------------------------------------------------------
+// forward: Y = X1 W1^T (+ X2 W2^T) + b
+// ---------------------------------------------------------------------------------------
+template <bool STATS>
+__global__ void __launch_bounds__(kBlock, 2)
+k_linear_fwd(const float* __restrict__ x1, const float* __restrict__ w1, int K1, const float* __restrict__ x2,
+             const float* __restrict__ w2, int K2, const float* __restrict__ bias, int64_t M, int N,
+             float* __restrict__ y, float* __restrict__ stats_partial /*[gridDim.x][2][N]*/) {
+  __shared__ __attribute__((aligned(16))) float sA[kBM * kLd];
+  __shared__ __attribute__((aligned(16))) float sB[kBN * kLd];
+  __shared__ float s_stats[2][2][kBN];  // [wave_m][sum|sumsq][n]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, hi = lane >> 5, lj = lane & 31;
+  const int64_t m0 = static_cast<int64_t>(blockIdx.x) * kBM;
+  const int n0 = blockIdx.y * kBN;
+  const int c1 = (K1 + kKC - 1) / kKC, c2 = (K2 + kKC - 1) / kKC;
+  const int steps = c1 + c2;
+
+  float4 ra[4], rb[4];
+  auto fetch = [&](int step) {
+    const bool second = step >= c1;
+    const float* xs = second ? x2 : x1;
+    const float* ws = second ? w2 : w1;
+    const int K = second ? K2 : K1;
+    const int k0 = (second ? step - c1 : step) * kKC;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int idx = t * kBlock + tid;  // 1024 float4 per operand chunk: row = idx / 8, 16-byte column = idx % 8
+      const int r = idx >> 3, k = k0 + 4 * (idx & 7);
+      const int64_t m = m0 + r;
+      const int n = n0 + r;
+      ra[t] = (m < M && k < K) ? ld4(xs + m * K + k) : zero4();
+      rb[t] = (n < N && k < K) ? ld4(ws + static_cast<int64_t>(n) * K + k) : zero4();
+    }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int idx = t * kBlock + tid;
+      st4(sA + (idx >> 3) * kLd + 4 * (idx & 7), ra[t]);
+      st4(sB + (idx >> 3) * kLd + 4 * (idx & 7), rb[t]);
+    }
+  };
+
+  floatx16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  fetch(0);
+  for (int step = 0; step < steps; ++step) {
+    stash();
+    __syncthreads();
+    if (step + 1 < steps) fetch(step + 1);
+#pragma unroll
+    for (int ms = 0; ms < kKC / 8; ++ms) {
+      const int ko = ms * 8 + hi * 4;  // lane half 0 takes k 0..3, half 1 takes k 4..7 of the micro-step
+      float4 a[2], b[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        a[t] = ld4(sA + (wm * 64 + t * 32 + lj) * kLd + ko);
+        b[t] = ld4(sB + (wn * 64 + t * 32 + lj) * kLd + ko);
+      }
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].x, b[tn].x, acc[tm][tn], 0, 0, 0);
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].y, b[tn].y, acc[tm][tn], 0, 0, 0);
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].z, b[tn].z, acc[tm][tn], 0, 0, 0);
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].w, b[tn].w, acc[tm][tn], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias, store (two 128-byte row segments per store instruction), column stats
+#pragma unroll
+  for (int tn = 0; tn < 2; ++tn) {
+    const int nl = wn * 64 + tn * 32 + lj;
+    const int n = n0 + nl;
+    const float bv = (bias != nullptr && n < N) ? bias[n] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t m = m0 + wm * 64 + tm * 32 + acc_row(r, hi);
+        const float v = acc[tm][tn][r] + bv;
+        if (m < M && n < N) {
+          y[m * N + n] = v;
+          if (STATS) { s1 += v; s2 += v * v; }
+        }
+      }
+    }
+    if (STATS) {
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (hi == 0) { s_stats[wm][0][nl] = s1; s_stats[wm][1][nl] = s2; }
+    }
+  }
+  if (STATS) {
+    __syncthreads();
+    if (tid < kBN && n0 + tid < N) {
+      float* p = stats_partial + static_cast<int64_t>(blockIdx.x) * 2 * N;
+      p[n0 + tid] = s_stats[0][0][tid] + s_stats[1][0][tid];
+      p[N + n0 + tid] = s_stats[0][1][tid] + s_stats[1][1][tid];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// backward-W: partial[s] = dY[rows of split s]^T X[rows of split s]; partial_db[s] = colsum dY
+// C[i = n][j = k]; the reduction index (row m) is the slow dimension of BOTH operands, so the
+// MFMA fragments are 4-byte LDS reads along a row (conflict-free: 32 consecutive dwords).
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock, 2)
+k_linear_bwd_weight(const float* __restrict__ dy, const float* __restrict__ x, int64_t M, int N, int K,
+                    int64_t rows_per_split, float* __restrict__ partial_dw /*[S][N][K]*/,
+                    float* __restrict__ partial_db /*[S][N]*/) {
+  __shared__ __attribute__((aligned(16))) float sA[kKC * kBN];  // dY chunk [32 m][128 n]
+  __shared__ __attribute__((aligned(16))) float sB[kKC * kBN];  // X  chunk [32 m][128 k]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wi = wave >> 1, wj = wave & 1, hi = lane >> 5, lj = lane & 31;
+  const int split = blockIdx.x;
+  const int n0 = blockIdx.y * kBN, k0 = blockIdx.z * kBN;
+  const int64_t mbeg = split * rows_per_split;
+  const int64_t mend = min(M, mbeg + rows_per_split);
+  const int steps = static_cast<int>((mend - mbeg + kKC - 1) / kKC);
+
+  float4 ra[4], rb[4];
+  auto fetch = [&](int step) {
+    const int64_t mm = mbeg + static_cast<int64_t>(step) * kKC;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int idx = t * kBlock + tid;  // 32 rows x 32 float4
+      const int r = idx >> 5, c = 4 * (idx & 31);
+      const int64_t m = mm + r;
+      ra[t] = (m < mend && n0 + c < N) ? ld4(dy + m * N + n0 + c) : zero4();
+      rb[t] = (m < mend && k0 + c < K) ? ld4(x + m * K + k0 + c) : zero4();
+    }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int idx = t * kBlock + tid;
+      st4(sA + (idx >> 5) * kBN + 4 * (idx & 31), ra[t]);
+      st4(sB + (idx >> 5) * kBN + 4 * (idx & 31), rb[t]);
+    }
+  };
+
+  floatx16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  float colsum = 0.f;
+
+  if (steps > 0) fetch(0);
+  for (int step = 0; step < steps; ++step) {
+    stash();
+    __syncthreads();
+    if (step + 1 < steps) fetch(step + 1);
+#pragma unroll 4
+    for (int ks = 0; ks < kKC / 2; ++ks) {
+      const int row = 2 * ks + hi;
+      float a[2], b[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        a[t] = sA[row * kBN + wi * 64 + t * 32 + lj];
+        b[t] = sB[row * kBN + wj * 64 + t * 32 + lj];
+      }
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+          acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ti], b[tj], acc[ti][tj], 0, 0, 0);
+    }
+    if (blockIdx.z == 0 && tid < kBN) {
+#pragma unroll 8
+      for (int r = 0; r < kKC; ++r) colsum += sA[r * kBN + tid];
+    }
+    __syncthreads();
+  }
+
+  float* pw = partial_dw + static_cast<int64_t>(split) * N * K;
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj) {
+      const int k = k0 + wj * 64 + tj * 32 + lj;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wi * 64 + ti * 32 + acc_row(r, hi);
+        if (n < N && k < K) pw[static_cast<int64_t>(n) * K + k] = acc[ti][tj][r];
+      }
+    }
+  if (blockIdx.z == 0 && tid < kBN && n0 + tid < N && partial_db != nullptr)
+    partial_db[static_cast<int64_t>(split) * N + n0 + tid] = colsum;
+}
+
+// out[i] = sum_s partial[s][i] in split order (deterministic), fp32 pairwise-free plain order.
+__global__ void __launch_bounds__(kBlock)
+k_reduce_splits(const float* __restrict__ partial, int splits, int64_t n, float* __restrict__ out) {
+  const int64_t i = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) * 4;
+  if (i >= n) return;
+  if (i + 3 < n) {
+    float4 a = zero4();
+    for (int s = 0; s < splits; ++s) {
+      const float4 v = ld4(partial + static_cast<int64_t>(s) * n + i);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    st4(out + i, a);
+  } else {
+    for (int64_t j = i; j < n; ++j) {
+      float a = 0.f;
+      for (int s = 0; s < splits; ++s) a += partial[static_cast<int64_t>(s) * n + j];
+      out[j] = a;
+    }
+  }
+}
+
+// out[c][r] = in[r][c] for small weight matrices (backward-X uses the forward kernel on W^T).
+__global__ void __launch_bounds__(kBlock)
+k_transpose(const float* __restrict__ in, int R, int C, float* __restrict__ out) {
+  __shared__ float tile[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int j = ty; j < 32; j += 8) {
+    const int r = by + j, c = bx + tx;
+    tile[j][tx] = (r < R && c < C) ? in[static_cast<int64_t>(r) * C + c] : 0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int c = bx + j, r = by + tx;
+    if (r < R && c < C) out[static_cast<int64_t>(c) * R + r] = tile[tx][j];
+  }
+}
+
+inline bool lin_dims_ok(int64_t M, int64_t N, int64_t K) {
+  return M >= 0 && N > 0 && K > 0 && K % 4 == 0 && N <= 65536 && K <= 65536;
+}
+
+inline int pick_splits(int64_t M) {
+  int64_t s = (M + 511) / 512;  // >= 512 rows (16 chunks) per split
+  if (s < 1) s = 1;
+  if (s > kMaxSplits) s = kMaxSplits;
+  return static_cast<int>(s);
+}
+
+}  // namespace
+}  // namespace stemgnn
+
+using namespace stemgnn;
+
+extern "C" {
+
+size_t stemgnn_linear_stats_partial_bytes(int64_t M, int64_t N) {
+  if (M < 0 || N <= 0) return 0;
+  return static_cast<size_t>((M + kBM - 1) / kBM) * 2 * N * sizeof(float) + 256;
+}
+
+int stemgnn_linear_fwd(const float* x1, const float* w1, int64_t K1, const float* x2, const float* w2, int64_t K2,
+                       const float* bias, int64_t M, int64_t N, float* y, float* stats_partial,
+                       int64_t* stats_blocks_host, void* stream_) {
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  if (!lin_dims_ok(M, N, K1) || K2 < 0 || K2 % 4 != 0) return STEMGNN_ERR_INVALID_ARG;
+  if (!fits_i32(M)) return STEMGNN_ERR_TOO_LARGE;
+  if (stats_blocks_host) *stats_blocks_host = (M + kBM - 1) / kBM;
+  if (M == 0) return STEMGNN_OK;
+  if (!x1 || !w1 || !y || (K2 > 0 && (!x2 || !w2))) return STEMGNN_ERR_INVALID_ARG;
+  if (N % 4 != 0) return STEMGNN_ERR_INVALID_ARG;
+  dim3 grid(static_cast<unsigned>((M + kBM - 1) / kBM), static_cast<unsigned>((N + kBN - 1) / kBN));
+  if (stats_partial)
+    k_linear_fwd<true><<<grid, kBlock, 0, st>>>(x1, w1, static_cast<int>(K1), x2, w2, static_cast<int>(K2), bias, M,
+                                                static_cast<int>(N), y, stats_partial);
+  else
+    k_linear_fwd<false><<<grid, kBlock, 0, st>>>(x1, w1, static_cast<int>(K1), x2, w2, static_cast<int>(K2), bias, M,
+                                                 static_cast<int>(N), y, nullptr);
+  STEMGNN_LAUNCH_CHECK();
+  return STEMGNN_OK;
+}
+
+size_t stemgnn_linear_bwd_weight_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  if (!lin_dims_ok(M, N, K)) return 0;
+  return static_cast<size_t>(pick_splits(M)) * (N * K + N) * sizeof(float) + 512;
+}
+
+int stemgnn_linear_bwd_weight(const float* dy, const float* x, int64_t M, int64_t N, int64_t K, float* dw, float* db,
+                              void* workspace, size_t workspace_bytes, void* stream_) {
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  if (!lin_dims_ok(M, N, K) || N % 4 != 0 || !dw) return STEMGNN_ERR_INVALID_ARG;
+  if (!fits_i32(M)) return STEMGNN_ERR_TOO_LARGE;
+  if (M == 0) {
+    STEMGNN_HIP_TRY(hipMemsetAsync(dw, 0, sizeof(float) * N * K, st));
+    if (db) STEMGNN_HIP_TRY(hipMemsetAsync(db, 0, sizeof(float) * N, st));
+    return STEMGNN_OK;
+  }
+  if (!dy || !x || !workspace) return STEMGNN_ERR_INVALID_ARG;
+  if (workspace_bytes < stemgnn_linear_bwd_weight_workspace_bytes(M, N, K)) return STEMGNN_ERR_WORKSPACE;
+  const int S = pick_splits(M);
+  int64_t rows = (M + S - 1) / S;
+  rows = (rows + kKC - 1) / kKC * kKC;
+  float* pw = reinterpret_cast<float*>(align_up(reinterpret_cast<uintptr_t>(workspace), 256));
+  float* pb = pw + static_cast<size_t>(S) * N * K;
+  dim3 grid(static_cast<unsigned>(S), static_cast<unsigned>((N + kBN - 1) / kBN), static_cast<unsigned>((K + kBN - 1) / kBN));
+  k_linear_bwd_weight<<<grid, kBlock, 0, st>>>(dy, x, M, static_cast<int>(N), static_cast<int>(K), rows, pw,
+                                               db ? pb : nullptr);
+  STEMGNN_LAUNCH_CHECK();
+  const int64_t nk = N * K;
+  k_reduce_splits<<<static_cast<unsigned>((nk / 4 + kBlock) / kBlock), kBlock, 0, st>>>(pw, S, nk, dw);
+  STEMGNN_LAUNCH_CHECK();
+  if (db) {
+    k_reduce_splits<<<static_cast<unsigned>((N / 4 + kBlock) / kBlock), kBlock, 0, st>>>(pb, S, N, db);
+    STEMGNN_LAUNCH_CHECK();
+  }
+  return STEMGNN_OK;
+}
+
+int stemgnn_transpose(const float* in, int64_t rows, int64_t cols, float* out, void* stream_) {
+  if (rows <= 0 || cols <= 0 || !in || !out) return STEMGNN_ERR_INVALID_ARG;
+  dim3 grid(static_cast<unsigned>((cols + 31) / 32), static_cast<unsigned>((rows + 31) / 32));
+  k_transpose<<<grid, kBlock, 0, static_cast<hipStream_t>(stream_)>>>(in, static_cast<int>(rows),
+                                                                     static_cast<int>(cols), out);
+  STEMGNN_LAUNCH_CHECK();
+  return STEMGNN_OK;
+}
+
+}  // extern "C"

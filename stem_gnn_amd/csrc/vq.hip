@@ -37,7 +37,7 @@ __device__ inline float4 ld4(const float* p) { return *reinterpret_cast<const fl
 __device__ inline void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
 template <int CG>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock, 2)
 k_vq_assign(const float* __restrict__ xp, int64_t N, int H, int Dc, const float* __restrict__ embed, int K,
             int training, float* __restrict__ xn_out, float* __restrict__ norm_out, int64_t* __restrict__ ind_out,
             float* __restrict__ quant, float* __restrict__ sq_partial) {

@@ -96,14 +96,24 @@ class MySAGEConv(nn.Module):
             x = (x, x)
         if size is not None and (size[0] != size[1] or size[0] != x[0].size(0)):
             raise NotImplementedError("bipartite propagation is not used by the reference path")
-        out = aggregate(x[0], edge_index, edge_attr)
-        out = self.lin_l(out)
+        out, _ = self._forward_fused(x, edge_index, edge_attr, want_stats=False)
+        return out
+
+    def _forward_fused(self, x, edge_index, edge_attr, want_stats: bool):
+        """lin_l(agg) + lin_r(x) as ONE MFMA kernel over the concatenated K dimension; optionally
+        also returns the BatchNorm column partials of the output (fused epilogue)."""
+        agg = aggregate(x[0], edge_index, edge_attr)
         x_r = x[1]
         if self.root_weight and x_r is not None:
-            out = out + self.lin_r(x_r)
+            out, partial = ops.LinearFn.apply(agg, self.lin_l.weight, x_r, self.lin_r.weight, self.lin_l.bias,
+                                              want_stats and not self.normalize)
+        else:
+            out, partial = ops.LinearFn.apply(agg, self.lin_l.weight, None, None, self.lin_l.bias,
+                                              want_stats and not self.normalize)
         if self.normalize:
             out = F.normalize(out, p=2.0, dim=-1)
-        return out
+            partial = None
+        return out, partial
 
     def __repr__(self) -> str:
         return f"{self.__class__.__name__}({self.in_channels}, {self.out_channels}, aggr={self.aggr})"
@@ -272,8 +282,9 @@ class Encoder(nn.Module):
     def forward(self, x, edge_index, edge_attr=None):
         return self.encode(x, edge_index, edge_attr)
 
-    def _norm_act_drop(self, i: int, z: Tensor, last: bool) -> Tensor:
-        """norms[i] -> activation -> dropout (encoder.py:313-317) as ONE fused op."""
+    def _norm_act_drop(self, i: int, z: Tensor, last: bool, partial: Optional[Tensor] = None) -> Tensor:
+        """norms[i] -> activation -> dropout (encoder.py:313-317) as ONE fused op.  ``partial``:
+        column partials of z from the producing linear kernel (saves the statistics pass)."""
         use_bn = self.normalize != "none"
         norm = self.norms[i]
         act = 0 if last else self._act_code
@@ -296,8 +307,11 @@ class Encoder(nn.Module):
                     momentum = 1.0 / float(norm.num_batches_tracked)
             rm = norm.running_mean if norm.track_running_stats else None
             rv = norm.running_var if norm.track_running_stats else None
+            stats = None
+            if partial is not None and z.size(0) > 1:
+                stats = ops.bn_stats_from_partials(partial, partial.size(0), z.size(0), norm.eps, rm, rv, momentum)
             return ops.BnActDropFn.apply(z, norm.weight, norm.bias, rm, rv, True, momentum, norm.eps, act,
-                                         self._slope, p, seed, offset)
+                                         self._slope, p, seed, offset, stats)
         return ops.BnActDropFn.apply(z, None, None, None, None, False, 0.0, 0.0, act, self._slope, p, seed, offset)
 
     def encode(self, x, edge_index, edge_attr=None):
@@ -329,9 +343,11 @@ class Encoder(nn.Module):
                 expert_outputs = layer(z, graph, edge_attr)
                 z = torch.sum(weights.unsqueeze(-1) * expert_outputs, dim=1)
                 env_idx += 1
+                partial = None
             else:
-                z = layer(z, graph, edge_attr)
-            z = self._norm_act_drop(i, z, last=(i == self.num_layers - 1))
+                want = self.normalize != "none" and self.training
+                z, partial = layer._forward_fused((z, z), graph, edge_attr, want_stats=want)
+            z = self._norm_act_drop(i, z, last=(i == self.num_layers - 1), partial=partial)
 
         if env_reg_total is not None and self.training and env_layers > 0:
             self._last_env_reg = env_reg_total / env_layers
@@ -360,7 +376,7 @@ class InnerProductDecoder(nn.Module):
             self.lin = nn.Linear(hidden_dim, output_dim)
 
     def forward(self, z: Tensor, edge_index: Tensor, sigmoid: bool = True) -> Tensor:
-        z = self.lin(z) if self.proj_z else z
+        z = ops.linear(z, self.lin) if self.proj_z else z
         value = ops.EdgeDotFn.apply(z, edge_index)
         return torch.sigmoid(value) if sigmoid else value
 

@@ -73,8 +73,12 @@ class PretrainModel(nn.Module):
         torch.save(self.vq.state_dict(), path)
 
     # -- losses ---------------------------------------------------------------------------
+    @staticmethod
+    def _lin(module, t):
+        return ops.linear(t, module) if isinstance(module, nn.Linear) else module(t)
+
     def feat_recon(self, z):
-        return self.feat_recon_decoder(z)
+        return self._lin(self.feat_recon_decoder, z)
 
     def feat_recon_loss(self, z, x, bs=None):
         return F.mse_loss(self.feat_recon(z[:bs]), x[:bs])  # pt_model.py:42-43
@@ -118,15 +122,16 @@ class PretrainModel(nn.Module):
             edge_attr = edge_attr[perm]
         target = edge_attr.dense() if isinstance(edge_attr, EdgeTypeAttr) else edge_attr
         zz = ops.EdgeConcatFn.apply(z, edge_index.contiguous())  # cat([z[u], z[v]]), pt_model.py:80
-        return F.mse_loss(self.topo_sem_recon_decoder(zz), target)
+        return F.mse_loss(self._lin(self.topo_sem_recon_decoder, zz), target)
 
     def sem_recon_loss(self, g, quantize, eta=1.0, bs=None):
         orig_x, orig_edge_index, orig_edge_attr = g[0], g[1], g[2]
         with torch.no_grad():  # .detach() in the reference (pt_model.py:93); teacher stays in train mode
             z = self.sem_encoder(orig_x, orig_edge_index, orig_edge_attr)
-        h = self.sem_projector(quantize)
+        # the projector is row-wise and only rows [:bs] are used (pt_model.py:94-97): project those rows only
+        h = self._lin(self.sem_projector, quantize[:bs])
         z = F.normalize(z[:bs], dim=-1, p=2)
-        h = F.normalize(h[:bs], dim=-1, p=2)
+        h = F.normalize(h, dim=-1, p=2)
         loss = (1 - (z * h).sum(dim=-1)).pow_(eta)
         return loss.mean()
 

@@ -198,6 +198,10 @@ class VectorQuantize(nn.Module):
     def get_output_from_indices(self, indices):
         return self.project_out(self.get_codes_from_indices(indices))
 
+    @staticmethod
+    def _project(lin, t):
+        return ops.linear(t, lin) if isinstance(lin, nn.Linear) else lin(t)
+
     def forward(self, x, indices=None, mask=None, sample_codebook_temp=None, freeze_codebook=False):
         if indices is not None or mask is not None:
             raise NotImplementedError("indices= / mask= are never passed by the reference's call sites")
@@ -208,7 +212,7 @@ class VectorQuantize(nn.Module):
         n = x.size(0)
         h, dc = self.heads, self.codebook_dim
         cb = self._codebook
-        xp = self.project_in(x).float()  # vq.py:881; the codebook forces fp32 (vq.py:623,634)
+        xp = self._project(self.project_in, x).float()  # vq.py:881; the codebook forces fp32 (vq.py:623,634)
         if not cb._initted_host:
             with torch.no_grad():
                 cb.init_embed_(l2norm(xp.detach().view(n, h, dc).permute(1, 0, 2)))
@@ -233,7 +237,7 @@ class VectorQuantize(nn.Module):
         if h == 1:
             embed_ind = embed_ind.view(n)  # heads == 1 is not "multiheaded" (vq.py:865)
         orig_quantize = quant  # [N, H*Dc], heads already merged 'b n (h d)' (vq.py:1034)
-        quantize = self.project_out(quant)  # vq.py:1041
+        quantize = self._project(self.project_out, quant)  # vq.py:1041
         if not only_one:
             quantize = quantize.reshape(*lead, -1)
             orig_quantize = orig_quantize.reshape(*lead, -1)

@@ -222,11 +222,25 @@ def bn_stats(y: Tensor, eps: float, running_mean: Optional[Tensor], running_var:
     return mean, rstd
 
 
+def bn_stats_from_partials(partial: Tensor, blocks: int, num_rows: int, eps: float, running_mean: Optional[Tensor],
+                           running_var: Optional[Tensor], momentum: float) -> Tuple[Tensor, Tensor]:
+    """Finalise BatchNorm statistics from the column partials LinearFn's fused epilogue wrote."""
+    D = partial.size(-1)
+    mean = torch.empty(D, dtype=torch.float32, device=partial.device)
+    rstd = torch.empty_like(mean)
+    check(lib.stemgnn_bn_stats_from_partials(_p(partial), blocks, num_rows, D, float(eps), _p(mean), _p(rstd),
+                                             _p(running_mean), _p(running_var), float(momentum), _stream()),
+          "bn_stats_from_partials")
+    return mean, rstd
+
+
 class BnActDropFn(torch.autograd.Function):
-    """dropout(act(batch_norm(y))) with training statistics (reference model/encoder.py:313-317)."""
+    """dropout(act(batch_norm(y))) with training statistics (reference model/encoder.py:313-317).
+    ``stats`` = (mean, rstd) already computed by a producer (LinearFn's fused epilogue)."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, running_mean, running_var, use_bn, momentum, eps, act, slope, p, seed, offset):
+    def forward(ctx, y, gamma, beta, running_mean, running_var, use_bn, momentum, eps, act, slope, p, seed, offset,
+                stats=None):
         y = y.contiguous()
         _req(y, torch.float32, "y", 2)
         N, D = y.shape
@@ -234,7 +248,10 @@ class BnActDropFn(torch.autograd.Function):
         if use_bn:
             if N <= 1:
                 raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(y.shape)}")
-            mean, rstd = bn_stats(y, eps, running_mean, running_var, momentum)
+            if stats is not None:
+                mean, rstd = stats
+            else:
+                mean, rstd = bn_stats(y, eps, running_mean, running_var, momentum)
         out = torch.empty_like(y)
         g = gamma if use_bn else None
         b = beta if use_bn else None
@@ -260,7 +277,102 @@ class BnActDropFn(torch.autograd.Function):
         check(lib.stemgnn_bn_act_drop_bwd(_p(g_out), _p(y), N, D, _p(mean), _p(rstd), _p(gamma), _p(beta), act, slope, p,
                                           seed, offset, _p(g_y), _p(g_gamma), _p(g_beta), _p(ws),
                                           0 if ws is None else ws.numel(), _stream()), "bn_act_drop_bwd")
-        return (g_y, g_gamma, g_beta) + (None,) * 10
+        return (g_y, g_gamma, g_beta) + (None,) * 11
+
+
+# ----------------------------------------------------------------------------------------
+# K3 / K5: dense projections on the fp32 matrix cores
+# ----------------------------------------------------------------------------------------
+def linear_fwd(x1: Tensor, w1: Tensor, x2: Optional[Tensor], w2: Optional[Tensor], bias: Optional[Tensor],
+               want_stats: bool = False):
+    """y = x1 w1^T (+ x2 w2^T) + bias; optionally the per-row-block column partials of y."""
+    _req(x1, torch.float32, "x1", 2)
+    _req(w1, torch.float32, "w1", 2)
+    M, K1 = x1.shape
+    N = w1.size(0)
+    if w1.size(1) != K1:
+        raise RuntimeError(f"linear: x1 {tuple(x1.shape)} vs w1 {tuple(w1.shape)}")
+    K2 = 0
+    if x2 is not None:
+        _req(x2, torch.float32, "x2", 2)
+        _req(w2, torch.float32, "w2", 2)
+        K2 = x2.size(1)
+        if x2.size(0) != M or tuple(w2.shape) != (N, K2):
+            raise RuntimeError("linear: second operand pair has inconsistent shapes")
+    if bias is not None:
+        _req(bias, torch.float32, "bias", 1)
+    y = torch.empty(M, N, dtype=torch.float32, device=x1.device)
+    partial = None
+    blocks = (M + 127) // 128
+    if want_stats:
+        partial = torch.empty(max(blocks, 1), 2, N, dtype=torch.float32, device=x1.device)
+    check(lib.stemgnn_linear_fwd(_p(x1), _p(w1), K1, _p(x2), _p(w2), K2, _p(bias), M, N, _p(y), _p(partial), None,
+                                 _stream()), "linear_fwd")
+    return y, partial, blocks
+
+
+def linear_bwd_weight(dy: Tensor, x: Tensor, want_bias: bool):
+    """dw = dy^T x, db = colsum(dy) (deterministic split reduction)."""
+    M, N = dy.shape
+    K = x.size(1)
+    dw = torch.empty(N, K, dtype=torch.float32, device=dy.device)
+    db = torch.empty(N, dtype=torch.float32, device=dy.device) if want_bias else None
+    ws = _workspace(lib.stemgnn_linear_bwd_weight_workspace_bytes(M, N, K), dy.device)
+    check(lib.stemgnn_linear_bwd_weight(_p(dy), _p(x), M, N, K, _p(dw), _p(db), _p(ws), ws.numel(), _stream()),
+          "linear_bwd_weight")
+    return dw, db
+
+
+def transpose(w: Tensor) -> Tensor:
+    _req(w, torch.float32, "w", 2)
+    out = torch.empty(w.size(1), w.size(0), dtype=torch.float32, device=w.device)
+    check(lib.stemgnn_transpose(_p(w), w.size(0), w.size(1), _p(out), _stream()), "transpose")
+    return out
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x1 w1^T (+ x2 w2^T) + b on the fp32 MFMA path; returns (y, column partials or None).
+    Replaces nn.Linear / lin_l + lin_r (reference model/encoder.py:83-87, model/vq.py:881,1041)."""
+
+    @staticmethod
+    def forward(ctx, x1, w1, x2, w2, bias, want_stats):
+        x1 = x1.contiguous()
+        w1c = w1.contiguous()
+        x2c = None if x2 is None else x2.contiguous()
+        w2c = None if w2 is None else w2.contiguous()
+        y, partial, blocks = linear_fwd(x1, w1c, x2c, w2c, bias, want_stats)
+        ctx.save_for_backward(x1, w1c, x2c, w2c)
+        ctx.has_bias = bias is not None
+        if partial is not None:
+            ctx.mark_non_differentiable(partial)
+        return y, partial
+
+    @staticmethod
+    def backward(ctx, gy, _gpartial):
+        x1, w1, x2, w2 = ctx.saved_tensors
+        gy = gy.contiguous()
+        need = ctx.needs_input_grad
+        gx1 = gw1 = gx2 = gw2 = gb = None
+        if need[0]:
+            gx1, _, _ = linear_fwd(gy, transpose(w1), None, None, None)
+        if need[1]:
+            gw1, gb = linear_bwd_weight(gy, x1, ctx.has_bias and need[4])
+        if x2 is not None:
+            if need[2]:
+                gx2, _, _ = linear_fwd(gy, transpose(w2), None, None, None)
+            if need[3]:
+                gw2, gb2 = linear_bwd_weight(gy, x2, ctx.has_bias and need[4] and gb is None)
+                gb = gb if gb is not None else gb2
+        if ctx.has_bias and need[4] and gb is None:
+            gb = gy.sum(dim=0)
+        return gx1, gw1, gx2, gw2, gb, None
+
+
+def linear(x: Tensor, lin: "torch.nn.Linear") -> Tensor:
+    """nn.Linear forward through LinearFn (any leading dims)."""
+    lead = x.shape[:-1]
+    y, _ = LinearFn.apply(x.reshape(-1, x.shape[-1]), lin.weight, None, None, lin.bias, False)
+    return y.reshape(*lead, y.shape[-1])
 
 
 # ----------------------------------------------------------------------------------------

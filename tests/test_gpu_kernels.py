@@ -203,3 +203,38 @@ def test_gather_rows_and_ema_lerp(dev):
     tg = t.to(dev)
     ops.ema_lerp_(tg, s.to(dev), 0.99)
     torch.testing.assert_close(tg.cpu(), t * 0.99 + s * (1 - 0.99), rtol=1e-6, atol=1e-7)
+
+
+# ---------------------------------------------------------------------------- K3 / K5
+@pytest.mark.parametrize("m,k1,k2,n,bias", [(1, 32, 0, 32, True), (130, 32, 32, 64, True), (1000, 128, 128, 128, True),
+                                            (777, 128, 0, 512, True), (513, 512, 0, 128, False),
+                                            (4100, 768, 768, 768, True), (300, 48, 0, 36, True)])
+def test_linear_fwd_bwd_and_stats(dev, m, k1, k2, n, bias):
+    from stem_gnn_amd import ops
+    torch.manual_seed(m + n)
+    x1, w1 = torch.randn(m, k1), torch.randn(n, k1) / k1 ** 0.5
+    x2 = torch.randn(m, k2) if k2 else None
+    w2 = torch.randn(n, k2) / k2 ** 0.5 if k2 else None
+    b = torch.randn(n) if bias else None
+    g = torch.randn(m, n)
+    refs = [t.clone().requires_grad_(True) if t is not None else None for t in (x1, w1, x2, w2, b)]
+    yr = refs[0] @ refs[1].t()
+    if k2:
+        yr = yr + refs[2] @ refs[3].t()
+    if bias:
+        yr = yr + refs[4]
+    (yr * g).sum().backward()
+    gp = [t.to(dev).requires_grad_(True) if t is not None else None for t in (x1, w1, x2, w2, b)]
+    yg, partial = ops.LinearFn.apply(gp[0], gp[1], gp[2], gp[3], gp[4], True)
+    (yg * g.to(dev)).sum().backward()
+    # exact-fp32 MFMA chains vs ATen's blocked GEMM: agreement ~1e-6 * sum|a*b|
+    torch.testing.assert_close(yg.detach().cpu(), yr.detach(), rtol=1e-4, atol=1e-4)
+    for a, r, name in zip(gp, refs, ("x1", "w1", "x2", "w2", "bias")):
+        if a is not None:
+            scale = float(r.grad.abs().max()) + 1e-6
+            torch.testing.assert_close(a.grad.cpu(), r.grad, rtol=1e-4, atol=1e-5 * scale + 1e-5,
+                                       msg=lambda s: f"{name}: {s}")
+    # fused column statistics == statistics of the stored output
+    ps = partial.sum(dim=0).cpu()
+    torch.testing.assert_close(ps[0], yr.detach().sum(dim=0), rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(ps[1], (yr.detach() ** 2).sum(dim=0), rtol=1e-4, atol=1e-3)
