@@ -91,6 +91,13 @@ k_linear_fwd(const float* __restrict__ x1, const float* __restrict__ w1, int K1,
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+  float bias_v[2];
+#pragma unroll
+  for (int tn = 0; tn < 2; ++tn) {
+    const int n = n0 + wn * 64 + tn * 32 + lj;
+    bias_v[tn] = (bias != nullptr && n < N) ? bias[n] : 0.f;
+  }
+
   fetch(0);
   for (int step = 0; step < steps; ++step) {
     stash();
@@ -118,22 +125,38 @@ k_linear_fwd(const float* __restrict__ x1, const float* __restrict__ w1, int K1,
     __syncthreads();
   }
 
-  // ---- epilogue: bias, store (two 128-byte row segments per store instruction), column stats
+  // ---- epilogue: bias, store (two 128-byte row segments per store instruction), column stats.
+  // The bias was loaded before the main loop: the epilogue issues stores only, so no
+  // s_waitcnt vmcnt(0) ever serialises them (vmcnt counts stores too).
+  const bool interior = (m0 + kBM <= M) && (n0 + kBN <= N);
 #pragma unroll
   for (int tn = 0; tn < 2; ++tn) {
     const int nl = wn * 64 + tn * 32 + lj;
     const int n = n0 + nl;
-    const float bv = (bias != nullptr && n < N) ? bias[n] : 0.f;
+    const float bv = bias_v[tn];
     float s1 = 0.f, s2 = 0.f;
+    if (interior) {
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm) {
+      for (int tm = 0; tm < 2; ++tm) {
+        float* yp = y + (m0 + wm * 64 + tm * 32 + 4 * hi) * N + n;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t m = m0 + wm * 64 + tm * 32 + acc_row(r, hi);
-        const float v = acc[tm][tn][r] + bv;
-        if (m < M && n < N) {
-          y[m * N + n] = v;
+        for (int r = 0; r < 16; ++r) {
+          const float v = acc[tm][tn][r] + bv;
+          yp[static_cast<int64_t>((r & 3) + 8 * (r >> 2)) * N] = v;
           if (STATS) { s1 += v; s2 += v * v; }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t m = m0 + wm * 64 + tm * 32 + acc_row(r, hi);
+          const float v = acc[tm][tn][r] + bv;
+          if (m < M && n < N) {
+            y[m * N + n] = v;
+            if (STATS) { s1 += v; s2 += v * v; }
+          }
         }
       }
     }
@@ -246,25 +269,32 @@ k_linear_bwd_weight(const float* __restrict__ dy, const float* __restrict__ x, i
     partial_db[static_cast<int64_t>(split) * N + n0 + tid] = colsum;
 }
 
-// out[i] = sum_s partial[s][i] in split order (deterministic), fp32 pairwise-free plain order.
+// out[i] = sum_s partial[s][i]: 16 float4 columns x 16 split-slices per block, fixed-order LDS
+// tree over the slices (deterministic).
 __global__ void __launch_bounds__(kBlock)
 k_reduce_splits(const float* __restrict__ partial, int splits, int64_t n, float* __restrict__ out) {
-  const int64_t i = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) * 4;
-  if (i >= n) return;
-  if (i + 3 < n) {
-    float4 a = zero4();
-    for (int s = 0; s < splits; ++s) {
+  __shared__ float4 red[kBlock];
+  const int col = threadIdx.x & 15, slice = threadIdx.x >> 4;
+  const int64_t i = (static_cast<int64_t>(blockIdx.x) * 16 + col) * 4;
+  float4 a = zero4();
+  if (i < n) {
+    for (int s = slice; s < splits; s += 16) {
       const float4 v = ld4(partial + static_cast<int64_t>(s) * n + i);
       a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
     }
-    st4(out + i, a);
-  } else {
-    for (int64_t j = i; j < n; ++j) {
-      float a = 0.f;
-      for (int s = 0; s < splits; ++s) a += partial[static_cast<int64_t>(s) * n + j];
-      out[j] = a;
-    }
   }
+  red[threadIdx.x] = a;
+  __syncthreads();
+  for (int o = 8; o > 0; o >>= 1) {
+    if (slice < o) {
+      const float4 b = red[threadIdx.x + o * 16];
+      float4 c = red[threadIdx.x];
+      c.x += b.x; c.y += b.y; c.z += b.z; c.w += b.w;
+      red[threadIdx.x] = c;
+    }
+    __syncthreads();
+  }
+  if (slice == 0 && i < n) st4(out + i, red[threadIdx.x]);
 }
 
 // out[c][r] = in[r][c] for small weight matrices (backward-X uses the forward kernel on W^T).
@@ -289,7 +319,7 @@ inline bool lin_dims_ok(int64_t M, int64_t N, int64_t K) {
 }
 
 inline int pick_splits(int64_t M) {
-  int64_t s = (M + 511) / 512;  // >= 512 rows (16 chunks) per split
+  int64_t s = (M + 223) / 224;  // ~7 chunks of 32 rows per split: ~2 blocks per CU at M = 1e5
   if (s < 1) s = 1;
   if (s > kMaxSplits) s = kMaxSplits;
   return static_cast<int>(s);
@@ -355,10 +385,10 @@ int stemgnn_linear_bwd_weight(const float* dy, const float* x, int64_t M, int64_
                                                db ? pb : nullptr);
   STEMGNN_LAUNCH_CHECK();
   const int64_t nk = N * K;
-  k_reduce_splits<<<static_cast<unsigned>((nk / 4 + kBlock) / kBlock), kBlock, 0, st>>>(pw, S, nk, dw);
+  k_reduce_splits<<<static_cast<unsigned>((nk / 4 + 15) / 16), kBlock, 0, st>>>(pw, S, nk, dw);
   STEMGNN_LAUNCH_CHECK();
   if (db) {
-    k_reduce_splits<<<static_cast<unsigned>((N / 4 + kBlock) / kBlock), kBlock, 0, st>>>(pb, S, N, db);
+    k_reduce_splits<<<static_cast<unsigned>((N / 4 + 15) / 16), kBlock, 0, st>>>(pb, S, N, db);
     STEMGNN_LAUNCH_CHECK();
   }
   return STEMGNN_OK;

@@ -56,36 +56,17 @@ k_vq_assign(const float* __restrict__ xp, int64_t N, int H, int Dc, const float*
   const float* xph = xp + h * Dc;
   const float* emb = embed + static_cast<int64_t>(h) * K * Dc;
 
-  // ---- prologue: row norms of this tile (2 lanes... one half-wave per row, 8 rows per pass)
-  {
-    const int sub = tid & 31, rsel = tid >> 5;  // 8 half-waves
-    for (int r = rsel; r < kRowsPerBlock; r += 8) {
-      const int64_t row = row0 + r;
-      float ss = 0.f;
-      if (row < N) {
-        const float* p = xph + row * HD;
-        for (int c = sub; c < nvec; c += 32) {
-          const float4 v = ld4(p + 4 * c);
-          ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-        }
-      }
-#pragma unroll
-      for (int o = 16; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 32);
-      if (sub == 0) {
-        const float nrm = sqrtf(ss);
-        s_inv[r] = row < N ? 1.0f / fmaxf(nrm, kNormEps) : 0.f;
-        if (row < N) norm_out[row * H + h] = nrm;
-      }
-    }
-  }
-  __syncthreads();
-
   // ---- main loop over code groups x k-chunks, register-prefetched staging
   const int kchunks = (Dc + kKC - 1) / kKC;
   const int groups = (K + 32 * CG - 1) / (32 * CG);
   const int steps = groups * kchunks;
 
+  // The arg-max over codes is invariant to the positive per-row scale 1/||x||, so the MFMA
+  // runs on the raw rows; the squared norms are accumulated on the fly while the first code
+  // group's chunks are staged (each staging thread always serves the same 4 rows) and are only
+  // needed by the epilogue.
   float4 ra[CG], rb[4];
+  float ssq[4] = {0.f, 0.f, 0.f, 0.f};
   auto fetch = [&](int step) {
     const int g = step / kchunks, kc = step % kchunks;
     const int k0 = kc * kKC;
@@ -108,6 +89,7 @@ k_vq_assign(const float* __restrict__ xp, int64_t N, int H, int Dc, const float*
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (row < N && k < Dc) v = ld4(xph + row * HD + k);
       rb[t] = v;
+      if (g == 0) ssq[t] += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
     }
   };
   auto stash = [&]() {
@@ -119,9 +101,7 @@ k_vq_assign(const float* __restrict__ xp, int64_t N, int H, int Dc, const float*
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int idx = t * kBlock + tid;
-      const int r = idx >> 3;
-      const float s = s_inv[r];
-      st4(sB + r * kLd + 4 * (idx & 7), make_float4(rb[t].x * s, rb[t].y * s, rb[t].z * s, rb[t].w * s));
+      st4(sB + (idx >> 3) * kLd + 4 * (idx & 7), rb[t]);
     }
   };
 
@@ -150,13 +130,15 @@ k_vq_assign(const float* __restrict__ xp, int64_t N, int H, int Dc, const float*
       float4 a[CG];
 #pragma unroll
       for (int t = 0; t < CG; ++t) a[t] = ld4(sA + (t * 32 + lj) * kLd + ko);
+      // k outer, code tile inner: consecutive MFMAs hit different accumulators
 #pragma unroll
-      for (int t = 0; t < CG; ++t) {
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].x, b.x, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].y, b.y, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].z, b.z, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].w, b.w, acc[t], 0, 0, 0);
-      }
+      for (int t = 0; t < CG; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].x, b.x, acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < CG; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].y, b.y, acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < CG; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].z, b.z, acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < CG; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].w, b.w, acc[t], 0, 0, 0);
     }
     if (kc == kchunks - 1) {
       // running arg-max: codes ascend with (t, r) inside a lane; strict '>' keeps the lowest index
@@ -172,6 +154,22 @@ k_vq_assign(const float* __restrict__ xp, int64_t N, int H, int Dc, const float*
     }
     __syncthreads();
   }
+  // row norms: the 8 staging threads of a row are 8 consecutive lanes
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    float v = ssq[t];
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    if ((tid & 7) == 0) {
+      const int r = (t * kBlock + tid) >> 3;
+      const int64_t row = row0 + r;
+      const float nrm = sqrtf(v);
+      s_inv[r] = row < N ? 1.0f / fmaxf(nrm, kNormEps) : 0.f;
+      if (row < N) norm_out[row * H + h] = nrm;
+    }
+  }
+  __syncthreads();
   // combine the two lane halves (same data row, disjoint code subsets)
   {
     const float ov = __shfl_xor(best_val, 32, 64);
@@ -184,23 +182,41 @@ k_vq_assign(const float* __restrict__ xp, int64_t N, int H, int Dc, const float*
   }
 
   // ---- epilogue: gather the winning code rows, straight-through value, commitment partial
+  // All loads of a batch are issued before its stores: vmcnt counts loads and stores in one
+  // in-order queue, so a load placed behind a store would wait for that store to retire.
   float sq = 0.f;
-  for (int it = 0; it * 64 < 32 * nvec; ++it) {  // wave-uniform trip count: every lane takes part in the shuffle
-    const int idx = it * 64 + lane;
-    const int r = idx / nvec, c = idx - r * nvec;
-    const int code = __shfl(best_idx, r & 31, 64);
-    const int64_t row = row0 + wave * 32 + r;
-    if (r < 32 && row < N) {
-      const float s = s_inv[wave * 32 + r];
-      const float4 xv = ld4(xph + row * HD + 4 * c);
-      const float4 q = ld4(emb + static_cast<int64_t>(code) * Dc + 4 * c);
-      const float4 n = make_float4(xv.x * s, xv.y * s, xv.z * s, xv.w * s);
-      const float4 d = make_float4(q.x - n.x, q.y - n.y, q.z - n.z, q.w - n.w);
-      sq += d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
-      float4 o = q;
-      if (training) o = make_float4(n.x + d.x, n.y + d.y, n.z + d.z, n.w + d.w);  // x + (q - x), vq.py:937
-      st4(quant + row * HD + h * Dc + 4 * c, o);
-      if (xn_out) st4(xn_out + row * HD + h * Dc + 4 * c, n);
+  constexpr int EB = 8;
+  const int iters = (32 * nvec + 63) / 64;  // wave-uniform trip count: every lane takes part in the shuffles
+  for (int it0 = 0; it0 < iters; it0 += EB) {
+    float4 xv[EB], qv[EB];
+#pragma unroll
+    for (int b = 0; b < EB; ++b) {
+      const int idx = (it0 + b) * 64 + lane;
+      const int r = idx / nvec, c = idx - r * nvec;
+      const int code = __shfl(best_idx, r & 31, 64);
+      const int64_t row = row0 + wave * 32 + r;
+      xv[b] = qv[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (it0 + b < iters && r < 32 && row < N) {
+        xv[b] = ld4(xph + row * HD + 4 * c);
+        qv[b] = ld4(emb + static_cast<int64_t>(code) * Dc + 4 * c);
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < EB; ++b) {
+      const int idx = (it0 + b) * 64 + lane;
+      const int r = idx / nvec, c = idx - r * nvec;
+      const int64_t row = row0 + wave * 32 + r;
+      if (it0 + b < iters && r < 32 && row < N) {
+        const float s = s_inv[wave * 32 + r];
+        const float4 q = qv[b];
+        const float4 n = make_float4(xv[b].x * s, xv[b].y * s, xv[b].z * s, xv[b].w * s);
+        const float4 d = make_float4(q.x - n.x, q.y - n.y, q.z - n.z, q.w - n.w);
+        sq += d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
+        float4 o = q;
+        if (training) o = make_float4(n.x + d.x, n.y + d.y, n.z + d.z, n.w + d.w);  // x + (q - x), vq.py:937
+        st4(quant + row * HD + h * Dc + 4 * c, o);
+        if (xn_out) st4(xn_out + row * HD + h * Dc + 4 * c, n);
+      }
     }
   }
   sq = wave_sum(sq);
