@@ -67,6 +67,31 @@ int stemgnn_csr_build(const int64_t* edge_index, int64_t num_edges, int64_t num_
                       int32_t* rowptr, int32_t* other, int32_t* eid, int32_t* bad_count,
                       void* workspace, size_t workspace_bytes, void* stream);
 
+/*
+ * dropout_adj(..., force_undirected=True) (reference pretrain.py:42-44, PyG 2.3.0) applied to a
+ * graph given by BOTH of its CSR views, producing both CSR views of the augmented graph with
+ * no host synchronisation.  keep(e) = philox(seed, offset)[e] >= p (the mask of
+ * stemgnn_dropout_keep_mask(E, p, seed, offset)) or keep[e] != 0 when `keep` is given; an edge
+ * survives when keep(e) && src(e) <= dst(e) and is emitted in both directions.  Output arrays
+ * hold up to 2E slots (a_rowptr[N] = number of augmented edges); slots carry the ORIGINAL edge
+ * id so the original dense edge_attr / edge types address them directly.
+ */
+size_t stemgnn_graph_dropout_workspace_bytes(int64_t num_nodes);
+int stemgnn_graph_dropout_undirected(const int32_t* rowptr, const int32_t* src, const int32_t* eid,
+                                     const int32_t* etype_slot, const int32_t* rowptr_t, const int32_t* dst_t,
+                                     const int32_t* eid_t, const int32_t* etype_slot_t, int64_t num_nodes,
+                                     int64_t num_edges, float p, uint64_t seed, uint64_t offset, const uint8_t* keep,
+                                     int32_t* a_rowptr, int32_t* a_src, int32_t* a_eid, int32_t* a_etype_slot,
+                                     int32_t* a_dst_t, int32_t* a_eid_t, int32_t* a_etype_slot_t, float* a_inv_deg,
+                                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* negative_sampling(pos_edge_index, N) (reference model/pt_model.py:60; PyG structured sparse
+ * sampling): k pairs (r, c), r != c, uniform over the N(N-1) non-loop pairs, rejecting pairs
+ * that are SELECTED positive edges (selected[e] != 0 over the graph's edges, looked up through
+ * the by-target CSR).  out int64 [2, k]. */
+int stemgnn_negative_sample(const int32_t* rowptr, const int32_t* src, const int32_t* eid, const uint8_t* selected,
+                            int64_t num_nodes, int64_t k, uint64_t seed, uint64_t offset, int64_t* out, void* stream);
+
 /* out[i] = table[index[i]] for int32 tables (edge-type id per CSR slot = xe[eid[slot]]). */
 int stemgnn_gather_i32(const int32_t* table, const int32_t* index, int64_t n, int32_t* out, void* stream);
 
@@ -211,6 +236,16 @@ int stemgnn_edge_dot_fwd(const float* z, int64_t num_nodes, int64_t dim, const i
                          int64_t num_edges, float* out, void* stream);
 int stemgnn_edge_dot_bwd(const float* g_out, const float* z, int64_t num_nodes, int64_t dim,
                          const int64_t* edge_index, int64_t num_edges, float* g_z, void* stream);
+
+/* topo_recon_loss (model/pt_model.py:62-65) from the edge scores of kp positive then kn negative
+ * edges: loss[0] = mean -log(sigmoid(d)+1e-15) over positives + mean -log(1-sigmoid(d)+1e-15)
+ * over negatives; coef[e] = d loss / d dots[e].  The backward is stemgnn_edge_dot_bwd_scaled:
+ * g_z += (g_scalar[0] * coef[e]) * z[other endpoint]  (g_z zero-initialised by the caller). */
+int stemgnn_edge_bce_loss(const float* dots, int64_t num_pos, int64_t num_neg, float* loss, float* coef,
+                          void* stream);
+int stemgnn_edge_dot_bwd_scaled(const float* coef, const float* g_scalar, const float* z, int64_t num_nodes,
+                                int64_t dim, const int64_t* edge_index, int64_t num_edges, float* g_z,
+                                void* stream);
 
 /* K12 feed: out[e] = concat(z[u_e], z[v_e]) ([E, 2D]); backward scatters g_out back
  * (atomics; g_z zero-initialised by the caller).  (model/pt_model.py:80) */

@@ -53,14 +53,14 @@ __device__ inline void atomic_add4(float* p, float4 v) {
 
 template <int G>
 __global__ void __launch_bounds__(kBlock)
-k_edge_dot_bwd(const float* __restrict__ g_out, const float* __restrict__ z, int64_t N, int D,
-               const int64_t* __restrict__ ei, int64_t E, float* __restrict__ g_z) {
+k_edge_dot_bwd(const float* __restrict__ g_out, const float* __restrict__ g_scalar, const float* __restrict__ z,
+               int64_t N, int D, const int64_t* __restrict__ ei, int64_t E, float* __restrict__ g_z) {
   const int lane = threadIdx.x % G;
   const int64_t e = static_cast<int64_t>(blockIdx.x) * (kBlock / G) + threadIdx.x / G;
   if (e >= E) return;
   int64_t u, v;
   if (!load_edge(ei, E, e, N, &u, &v)) return;
-  const float g = g_out[e];
+  const float g = g_out[e] * (g_scalar ? g_scalar[0] : 1.0f);
   const int nvec = D / 4;
   for (int c = lane; c < nvec; c += G) {
     const float4 a = ld4(z + u * D + 4 * c), b = ld4(z + v * D + 4 * c);
@@ -118,6 +118,41 @@ k_gather_rows(const float* __restrict__ table, int64_t R, int D, const int64_t* 
     st4(out + i * D + 4 * c, ok ? ld4(table + r * D + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f));
 }
 
+// topo_recon_loss terms (reference model/pt_model.py:62-65, EPS = 1e-15):
+//   loss = mean_{e < kp} -log(sigmoid(d_e) + EPS) + mean_{e >= kp} -log(1 - sigmoid(d_e) + EPS)
+// and coef[e] = d loss / d d_e (so the backward is one scaled edge-dot scatter).  One block.
+__global__ void __launch_bounds__(1024) k_edge_bce(const float* __restrict__ dots, int64_t kp, int64_t kn,
+                                                   float* __restrict__ loss, float* __restrict__ coef) {
+  __shared__ double red[2][1024];
+  const float eps = 1e-15f;
+  double sp = 0.0, sn = 0.0;
+  for (int64_t e = threadIdx.x; e < kp + kn; e += 1024) {
+    const float d = dots[e];
+    const float sg = 1.0f / (1.0f + expf(-d));
+    if (e < kp) {
+      sp += static_cast<double>(-logf(sg + eps));
+      coef[e] = -(sg * (1.0f - sg)) / (sg + eps) / static_cast<float>(kp);
+    } else {
+      const float q = 1.0f - sg + eps;
+      sn += static_cast<double>(-logf(q));
+      coef[e] = (sg * (1.0f - sg)) / q / static_cast<float>(kn);
+    }
+  }
+  red[0][threadIdx.x] = sp;
+  red[1][threadIdx.x] = sn;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + o];
+      red[1][threadIdx.x] += red[1][threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0)
+    loss[0] = static_cast<float>(red[0][0] / static_cast<double>(kp > 0 ? kp : 1) +
+                                 red[1][0] / static_cast<double>(kn > 0 ? kn : 1));
+}
+
 __global__ void __launch_bounds__(kBlock) k_ema_lerp(float* __restrict__ t, const float* __restrict__ s, int64_t n,
                                                      float decay) {
   const float w = 1.0f - decay;
@@ -166,7 +201,26 @@ int stemgnn_edge_dot_bwd(const float* g_out, const float* z, int64_t N, int64_t 
   if (!fits_i32(E)) return STEMGNN_ERR_TOO_LARGE;
   if (E == 0) return STEMGNN_OK;
   if (!g_out || !z || !edge_index || !g_z) return STEMGNN_ERR_INVALID_ARG;
-  STEMGNN_EDGE_DISPATCH(k_edge_dot_bwd, E, g_out, z, N, static_cast<int>(D), edge_index, E, g_z);
+  STEMGNN_EDGE_DISPATCH(k_edge_dot_bwd, E, g_out, nullptr, z, N, static_cast<int>(D), edge_index, E, g_z);
+  return STEMGNN_OK;
+}
+
+int stemgnn_edge_dot_bwd_scaled(const float* coef, const float* g_scalar, const float* z, int64_t N, int64_t D,
+                                const int64_t* edge_index, int64_t E, float* g_z, void* stream_) {
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  if (N < 0 || E < 0 || !dim_ok(D)) return STEMGNN_ERR_INVALID_ARG;
+  if (!fits_i32(E)) return STEMGNN_ERR_TOO_LARGE;
+  if (E == 0) return STEMGNN_OK;
+  if (!coef || !g_scalar || !z || !edge_index || !g_z) return STEMGNN_ERR_INVALID_ARG;
+  STEMGNN_EDGE_DISPATCH(k_edge_dot_bwd, E, coef, g_scalar, z, N, static_cast<int>(D), edge_index, E, g_z);
+  return STEMGNN_OK;
+}
+
+int stemgnn_edge_bce_loss(const float* dots, int64_t kp, int64_t kn, float* loss, float* coef, void* stream_) {
+  if (kp < 0 || kn < 0 || !loss) return STEMGNN_ERR_INVALID_ARG;
+  if (kp + kn > 0 && (!dots || !coef)) return STEMGNN_ERR_INVALID_ARG;
+  k_edge_bce<<<1, 1024, 0, static_cast<hipStream_t>(stream_)>>>(dots, kp, kn, loss, coef);
+  STEMGNN_LAUNCH_CHECK();
   return STEMGNN_OK;
 }
 

@@ -1,0 +1,200 @@
+// Augmented-graph construction and loss-edge sampling on the device, without host round trips.
+//
+// Reference: torch_geometric.utils.dropout_adj(edge_index, edge_attr, p, force_undirected=True)
+// (STEM-GNN/pretrain.py:42-44) and torch_geometric.utils.negative_sampling (model/pt_model.py:60).
+// PyG's dropout_adj builds a new COO with boolean-mask indexing (a device->host sync for the
+// output size) that the aggregation then has to re-sort.  Here the survivors are selected
+// straight out of the ORIGINAL graph's two CSR views, which already hold every edge grouped by
+// target and by source in edge order:
+//
+//   valid(e) = keep(e) && src(e) <= dst(e)            keep(e) = philox(seed, offset)[e] >= p
+//   augmented in-list of v  = [valid in-edges of v, sources]  ++ [valid out-edges of v, targets]
+//   augmented out-list of u = [valid out-edges of u, targets] ++ [valid in-edges of u, sources]
+//
+// which is exactly PyG's [row;col] ++ [col;row] emission stably grouped by target / by source.
+// Slots carry the ORIGINAL edge id, so the dense edge_attr of the original graph (or its edge
+// types) serves the augmented graph without the cat([ea, ea]) copy.  count -> scan -> fill,
+// all sizes stay on the device (arrays are allocated at the 2E upper bound).
+#include "common.h"
+
+#include <cstring>
+#include <rocprim/device/device_scan.hpp>
+
+namespace stemgnn {
+namespace {
+
+constexpr int kThreads = 256;
+
+__device__ inline bool keep_edge(uint64_t seed, uint64_t offset, float p, int e) {
+  if (p <= 0.f) return true;
+  uint32_t r[4];
+  Philox::gen(seed, offset, static_cast<uint64_t>(e) >> 2, r);
+  return Philox::to_unit(r[e & 3]) >= p;
+}
+
+__global__ void __launch_bounds__(kThreads)
+k_aug_count(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src, const int32_t* __restrict__ eid,
+            const int32_t* __restrict__ rowptr_t, const int32_t* __restrict__ dst_t,
+            const int32_t* __restrict__ eid_t, int64_t N, float p, uint64_t seed, uint64_t offset,
+            const uint8_t* __restrict__ keep_in, int32_t* __restrict__ cnt_a, int32_t* __restrict__ deg) {
+  const int64_t v = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+  if (v >= N) return;
+  int a = 0, b = 0;
+  for (int s = rowptr[v]; s < rowptr[v + 1]; ++s) {
+    const int e = eid[s];
+    const bool k = keep_in ? keep_in[e] != 0 : keep_edge(seed, offset, p, e);
+    a += (k && src[s] <= v) ? 1 : 0;
+  }
+  for (int t = rowptr_t[v]; t < rowptr_t[v + 1]; ++t) {
+    const int e = eid_t[t];
+    const bool k = keep_in ? keep_in[e] != 0 : keep_edge(seed, offset, p, e);
+    b += (k && v <= dst_t[t]) ? 1 : 0;
+  }
+  cnt_a[v] = a;
+  deg[v] = a + b;
+}
+
+__global__ void __launch_bounds__(kThreads)
+k_aug_fill(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src, const int32_t* __restrict__ eid,
+           const int32_t* __restrict__ etype_slot, const int32_t* __restrict__ rowptr_t,
+           const int32_t* __restrict__ dst_t, const int32_t* __restrict__ eid_t,
+           const int32_t* __restrict__ etype_slot_t, int64_t N, float p, uint64_t seed, uint64_t offset,
+           const uint8_t* __restrict__ keep_in, const int32_t* __restrict__ cnt_a, const int32_t* __restrict__ deg,
+           int32_t* __restrict__ arowptr /* exclusive scan of deg, [N+1] */, int32_t* __restrict__ a_src,
+           int32_t* __restrict__ a_eid, int32_t* __restrict__ a_type, int32_t* __restrict__ a_dst_t,
+           int32_t* __restrict__ a_eid_t, int32_t* __restrict__ a_type_t, float* __restrict__ inv_deg) {
+  const int64_t v = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+  if (v >= N) return;
+  const int base = arowptr[v];
+  const int na = cnt_a[v], d = deg[v];
+  if (v == N - 1) arowptr[N] = base + d;
+  inv_deg[v] = 1.0f / static_cast<float>(d < 1 ? 1 : d);
+  int ia = 0, ib = 0;
+  // in-edges of v (u -> v, u <= v): first in the by-target list, second in the by-source list
+  for (int s = rowptr[v]; s < rowptr[v + 1]; ++s) {
+    const int e = eid[s], u = src[s];
+    const bool k = keep_in ? keep_in[e] != 0 : keep_edge(seed, offset, p, e);
+    if (k && u <= v) {
+      const int ty = etype_slot ? etype_slot[s] : 0;
+      const int pd = base + ia, ps = base + (d - na) + ia;
+      a_src[pd] = u; a_eid[pd] = e; if (a_type) a_type[pd] = ty;
+      a_dst_t[ps] = u; a_eid_t[ps] = e; if (a_type_t) a_type_t[ps] = ty;
+      ++ia;
+    }
+  }
+  // out-edges of v (v -> w, v <= w): second in the by-target list, first in the by-source list
+  for (int t = rowptr_t[v]; t < rowptr_t[v + 1]; ++t) {
+    const int e = eid_t[t], w = dst_t[t];
+    const bool k = keep_in ? keep_in[e] != 0 : keep_edge(seed, offset, p, e);
+    if (k && v <= w) {
+      const int ty = etype_slot_t ? etype_slot_t[t] : 0;
+      const int pd = base + na + ib, ps = base + ib;
+      a_src[pd] = w; a_eid[pd] = e; if (a_type) a_type[pd] = ty;
+      a_dst_t[ps] = w; a_eid_t[ps] = e; if (a_type_t) a_type_t[ps] = ty;
+      ++ib;
+    }
+  }
+}
+
+// PyG negative_sampling (structured, sparse, directed): uniform over the N*(N-1) non-self-loop
+// pairs, rejecting pairs that are SELECTED positive edges (selected[e] != 0).  Membership is
+// looked up in the target's in-list of the original graph.  Each thread redraws until accepted
+// (<= 64 tries; the acceptance probability is 1 - k/(N(N-1)) ~ 1).
+__global__ void __launch_bounds__(kThreads)
+k_negative_sample(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src,
+                  const int32_t* __restrict__ eid, const uint8_t* __restrict__ selected, int64_t N, int64_t k,
+                  uint64_t seed, uint64_t offset, int64_t* __restrict__ out /*[2][k]*/) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+  if (i >= k) return;
+  const uint64_t population = static_cast<uint64_t>(N) * static_cast<uint64_t>(N - 1);
+  int64_t r = 0, c = 1 % N;
+  for (int attempt = 0; attempt < 64; ++attempt) {
+    uint32_t u[4];
+    Philox::gen(seed, offset + static_cast<uint64_t>(attempt), static_cast<uint64_t>(i), u);
+    const uint64_t x = (static_cast<uint64_t>(u[0]) << 32 | u[1]) % population;
+    r = static_cast<int64_t>(x / static_cast<uint64_t>(N - 1));
+    c = static_cast<int64_t>(x % static_cast<uint64_t>(N - 1));
+    if (r <= c) ++c;  // vector_to_edge_index: skip the diagonal
+    bool hit = false;
+    for (int s = rowptr[c]; s < rowptr[c + 1] && !hit; ++s) hit = (src[s] == r) && selected[eid[s]] != 0;
+    if (!hit) break;
+  }
+  out[i] = r;
+  out[k + i] = c;
+}
+
+}  // namespace
+}  // namespace stemgnn
+
+using namespace stemgnn;
+
+extern "C" {
+
+size_t stemgnn_graph_dropout_workspace_bytes(int64_t N) {
+  if (N < 0) return 0;
+  size_t temp = 0;
+  int32_t* p = nullptr;
+  hipError_t e = rocprim::exclusive_scan(nullptr, temp, p, p, 0, static_cast<size_t>(N < 1 ? 1 : N),
+                                         rocprim::plus<int32_t>(), hipStream_t(0), false);
+  if (e != hipSuccess || temp == 0) {
+    (void)hipGetLastError();
+    temp = static_cast<size_t>(N) * 8 + (1u << 20);
+  }
+  return 2 * align_up(static_cast<size_t>(N + 1) * sizeof(int32_t), 256) + align_up(temp, 256) + 512;
+}
+
+int stemgnn_graph_dropout_undirected(const int32_t* rowptr, const int32_t* src, const int32_t* eid,
+                                     const int32_t* etype_slot, const int32_t* rowptr_t, const int32_t* dst_t,
+                                     const int32_t* eid_t, const int32_t* etype_slot_t, int64_t N, int64_t E,
+                                     float p, uint64_t seed, uint64_t offset, const uint8_t* keep,
+                                     int32_t* a_rowptr, int32_t* a_src, int32_t* a_eid, int32_t* a_etype_slot,
+                                     int32_t* a_dst_t, int32_t* a_eid_t, int32_t* a_etype_slot_t, float* a_inv_deg,
+                                     void* workspace, size_t workspace_bytes, void* stream_) {
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  if (N < 0 || E < 0 || p < 0.f || p > 1.f || !a_rowptr) return STEMGNN_ERR_INVALID_ARG;
+  if (!fits_i32(N) || !fits_i32(2 * E)) return STEMGNN_ERR_TOO_LARGE;
+  if (N == 0) {
+    STEMGNN_HIP_TRY(hipMemsetAsync(a_rowptr, 0, sizeof(int32_t), st));
+    return STEMGNN_OK;
+  }
+  if (!rowptr || !rowptr_t || !a_inv_deg || !workspace) return STEMGNN_ERR_INVALID_ARG;
+  if (E > 0 && (!src || !eid || !dst_t || !eid_t || !a_src || !a_eid || !a_dst_t || !a_eid_t))
+    return STEMGNN_ERR_INVALID_ARG;
+  if ((etype_slot == nullptr) != (etype_slot_t == nullptr)) return STEMGNN_ERR_INVALID_ARG;
+  if (workspace_bytes < stemgnn_graph_dropout_workspace_bytes(N)) return STEMGNN_ERR_WORKSPACE;
+  uintptr_t base = align_up(reinterpret_cast<uintptr_t>(workspace), 256);
+  const size_t arr = align_up(static_cast<size_t>(N + 1) * sizeof(int32_t), 256);
+  int32_t* cnt_a = reinterpret_cast<int32_t*>(base);
+  int32_t* deg = reinterpret_cast<int32_t*>(base + arr);
+  void* temp = reinterpret_cast<void*>(base + 2 * arr);
+  size_t temp_bytes = workspace_bytes - (base - reinterpret_cast<uintptr_t>(workspace)) - 2 * arr;
+  const unsigned grid = static_cast<unsigned>((N + kThreads - 1) / kThreads);
+  k_aug_count<<<grid, kThreads, 0, st>>>(rowptr, src, eid, rowptr_t, dst_t, eid_t, N, p, seed, offset, keep, cnt_a, deg);
+  STEMGNN_LAUNCH_CHECK();
+  size_t need = 0;
+  STEMGNN_HIP_TRY(rocprim::exclusive_scan(nullptr, need, deg, a_rowptr, 0, static_cast<size_t>(N),
+                                          rocprim::plus<int32_t>(), st, false));
+  if (need > temp_bytes) return STEMGNN_ERR_WORKSPACE;
+  STEMGNN_HIP_TRY(rocprim::exclusive_scan(temp, need, deg, a_rowptr, 0, static_cast<size_t>(N),
+                                          rocprim::plus<int32_t>(), st, false));
+  k_aug_fill<<<grid, kThreads, 0, st>>>(rowptr, src, eid, etype_slot, rowptr_t, dst_t, eid_t, etype_slot_t, N, p, seed,
+                                        offset, keep, cnt_a, deg, a_rowptr, a_src, a_eid,
+                                        etype_slot ? a_etype_slot : nullptr, a_dst_t, a_eid_t,
+                                        etype_slot ? a_etype_slot_t : nullptr, a_inv_deg);
+  STEMGNN_LAUNCH_CHECK();
+  return STEMGNN_OK;
+}
+
+int stemgnn_negative_sample(const int32_t* rowptr, const int32_t* src, const int32_t* eid, const uint8_t* selected,
+                            int64_t N, int64_t k, uint64_t seed, uint64_t offset, int64_t* out, void* stream_) {
+  if (N < 0 || k < 0) return STEMGNN_ERR_INVALID_ARG;
+  if (k == 0) return STEMGNN_OK;
+  if (N < 2 || !rowptr || !src || !eid || !selected || !out) return STEMGNN_ERR_INVALID_ARG;
+  if (!fits_i32(N)) return STEMGNN_ERR_TOO_LARGE;
+  k_negative_sample<<<static_cast<unsigned>((k + kThreads - 1) / kThreads), kThreads, 0,
+                      static_cast<hipStream_t>(stream_)>>>(rowptr, src, eid, selected, N, k, seed, offset, out);
+  STEMGNN_LAUNCH_CHECK();
+  return STEMGNN_OK;
+}
+
+}  // extern "C"

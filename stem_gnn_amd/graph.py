@@ -1,11 +1,11 @@
-"""Graph-structure object: the int32 CSR views of one int64 COO ``edge_index`` that the
-HIP aggregation kernels consume, built once per (sub)graph on the device.
+"""Graph-structure object: the int32 CSR views of one (sub)graph that the HIP aggregation
+kernels consume, built once per graph on the device.
 
-The reference has no such object: PyG's MessagePassing.propagate re-indexes the raw
+The reference has no such object: PyG's MessagePassing.propagate re-indexes the raw int64
 ``edge_index`` on every layer call (reference model/encoder.py:82).  ``GraphStructure`` may be
 passed anywhere the modules accept ``edge_index``; a raw tensor is converted through a small
 identity-keyed cache so a caller that only knows the reference API pays the build once per
-distinct ``edge_index`` tensor.
+distinct ``edge_index`` tensor.  A loader can hand batches over as GraphStructure directly.
 """
 from __future__ import annotations
 
@@ -33,17 +33,11 @@ class EdgeTypeAttr:
     [E, D] tensor ``edge_text_feat[xe]`` the reference materialises on the host
     (reference pretrain.py:38).  ``dense()`` yields exactly that tensor."""
 
-    def __init__(self, table: Tensor, etype: Tensor):
-        if etype.dtype not in (torch.int32, torch.int64):
+    def __init__(self, table: Tensor, etype: Optional[Tensor]):
+        if etype is not None and etype.dtype not in (torch.int32, torch.int64):
             raise RuntimeError("EdgeTypeAttr: etype must be an integer tensor")
         self.table = table.contiguous()
-        self.etype = etype.contiguous()
-        self._etype_i32 = None
-
-    def etype_i32(self) -> Tensor:
-        if self._etype_i32 is None:
-            self._etype_i32 = self.etype.to(torch.int32)
-        return self._etype_i32
+        self.etype = None if etype is None else etype.contiguous()
 
     def size(self, dim: int) -> int:
         return (self.etype.numel(), self.table.size(1))[dim]
@@ -55,29 +49,52 @@ class EdgeTypeAttr:
         return self.table.index_select(0, self.etype.long())
 
     def to(self, device) -> "EdgeTypeAttr":
-        return EdgeTypeAttr(self.table.to(device), self.etype.to(device))
+        return EdgeTypeAttr(self.table.to(device), None if self.etype is None else self.etype.to(device))
 
 
 class GraphStructure:
-    """CSR grouped by target (forward) and, lazily, by source (backward)."""
+    """CSR grouped by target (forward aggregation) and, lazily, by source (its backward).
 
-    def __init__(self, edge_index: Tensor, num_nodes: int, edge_type: Optional[Tensor] = None,
+    ``num_edges`` is the number of rows a dense ``edge_attr`` for this graph has (slots address
+    it through ``eid``); for an augmented graph made by ``dropout_undirected`` that is the
+    ORIGINAL graph's edge count and the live edge count stays on the device (rowptr[-1])."""
+
+    def __init__(self, edge_index: Optional[Tensor], num_nodes: int, edge_type: Optional[Tensor] = None,
                  validate: Optional[bool] = None):
-        if edge_index.dim() != 2 or edge_index.size(0) != 2:
-            raise RuntimeError(f"edge_index: expected shape [2, E], got {tuple(edge_index.shape)}")
-        self.edge_index = edge_index.contiguous()
         self.num_nodes = int(num_nodes)
-        self.num_edges = int(edge_index.size(1))
-        self.rowptr, self.src, self.eid, self._bad = ops.csr_build(self.edge_index, self.num_nodes, 1)
         self.rowptr_t = self.dst_t = self.eid_t = self.inv_deg = None
         self.etype_slot = self.etype_slot_t = None
         self._edge_type = None
+        self._edge_index = None
+        if edge_index is None:  # filled in by a factory (dropout_undirected)
+            self.num_edges = 0
+            self.rowptr = self.src = self.eid = self._bad = None
+            return
+        if edge_index.dim() != 2 or edge_index.size(0) != 2:
+            raise RuntimeError(f"edge_index: expected shape [2, E], got {tuple(edge_index.shape)}")
+        self._edge_index = edge_index.contiguous()
+        self.num_edges = int(edge_index.size(1))
+        self.rowptr, self.src, self.eid, self._bad = ops.csr_build(self._edge_index, self.num_nodes, 1)
         if edge_type is not None:
             self.set_edge_type(edge_type)
         if _VALIDATE if validate is None else validate:
             bad = int(self._bad.item())
             if bad:
                 raise IndexError(f"edge_index has {bad} entries outside [0, {self.num_nodes})")
+
+    @property
+    def edge_index(self) -> Tensor:
+        """int64 COO [2, E] (row 0 = source, row 1 = target).  For an augmented graph it is
+        rebuilt from the CSR on demand (one device->host sync for the size)."""
+        if self._edge_index is None:
+            n_live = int(self.rowptr[-1].item())
+            deg = (self.rowptr[1:] - self.rowptr[:-1]).long()
+            dst = torch.repeat_interleave(torch.arange(self.num_nodes, device=deg.device), deg)
+            self._edge_index = torch.stack([self.src[:n_live].long(), dst], dim=0)
+        return self._edge_index
+
+    def has_edge_type(self) -> bool:
+        return self.etype_slot is not None
 
     def set_edge_type(self, edge_type: Tensor) -> None:
         if edge_type.numel() != self.num_edges:
@@ -88,15 +105,32 @@ class GraphStructure:
         if self.eid_t is not None:
             self.etype_slot_t = ops.gather_i32(self._edge_type, self.eid_t) if self.num_edges else self._edge_type
 
-    def ensure_transpose(self) -> None:
+    def ensure_transpose(self) -> "GraphStructure":
         if self.rowptr_t is None:
-            self.rowptr_t, self.dst_t, self.eid_t, _ = ops.csr_build(self.edge_index, self.num_nodes, 0)
+            self.rowptr_t, self.dst_t, self.eid_t, _ = ops.csr_build(self._edge_index, self.num_nodes, 0)
             self.inv_deg = ops.inv_degree(self.rowptr)
         if self._edge_type is not None and self.etype_slot_t is None:
             self.etype_slot_t = (ops.gather_i32(self._edge_type, self.eid_t) if self.num_edges else self._edge_type)
+        return self
 
     def in_degree(self) -> Tensor:
         return (self.rowptr[1:] - self.rowptr[:-1]).long()
+
+    def dropout_undirected(self, p: float, keep: Optional[Tensor] = None) -> "GraphStructure":
+        """dropout_adj(edge_index, edge_attr, p, force_undirected=True) (reference pretrain.py:42-44)
+        as a GraphStructure -> GraphStructure map on the device: no COO, no re-sort, no host
+        sync.  The result's slots address THIS graph's edge_attr rows / edge types.  The Bernoulli
+        draw is ``ops.dropout_keep_mask(E, p, *result.keep_key)`` unless ``keep`` is given."""
+        self.ensure_transpose()
+        out = GraphStructure(None, self.num_nodes)
+        out.num_edges = self.num_edges
+        seed, offset = (0, 0) if keep is not None else ops.next_dropout_key()
+        out.keep_key = (seed, offset)
+        (out.rowptr, out.src, out.eid, out.etype_slot, out.dst_t, out.eid_t, out.etype_slot_t,
+         out.inv_deg) = ops.graph_dropout_undirected(self, p, seed, offset, keep)
+        out.rowptr_t = out.rowptr  # the augmented graph is symmetric: identical degree sequence
+        out._edge_type = self._edge_type
+        return out
 
 
 _CACHE: "OrderedDict[tuple, GraphStructure]" = OrderedDict()
@@ -108,7 +142,7 @@ def as_graph(edge_index, num_nodes: int, edge_type: Optional[Tensor] = None) -> 
     if isinstance(edge_index, GraphStructure):
         if edge_index.num_nodes != num_nodes:
             raise RuntimeError("GraphStructure was built for a different number of nodes")
-        if edge_type is not None and edge_index._edge_type is None:
+        if edge_type is not None and not edge_index.has_edge_type():
             edge_index.set_edge_type(edge_type)
         return edge_index
     key = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version, int(num_nodes),

@@ -17,8 +17,8 @@ import torch.nn.functional as F
 from torch import Tensor
 
 from .. import ops
-from ..graph import EdgeTypeAttr, GraphStructure
-from ..utils.graph_utils import negative_sampling
+from ..graph import EdgeTypeAttr, GraphStructure, as_graph
+from .encoder import InnerProductDecoder
 
 EPS = 1e-15  # pt_model.py:8
 
@@ -90,26 +90,47 @@ class PretrainModel(nn.Module):
         if draws is not None and key in draws:
             perm = draws[key]
         else:
+            # a uniformly random k-subset (what randperm(E)[:k] is), drawn as the k largest of E
+            # uniform keys: a radix select instead of a full sort of E keys
             k = max(int(num_edges * ratio), 1)
-            perm = torch.randperm(num_edges, device=device)[:k]
+            perm = torch.topk(torch.rand(num_edges, device=device), k, sorted=False).indices
         self.last_draws[key] = perm
         return perm
 
     def topo_recon_loss(self, z, pos_edge_index, neg_edge_index=None, ratio=1.0, draws=None):
         if ratio == 0.0:
             return torch.tensor(0.0, device=z.device)
-        pos_edge_index = _edge_index_of(pos_edge_index)
-        perm = self._sample_edges(pos_edge_index.size(1), ratio, z.device, "topo_perm", draws)
+        graph = pos_edge_index if isinstance(pos_edge_index, GraphStructure) else None
+        full_edge_index = _edge_index_of(pos_edge_index)
+        pos_edge_index = full_edge_index
+        num_edges = pos_edge_index.size(1)
+        perm = self._sample_edges(num_edges, ratio, z.device, "topo_perm", draws)
         if perm is not None:
             pos_edge_index = pos_edge_index[:, perm]
         if neg_edge_index is None:
             if draws is not None and "neg_edge_index" in draws:
                 neg_edge_index = draws["neg_edge_index"]
             else:
-                neg_edge_index = negative_sampling(pos_edge_index, z.size(0))  # pt_model.py:60
+                # negative_sampling(pos_edge_index, N) (pt_model.py:60): negatives must avoid the
+                # SAMPLED positives; membership is looked up through the graph's by-target CSR
+                if graph is None:
+                    graph = as_graph(full_edge_index, z.size(0))
+                selected = torch.zeros(num_edges, dtype=torch.uint8, device=z.device)
+                if perm is None:
+                    selected.fill_(1)
+                else:
+                    selected[perm] = 1
+                seed, offset = ops.next_dropout_key()
+                neg_edge_index = ops.negative_sample(graph, selected, pos_edge_index.size(1), seed, offset)
         self.last_draws["neg_edge_index"] = neg_edge_index
-        pos_loss = -torch.log(self.topo_recon_decoder(z, pos_edge_index, sigmoid=True) + EPS).mean()
-        neg_loss = -torch.log(1 - self.topo_recon_decoder(z, neg_edge_index, sigmoid=True) + EPS).mean()
+        dec = self.topo_recon_decoder
+        if isinstance(dec, InnerProductDecoder):
+            # -log(sigmoid(<.,.>)+EPS) means over positives and negatives, fused (pt_model.py:62-65)
+            zl = ops.linear(z, dec.lin) if dec.proj_z else z
+            both = torch.cat([pos_edge_index, neg_edge_index], dim=1)
+            return ops.EdgeBceLossFn.apply(zl, both, pos_edge_index.size(1))
+        pos_loss = -torch.log(dec(z, pos_edge_index, sigmoid=True) + EPS).mean()
+        neg_loss = -torch.log(1 - dec(z, neg_edge_index, sigmoid=True) + EPS).mean()
         return pos_loss + neg_loss
 
     def topo_sem_recon_loss(self, z, edge_index, edge_attr, ratio=1.0, draws=None):

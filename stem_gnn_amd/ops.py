@@ -104,6 +104,41 @@ def gather_i32(table: Tensor, index: Tensor) -> Tensor:
     return out
 
 
+def graph_dropout_undirected(g, p: float, seed: int, offset: int, keep: Optional[Tensor]):
+    """Both CSR views of dropout_adj(force_undirected=True) applied to graph `g` (which has both views)."""
+    N, E, dev = g.num_nodes, g.num_edges, g.rowptr.device
+    cap = max(2 * E, 1)
+    i32 = dict(dtype=torch.int32, device=dev)
+    a_rowptr = torch.empty(N + 1, **i32)
+    a_src, a_eid, a_dst_t, a_eid_t = (torch.empty(cap, **i32) for _ in range(4))
+    typed = g.etype_slot is not None
+    if typed and g.etype_slot_t is None:
+        raise RuntimeError("graph_dropout_undirected: call ensure_transpose() after set_edge_type()")
+    a_type = torch.empty(cap, **i32) if typed else None
+    a_type_t = torch.empty(cap, **i32) if typed else None
+    inv_deg = torch.empty(N, dtype=torch.float32, device=dev)
+    keep_u8 = None
+    if keep is not None:
+        if keep.numel() != E:
+            raise RuntimeError("keep: one flag per edge expected")
+        keep_u8 = keep.to(torch.uint8).contiguous()
+    ws = _workspace(lib.stemgnn_graph_dropout_workspace_bytes(N), dev)
+    check(lib.stemgnn_graph_dropout_undirected(
+        _p(g.rowptr), _p(g.src), _p(g.eid), _p(g.etype_slot), _p(g.rowptr_t), _p(g.dst_t), _p(g.eid_t),
+        _p(g.etype_slot_t), N, E, float(p), seed, offset, _p(keep_u8), _p(a_rowptr), _p(a_src), _p(a_eid), _p(a_type),
+        _p(a_dst_t), _p(a_eid_t), _p(a_type_t), _p(inv_deg), _p(ws), ws.numel(), _stream()), "graph_dropout_undirected")
+    return a_rowptr, a_src, a_eid, a_type, a_dst_t, a_eid_t, a_type_t, inv_deg
+
+
+def negative_sample(g, selected: Tensor, k: int, seed: int, offset: int) -> Tensor:
+    """k negative pairs for the positives flagged in `selected` (uint8 per edge of graph g)."""
+    _req(selected, torch.uint8, "selected", 1)
+    out = torch.empty(2, k, dtype=torch.int64, device=selected.device)
+    check(lib.stemgnn_negative_sample(_p(g.rowptr), _p(g.src), _p(g.eid), _p(selected), g.num_nodes, k, seed, offset,
+                                      _p(out), _stream()), "negative_sample")
+    return out
+
+
 def inv_degree(rowptr: Tensor) -> Tensor:
     _req(rowptr, torch.int32, "rowptr", 1)
     n = rowptr.numel() - 1
@@ -472,6 +507,36 @@ class EdgeDotFn(torch.autograd.Function):
         check(lib.stemgnn_edge_dot_bwd(_p(g_out.contiguous()), _p(z), z.size(0), z.size(1), _p(ei), ei.size(1),
                                        _p(g_z), _stream()), "edge_dot_bwd")
         return g_z, None
+
+
+class EdgeBceLossFn(torch.autograd.Function):
+    """topo_recon_loss (reference model/pt_model.py:62-65): mean -log(sigmoid(<z_u,z_v>)+EPS) over the
+    first `num_pos` edges + mean -log(1-sigmoid(.)+EPS) over the rest, as three small kernels
+    forward (edge scores, loss + d loss/d score, -) and one scaled scatter backward."""
+
+    @staticmethod
+    def forward(ctx, z, edge_index, num_pos):
+        z = z.contiguous()
+        _req(z, torch.float32, "z", 2)
+        ei = _req(edge_index.contiguous(), torch.int64, "edge_index", 2)
+        E = ei.size(1)
+        dots = torch.empty(E, dtype=torch.float32, device=z.device)
+        check(lib.stemgnn_edge_dot_fwd(_p(z), z.size(0), z.size(1), _p(ei), E, _p(dots), _stream()), "edge_dot_fwd")
+        loss = torch.empty(1, dtype=torch.float32, device=z.device)
+        coef = torch.empty_like(dots)
+        check(lib.stemgnn_edge_bce_loss(_p(dots), int(num_pos), E - int(num_pos), _p(loss), _p(coef), _stream()),
+              "edge_bce_loss")
+        ctx.save_for_backward(z, ei, coef)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        z, ei, coef = ctx.saved_tensors
+        g_z = torch.zeros_like(z)
+        g = g_loss.reshape(1).contiguous().float()
+        check(lib.stemgnn_edge_dot_bwd_scaled(_p(coef), _p(g), _p(z), z.size(0), z.size(1), _p(ei), ei.size(1), _p(g_z),
+                                              _stream()), "edge_dot_bwd_scaled")
+        return g_z, None, None
 
 
 class EdgeConcatFn(torch.autograd.Function):

@@ -17,7 +17,7 @@ import torch.nn as nn
 from torch.optim import AdamW
 
 from . import ops
-from .graph import EdgeTypeAttr
+from .graph import EdgeTypeAttr, as_graph
 from .model.encoder import Encoder, InnerProductDecoder
 from .model.pt_model import PretrainModel
 from .model.vq import VectorQuantize
@@ -85,11 +85,17 @@ def pretrain_step(model: PretrainModel, optimizer, scheduler, params: Dict, x, e
     ``forward_fn`` replaces ``model.__call__`` (e.g. the DistributedDataParallel wrapper, whose
     hooks overlap the RCCL gradient all-reduce with backward)."""
     draws_in = draws or {}
-    graph = [x, edge_index, edge_attr]
+    etype = edge_attr.etype if isinstance(edge_attr, EdgeTypeAttr) else None
+    g = as_graph(edge_index, x.size(0), etype)  # a loader may hand the batch over as GraphStructure already
+    if etype is not None:
+        g.ensure_transpose()
+    graph = [x, g, edge_attr]
     aug_x, fmask = mask_feature(x, p=params["feat_p"], keep=draws_in.get("feat_keep"))  # pretrain.py:41
-    aug_edge_index, aug_edge_attr = dropout_adj(edge_index, edge_attr, p=params["edge_p"], force_undirected=True,
-                                                num_nodes=x.size(0), keep=draws_in.get("edge_keep"))  # :42-44
-    aug_graph = [aug_x, aug_edge_index, aug_edge_attr]
+    # dropout_adj(..., force_undirected=True) (pretrain.py:42-44) straight from the CSR views: no COO
+    # round trip, no re-sort, no host sync; the augmented slots address the ORIGINAL edge attributes
+    g_aug = g.dropout_undirected(params["edge_p"], keep=draws_in.get("edge_keep"))
+    aug_attr = EdgeTypeAttr(edge_attr.table, None) if isinstance(edge_attr, EdgeTypeAttr) else edge_attr
+    aug_graph = [aug_x, g_aug, aug_attr]
 
     z, quantize, indices, losses = (forward_fn or model)(aug_graph, graph, params["topo_recon_ratio"], bs=bs,
                                                          no_codebook=no_codebook, draws=draws_in)
@@ -110,10 +116,8 @@ def pretrain_step(model: PretrainModel, optimizer, scheduler, params: Dict, x, e
         n, d = x.shape
         out_draws = dict(model.last_draws)
         out_draws["feat_keep"] = fmask.view(-1) if params["feat_p"] > 0 else torch.ones(d, dtype=torch.bool, device=x.device)
-        if params["edge_p"] > 0:
-            out_draws["edge_keep"] = dropout_adj.last_keep
-        else:
-            out_draws["edge_keep"] = torch.ones(edge_index.size(1), dtype=torch.bool, device=x.device)
+        out_draws["edge_keep"] = (draws_in["edge_keep"] if "edge_keep" in draws_in else
+                                  ops.dropout_keep_mask(g.num_edges, params["edge_p"], *g_aug.keep_key, x.device))
         p = params["dropout"]
         out_draws["student_dropout"] = [ops.dropout_keep_mask(n * d, p, s, o, x.device).view(n, d)
                                         for (s, o) in model.encoder.last_dropout_keys]

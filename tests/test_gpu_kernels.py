@@ -238,3 +238,72 @@ def test_linear_fwd_bwd_and_stats(dev, m, k1, k2, n, bias):
     ps = partial.sum(dim=0).cpu()
     torch.testing.assert_close(ps[0], yr.detach().sum(dim=0), rtol=1e-4, atol=1e-3)
     torch.testing.assert_close(ps[1], (yr.detach() ** 2).sum(dim=0), rtol=1e-4, atol=1e-3)
+
+
+# ---------------------------------------------------------------------------- augmentation / sampling
+@pytest.mark.parametrize("n,e,p", [(1, 0, 0.2), (9, 30, 0.0), (50, 400, 0.2), (3000, 40000, 0.5), (100, 3000, 1.0)])
+@pytest.mark.parametrize("typed", [False, True])
+def test_dropout_undirected_matches_pyg_semantics(dev, n, e, p, typed):
+    """The fused CSR->CSR augmentation equals dropout_adj(force_undirected=True) restated in
+    the oracle (same Bernoulli draw): identical multiset of (src, dst, original edge id) per
+    target row IN ORDER, for both CSR views; bit-exact (index work)."""
+    from stem_gnn_amd import ops
+    from stem_gnn_amd.graph import GraphStructure
+    ei = rand_graph(n, e, seed=e + 3)
+    et = torch.randint(0, 5, (e,))
+    g = GraphStructure(ei.to(dev), n, et.to(dev) if typed else None).ensure_transpose()
+    ga = g.dropout_undirected(p)
+    keep = ops.dropout_keep_mask(e, p, *ga.keep_key, dev).cpu() if e else torch.zeros(0, dtype=torch.bool)
+    aug_ei, _, m = O.dropout_adj_undirected(ei, None, keep)
+    sel = m.nonzero().view(-1)
+    orig_id = torch.cat([sel, sel])
+    live = int(ga.rowptr[-1].item())
+    assert live == aug_ei.size(1)
+    for key_row, (rowptr, other, eid, ety) in ((1, (ga.rowptr, ga.src, ga.eid, ga.etype_slot)),
+                                                (0, (ga.rowptr_t, ga.dst_t, ga.eid_t, ga.etype_slot_t))):
+        order = np.argsort(aug_ei[key_row].numpy(), kind="stable")
+        exp_rowptr = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(np.bincount(aug_ei[key_row].numpy(), minlength=n), out=exp_rowptr[1:])
+        assert np.array_equal(rowptr.cpu().numpy(), exp_rowptr)
+        assert np.array_equal(other[:live].cpu().numpy(), aug_ei[1 - key_row].numpy()[order])
+        assert np.array_equal(eid[:live].cpu().numpy(), orig_id.numpy()[order])
+        if typed:
+            assert np.array_equal(ety[:live].cpu().numpy(), et[orig_id].numpy()[order])
+    deg = np.diff(ga.rowptr.cpu().numpy())
+    torch.testing.assert_close(ga.inv_deg.cpu(), torch.from_numpy(1.0 / np.maximum(deg, 1)).float())
+    # injected keep mask gives the same graph
+    gb = g.dropout_undirected(p, keep=keep.to(dev))
+    assert torch.equal(gb.rowptr, ga.rowptr) and torch.equal(gb.src[:live], ga.src[:live])
+
+
+def test_negative_sample_properties(dev):
+    from stem_gnn_amd import ops
+    from stem_gnn_amd.graph import GraphStructure
+    n, e, k = 40, 600, 300   # dense enough that rejections actually happen
+    ei = rand_graph(n, e, seed=9)
+    g = GraphStructure(ei.to(dev), n)
+    perm = torch.randperm(e)[:k]
+    sel = torch.zeros(e, dtype=torch.uint8)
+    sel[perm] = 1
+    neg = ops.negative_sample(g, sel.to(dev), k, 5, 7).cpu()
+    assert tuple(neg.shape) == (2, k) and neg.dtype == torch.int64
+    assert O.check_negative_edges(neg, ei[:, perm], n)
+    neg2 = ops.negative_sample(g, sel.to(dev), k, 5, 7).cpu()
+    assert torch.equal(neg, neg2)  # pure function of (seed, offset)
+
+
+def test_edge_bce_loss(dev):
+    from stem_gnn_amd import ops
+    n, d, kp, kn = 200, 64, 301, 257
+    torch.manual_seed(4)
+    z = torch.randn(n, d) * 0.3
+    ei = torch.randint(0, n, (2, kp + kn))
+    zr = z.clone().requires_grad_(True)
+    val = (zr[ei[0]] * zr[ei[1]]).sum(1)
+    ref = -torch.log(torch.sigmoid(val[:kp]) + O.EPS).mean() - torch.log(1 - torch.sigmoid(val[kp:]) + O.EPS).mean()
+    (ref * 1.7).backward()
+    zg = z.to(dev).requires_grad_(True)
+    out = ops.EdgeBceLossFn.apply(zg, ei.to(dev), kp)
+    (out * 1.7).backward()
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(zg.grad.cpu(), zr.grad, rtol=1e-4, atol=1e-6)
