@@ -173,7 +173,7 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    recs = ops.k1_timer.records
+    k1_ms, k1_launches, k1_bytes = ops.k1_timer.collect()
     ops.k1_timer.reset(False)
 
     edges = float(sum(batches[i][1].num_edges for i in range(args.warmup, total)))
@@ -186,8 +186,6 @@ def main():
         dt, edges = float(tmax), float(esum)
 
     if rank == 0:
-        k1_bytes = sum(r[0] for r in recs)
-        k1_ms = sum(r[1].elapsed_time(r[2]) for r in recs)
         achieved = k1_bytes / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
         peak = 8000.0  # MI355X HBM3E spec, GB/s (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
         nb = batches[args.warmup]
@@ -203,9 +201,9 @@ def main():
                        "parallelism": f"dp{world}", "edge_attr": "type-indexed (4E + T*D*4 bytes)"},
             "roofline": {"bound": "hbm", "kernel": "k_sage_agg_fwd (K1, type-indexed edge attr)",
                          "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
-                         "traffic": None, "launches": len(recs),
-                         "avg_launch_us": (k1_ms * 1e3 / len(recs)) if recs else None,
-                         "algorithmic_bytes_per_launch": (k1_bytes / len(recs)) if recs else None},
+                         "traffic": None, "launches": k1_launches,
+                         "avg_launch_us": (k1_ms * 1e3 / k1_launches) if k1_launches else None,
+                         "algorithmic_bytes_per_launch": (k1_bytes / k1_launches) if k1_launches else None},
         }
         if world == 1 and not args.no_cpu_baseline:
             x, ei, xe, bs = batches[args.warmup]

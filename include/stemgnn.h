@@ -114,6 +114,12 @@ int stemgnn_sage_agg_fwd(const float* x, int64_t num_nodes, int64_t dim,
                          const float* edge_attr, const float* etab, const int32_t* etype_slot, int64_t num_types,
                          float* agg, void* stream);
 
+/* Measurement aid (bench.py roofline leg): while enabled, every stemgnn_sage_agg_fwd launch is
+ * stamped with its own begin/end HIP events (hipExtLaunchKernelGGL); collect() waits for them
+ * and returns the summed kernel time in ms and the launch count through HOST pointers. */
+int stemgnn_profile_k1(int enable);
+int stemgnn_profile_k1_collect(double* total_ms_host, int64_t* launches_host);
+
 /*
  * K2: backward of K1 w.r.t. x (PyG autograd: index_select backward = index_add,
  * scatter-mean backward = gather / count).  Deterministic, no atomics:

@@ -14,11 +14,26 @@
 //   A = E*D*4 + 4E (dense edge_attr rows + edge ids)  |  4E + T*D*4 (edge-type ids + table)
 #include "common.h"
 
+#include <hip/hip_ext.h>
+#include <mutex>
+#include <utility>
+#include <vector>
+
 namespace stemgnn {
 namespace {
 
 constexpr int kBlock = 256;
 constexpr int kMaxLdsTableBytes = 48 * 1024;
+
+// Optional in-situ timing of the K1 forward launches (bench.py's roofline leg): the launch
+// goes through hipExtLaunchKernelGGL with a start/stop event pair, which stamps the kernel's
+// own begin/end (not marker packets around it), so the figure matches rocprofv3's.
+struct K1Profile {
+  std::mutex mu;
+  bool enabled = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+};
+K1Profile g_k1_profile;
 
 enum EdgeMode { kNoEdge = 0, kDenseEdge = 1, kTableLds = 2, kTableGlobal = 3 };
 
@@ -217,18 +232,39 @@ inline bool pick_geometry(int64_t D, Geometry* g) {
   return true;
 }
 
+template <int G, int V, int MODE>
+int launch_fwd_one(size_t lds, dim3 grid, hipStream_t st, const float* x, int64_t N, int D, const int32_t* rowptr,
+                   const int32_t* src, const int32_t* aux, const float* ea, const float* etab, int64_t T,
+                   float* agg) {
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_k1_profile.mu);
+    if (g_k1_profile.enabled) {
+      STEMGNN_HIP_TRY(hipEventCreate(&ev0));
+      STEMGNN_HIP_TRY(hipEventCreate(&ev1));
+      g_k1_profile.events.emplace_back(ev0, ev1);
+    }
+  }
+  if (ev0) {
+    hipExtLaunchKernelGGL((k_sage_agg_fwd<G, V, MODE>), grid, dim3(kBlock), lds, st, ev0, ev1, 0, x, N, D, rowptr, src,
+                          aux, ea, etab, T, agg);
+  } else {
+    k_sage_agg_fwd<G, V, MODE><<<grid, kBlock, lds, st>>>(x, N, D, rowptr, src, aux, ea, etab, T, agg);
+  }
+  STEMGNN_LAUNCH_CHECK();
+  return STEMGNN_OK;
+}
+
 template <int G, int V>
 int launch_fwd_mode(int mode, size_t lds, dim3 grid, hipStream_t st, const float* x, int64_t N, int D,
                     const int32_t* rowptr, const int32_t* src, const int32_t* aux, const float* ea,
                     const float* etab, int64_t T, float* agg) {
   switch (mode) {
-    case kNoEdge: k_sage_agg_fwd<G, V, kNoEdge><<<grid, kBlock, 0, st>>>(x, N, D, rowptr, src, aux, ea, etab, T, agg); break;
-    case kDenseEdge: k_sage_agg_fwd<G, V, kDenseEdge><<<grid, kBlock, 0, st>>>(x, N, D, rowptr, src, aux, ea, etab, T, agg); break;
-    case kTableLds: k_sage_agg_fwd<G, V, kTableLds><<<grid, kBlock, lds, st>>>(x, N, D, rowptr, src, aux, ea, etab, T, agg); break;
-    default: k_sage_agg_fwd<G, V, kTableGlobal><<<grid, kBlock, 0, st>>>(x, N, D, rowptr, src, aux, ea, etab, T, agg); break;
+    case kNoEdge: return launch_fwd_one<G, V, kNoEdge>(0, grid, st, x, N, D, rowptr, src, aux, ea, etab, T, agg);
+    case kDenseEdge: return launch_fwd_one<G, V, kDenseEdge>(0, grid, st, x, N, D, rowptr, src, aux, ea, etab, T, agg);
+    case kTableLds: return launch_fwd_one<G, V, kTableLds>(lds, grid, st, x, N, D, rowptr, src, aux, ea, etab, T, agg);
+    default: return launch_fwd_one<G, V, kTableGlobal>(0, grid, st, x, N, D, rowptr, src, aux, ea, etab, T, agg);
   }
-  STEMGNN_LAUNCH_CHECK();
-  return STEMGNN_OK;
 }
 
 template <int G, int V>
@@ -299,6 +335,32 @@ int stemgnn_sage_agg_fwd(const float* x, int64_t N, int64_t D, const int32_t* ro
   dim3 grid(static_cast<unsigned>((N + groups - 1) / groups));
   const int Di = static_cast<int>(D);
   STEMGNN_GEOM_DISPATCH(launch_fwd_mode, mode, lds, grid, st, x, N, Di, rowptr, src, aux, edge_attr, etab, T, agg);
+}
+
+int stemgnn_profile_k1(int enable) {
+  std::lock_guard<std::mutex> lock(g_k1_profile.mu);
+  g_k1_profile.enabled = enable != 0;
+  return STEMGNN_OK;
+}
+
+int stemgnn_profile_k1_collect(double* total_ms_host, int64_t* launches_host) {
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;
+  {
+    std::lock_guard<std::mutex> lock(g_k1_profile.mu);
+    evs.swap(g_k1_profile.events);
+  }
+  double total = 0.0;
+  for (auto& pr : evs) {
+    STEMGNN_HIP_TRY(hipEventSynchronize(pr.second));
+    float ms = 0.f;
+    STEMGNN_HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
+    total += ms;
+    (void)hipEventDestroy(pr.first);
+    (void)hipEventDestroy(pr.second);
+  }
+  if (total_ms_host) *total_ms_host = total;
+  if (launches_host) *launches_host = static_cast<int64_t>(evs.size());
+  return STEMGNN_OK;
 }
 
 int stemgnn_sage_agg_bwd(const float* g_agg, const float* x, int64_t N, int64_t D, const int32_t* rowptr_t,

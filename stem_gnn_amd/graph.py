@@ -93,6 +93,13 @@ class GraphStructure:
             self._edge_index = torch.stack([self.src[:n_live].long(), dst], dim=0)
         return self._edge_index
 
+    def live_edges_host(self) -> int:
+        """Number of edges the CSR actually holds, on the host (one sync the first time for an
+        augmented graph; measurement/reporting use only)."""
+        if getattr(self, "_live", None) is None:
+            self._live = self.num_edges if self._edge_index is not None else int(self.rowptr[-1].item())
+        return self._live
+
     def has_edge_type(self) -> bool:
         return self.etype_slot is not None
 

@@ -151,16 +151,26 @@ def inv_degree(rowptr: Tensor) -> Tensor:
 # K1 / K2
 # ----------------------------------------------------------------------------------------
 class KernelTimer:
-    """Brackets every K1-forward launch with HIP events on the launch stream (bench.py's
-    roofline leg).  Records (algorithmic bytes, start event, end event) per launch."""
+    """In-situ timing of every K1-forward launch (bench.py's roofline leg).  The library stamps
+    each launch with its own begin/end HIP events (hipExtLaunchKernelGGL), so the time is the
+    kernel's, not the gap-inclusive span between marker packets."""
 
     def __init__(self):
         self.enabled = False
-        self.records = []
+        self.bytes = []
 
     def reset(self, enabled: bool):
         self.enabled = enabled
-        self.records = []
+        self.bytes = []
+        check(lib.stemgnn_profile_k1(1 if enabled else 0), "profile_k1")
+
+    def collect(self):
+        """-> (total kernel ms, launches, total algorithmic bytes)"""
+        import ctypes
+        ms, n = ctypes.c_double(0.0), ctypes.c_int64(0)
+        check(lib.stemgnn_profile_k1_collect(ctypes.byref(ms), ctypes.byref(n)), "profile_k1_collect")
+        total = sum(k1_algorithmic_bytes(N, g.live_edges_host(), D, mode, T) for (N, g, D, mode, T) in self.bytes)
+        return ms.value, n.value, float(total)
 
 
 k1_timer = KernelTimer()
@@ -195,15 +205,11 @@ def sage_agg_fwd(x: Tensor, graph, edge_attr: Optional[Tensor], etab: Optional[T
         if etype_slot is None:
             raise RuntimeError("graph structure has no edge types; build it with edge_type=...")
     agg = torch.empty_like(x)
-    if k1_timer.enabled:
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev0.record()
     check(lib.stemgnn_sage_agg_fwd(_p(x), N, D, _p(graph.rowptr), _p(graph.src), _p(graph.eid), _p(edge_attr),
                                    _p(etab), _p(etype_slot), T, _p(agg), _stream()), "sage_agg_fwd")
     if k1_timer.enabled:
-        ev1.record()
         mode = "dense" if edge_attr is not None else ("table" if etab is not None else "none")
-        k1_timer.records.append((k1_algorithmic_bytes(N, graph.num_edges, D, mode, T), ev0, ev1))
+        k1_timer.bytes.append((N, graph, D, mode, T))  # edge counts are resolved after the timed region
     return agg
 
 
