@@ -1,0 +1,80 @@
+"""Data-parallel plumbing for the pretraining path (no reference counterpart: the reference is
+single-process, pretrain.py:84).  One process per GPU; RCCL over xGMI through
+torch.distributed's "nccl" backend on ROCm; "gloo" on CPU for the logic tests.
+
+The path shards naturally over seed-node mini-batches: graph structure and
+feature tables are replicated, every rank samples its own subgraphs from its shard of the
+shuffled seed list and runs the full step; the only exchange is the gradient all-reduce
+(DistributedDataParallel buckets, overlapped with backward) plus, when EMA codebook updates
+are enabled, the VQ statistics all-reduce the reference already carries (vq.py:666,672).
+"""
+from __future__ import annotations
+
+import os
+from typing import Iterable, Tuple
+
+import torch
+import torch.distributed as dist
+from torch import Tensor
+
+
+def init_distributed(backend: str = "nccl", device=None) -> Tuple[int, int]:
+    """(rank, world_size) from the torchrun environment; no-op when WORLD_SIZE <= 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        kwargs = {"device_id": device} if (device is not None and backend == "nccl") else {}
+        dist.init_process_group(backend, **kwargs)
+    return rank, world
+
+
+def shard_seeds(nodes: Tensor, rank: int, world_size: int, seed: int, shuffle: bool = True) -> Tensor:
+    """Shuffle the seed list with a seed shared by all ranks, then deal it round-robin: the
+    shards are disjoint and cover the list; shard sizes differ by at most one."""
+    if shuffle:
+        g = torch.Generator(device=nodes.device).manual_seed(seed)
+        nodes = nodes[torch.randperm(nodes.numel(), generator=g, device=nodes.device)]
+    return nodes[rank::world_size]
+
+
+def reduce_bench_stats(elapsed_s: float, units: float, device) -> Tuple[float, float]:
+    """(max over ranks of the elapsed time, sum over ranks of the processed units)."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return elapsed_s, units
+    t = torch.tensor([elapsed_s], dtype=torch.float64, device=device)
+    u = torch.tensor([units], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(u, op=dist.ReduceOp.SUM)
+    return float(t), float(u)
+
+
+def allreduce_mean_grads_(params: Iterable[Tensor]) -> None:
+    """Explicit (non-overlapped) alternative to DDP: average all gradients in ONE flat
+    all-reduce (2.2 MB at D=128, 41.7 MB at D=768: SURVEY.md §8e)."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return
+    grads = [p.grad for p in params if p.grad is not None]
+    if not grads:
+        return
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat.div_(dist.get_world_size())
+    off = 0
+    for g in grads:
+        n = g.numel()
+        g.copy_(flat[off:off + n].view_as(g))
+        off += n
+
+
+def wrap_ddp(model: torch.nn.Module, device_index=None):
+    """DistributedDataParallel over the trainable parameters.  The EMA teacher never receives
+    gradients (reference pt_model.py:93 detaches it) and is excluded; BatchNorm statistics stay
+    per-rank (no buffer broadcast), like the per-batch statistics of the single-GPU path."""
+    if hasattr(model, "sem_encoder"):
+        for p in model.sem_encoder.parameters():
+            p.requires_grad_(False)
+    kw = dict(broadcast_buffers=False, gradient_as_bucket_view=True)
+    if device_index is not None:
+        kw["device_ids"] = [device_index]
+    return torch.nn.parallel.DistributedDataParallel(model, **kw)

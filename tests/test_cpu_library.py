@@ -1,0 +1,118 @@
+"""CPU-side checks (no GPU): the C-ABI library builds/loads, exports every symbol the header
+declares, rejects bad arguments on the host before any launch, and the product package never
+routes through the oracle."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def L():
+    from stem_gnn_amd import _lib
+    return _lib
+
+
+def test_library_exports_every_declared_symbol(L):
+    names = L.declared_symbols()
+    assert len(names) >= 30
+    missing = [n for n in names if not hasattr(L.lib, n)]
+    assert not missing, missing
+    unbound = [n for n in names if n not in L._SIGNATURES]
+    assert not unbound, f"declared in include/stemgnn.h but not bound in _lib.py: {unbound}"
+    assert L.lib.stemgnn_abi_version() == 1
+    assert L.lib.stemgnn_status_string(0) == b"ok"
+    assert b"workspace" in L.lib.stemgnn_status_string(-3)
+
+
+def test_host_side_argument_validation_needs_no_gpu(L):
+    lib = L.lib
+    # negative sizes / bad dims / null pointers are rejected before anything touches a device
+    assert lib.stemgnn_sage_agg_fwd(None, -1, 128, None, None, None, None, None, None, 0, None, None) == -1
+    assert lib.stemgnn_sage_agg_fwd(None, 10, 130, None, None, None, None, None, None, 0, None, None) == -1  # D % 4
+    assert lib.stemgnn_sage_agg_fwd(None, 10, 128, None, None, None, None, None, None, 0, None, None) == -1  # null x
+    assert lib.stemgnn_sage_agg_fwd(None, 2 ** 31, 128, None, None, None, None, None, None, 0, None, None) == -2
+    assert lib.stemgnn_csr_build(None, 2 ** 31, 10, 1, ctypes.c_void_p(8), None, None, ctypes.c_void_p(8), None, 0,
+                                 None) == -2
+    assert lib.stemgnn_vq_assign_fwd(None, 10, 4, 130, None, 128, 1, None, None, None, None, ctypes.c_void_p(8), None,
+                                     0, None) == -1
+    assert lib.stemgnn_linear_fwd(None, None, 126, None, None, 0, None, 10, 128, None, None, None, None) == -1
+    assert lib.stemgnn_bn_act_drop_fwd(None, 10, 128, None, None, None, None, 2, 0.0, 0.0, 0, 0, None, None) == -1
+    with pytest.raises(L.StemGnnLibraryError):
+        L.check(-1, "probe")
+    assert lib.stemgnn_csr_workspace_bytes(1000, 5000) > 3 * 5000 * 4
+    assert lib.stemgnn_bn_workspace_bytes(1000, 128) > 0
+    assert lib.stemgnn_linear_bwd_weight_workspace_bytes(100000, 128, 128) >= 128 * 128 * 4
+
+
+def test_ops_refuse_cpu_tensors():
+    from stem_gnn_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.csr_build(torch.zeros(2, 4, dtype=torch.int64), 4, 1)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.linear_fwd(torch.zeros(4, 8), torch.zeros(8, 8), None, None, None)
+
+
+def test_product_never_imports_the_oracle():
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b|stem_oracle", re.M)
+    bad = []
+    for base, _, files in os.walk(os.path.join(ROOT, "stem_gnn_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                with open(os.path.join(base, f)) as fh:
+                    if pat.search(fh.read()):
+                        bad.append(os.path.join(base, f))
+    assert not bad, bad
+
+
+def test_module_surface_and_state_dict_contract():
+    """Constructor signatures and state-dict keys/shapes of the reference."""
+    import torch.nn as nn
+    from stem_gnn_amd.model.encoder import Encoder, InnerProductDecoder, MySAGEConv
+    from stem_gnn_amd.model.pt_model import PretrainModel
+    from stem_gnn_amd.model.vq import VectorQuantize
+    D, L_, H, K = 32, 2, 4, 16
+    enc = Encoder(D, D, nn.ReLU, L_, backbone="sage", normalize="batch", dropout=0.15)
+    keys = {k: tuple(v.shape) for k, v in enc.state_dict().items()}
+    for i in range(L_):
+        assert keys[f"layers.{i}.lin_l.weight"] == (D, D) and keys[f"layers.{i}.lin_l.bias"] == (D,)
+        assert keys[f"layers.{i}.lin_r.weight"] == (D, D) and f"layers.{i}.lin_r.bias" not in keys
+        for s in ("weight", "bias", "running_mean", "running_var"):
+            assert keys[f"norms.{i}.{s}"] == (D,)
+        assert keys[f"norms.{i}.num_batches_tracked"] == ()
+    vq = VectorQuantize(dim=D, codebook_size=K, codebook_dim=D, heads=H, separate_codebook_per_head=True,
+                        use_cosine_sim=True, orthogonal_reg_weight=1, orthogonal_reg_max_codes=8, ema_update=False)
+    vk = {k: tuple(v.shape) for k, v in vq.state_dict().items()}
+    assert vk == {"project_in.weight": (H * D, D), "project_in.bias": (H * D,), "project_out.weight": (D, H * D),
+                  "project_out.bias": (D,), "_codebook.embed": (H, K, D), "_codebook.initted": (1,),
+                  "_codebook.cluster_size": (H, K), "_codebook.embed_avg": (H, K, D)}
+    assert tuple(vq.codebook.shape) == (H, K, D) and vq._codebook.num_codebooks == H and vq.dim == D
+    pm = PretrainModel(enc, vq, nn.Linear(D, D), InnerProductDecoder(D, D), nn.Linear(2 * D, D))
+    assert hasattr(pm, "sem_encoder") and hasattr(pm, "sem_projector") and pm.get_encoder is enc and pm.get_vq is vq
+    moe = Encoder(D, D, nn.LeakyReLU, 2, moe=True, num_experts=3, moe_layers="last", normalize="batch")
+    mk = moe.state_dict()
+    assert tuple(mk["layers.1.weights"].shape) == (3, 2 * D, D) and "env_encoders.0.weight" in mk
+    with pytest.raises(NotImplementedError):
+        VectorQuantize(dim=D, codebook_size=K, use_cosine_sim=False)
+    with pytest.raises(NotImplementedError):
+        MySAGEConv(D, D, aggr="max")
+
+
+def test_params_and_scheduler_match_reference_defaults():
+    from stem_gnn_amd.pretrain import default_params
+    from stem_gnn_amd.utils.others import get_scheduler
+    p = default_params()
+    assert (p["hidden_dim"], p["num_layers"], p["codebook_size"], p["codebook_head"]) == (768, 2, 128, 4)
+    assert (p["feat_lambda"], p["topo_lambda"], p["topo_sem_lambda"], p["sem_lambda"]) == (100, 0.01, 100, 1)
+    opt = torch.optim.AdamW([torch.nn.Parameter(torch.zeros(1))], lr=1.0)
+    sch = get_scheduler(opt, True, 50)
+    lrs = []
+    for _ in range(51):
+        lrs.append(opt.param_groups[0]["lr"])
+        opt.step()
+        sch.step()
+    assert abs(lrs[0] - 1.0) < 1e-12 and abs(lrs[25] - 0.5) < 1e-9 and abs(lrs[50]) < 1e-9
