@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--codebook-size", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
     return ap.parse_args()
 
 
@@ -97,11 +98,16 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if os.environ.get("STEMGNN_SHARE_DEVICE"):  # rehearsal only: several ranks on one card (gloo backend)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        else:
+            dist.init_process_group(args.backend)
 
     from stem_gnn_amd import ops
     from stem_gnn_amd.data.sampler import NeighborLoader, NeighborSampler
@@ -149,9 +155,8 @@ def main():
     opt, sched = build_optimizer(model, params)
     fwd = None
     if world > 1:
-        ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], broadcast_buffers=False,
-                                                        gradient_as_bucket_view=True)
-        fwd = ddp
+        from stem_gnn_amd.parallel import wrap_ddp
+        fwd = wrap_ddp(model, local_rank)
     set_validation(False)  # batches come from our own sampler: skip the per-build device->host range check
     model.train()
 
@@ -176,14 +181,9 @@ def main():
     k1_ms, k1_launches, k1_bytes = ops.k1_timer.collect()
     ops.k1_timer.reset(False)
 
+    from stem_gnn_amd.parallel import reduce_bench_stats
     edges = float(sum(batches[i][1].num_edges for i in range(args.warmup, total)))
-    stat = torch.tensor([dt, edges], dtype=torch.float64, device=dev)
-    if world > 1:
-        tmax = stat[:1].clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        esum = stat[1:].clone()
-        dist.all_reduce(esum, op=dist.ReduceOp.SUM)
-        dt, edges = float(tmax), float(esum)
+    dt, edges = reduce_bench_stats(dt, edges, dev)
 
     if rank == 0:
         achieved = k1_bytes / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0

@@ -61,11 +61,12 @@ k_edge_dot_bwd(const float* __restrict__ g_out, const float* __restrict__ g_scal
   int64_t u, v;
   if (!load_edge(ei, E, e, N, &u, &v)) return;
   const float g = g_out[e] * (g_scalar ? g_scalar[0] : 1.0f);
-  const int nvec = D / 4;
-  for (int c = lane; c < nvec; c += G) {
-    const float4 a = ld4(z + u * D + 4 * c), b = ld4(z + v * D + 4 * c);
-    atomic_add4(g_z + u * D + 4 * c, make_float4(g * b.x, g * b.y, g * b.z, g * b.w));
-    atomic_add4(g_z + v * D + 4 * c, make_float4(g * a.x, g * a.y, g * a.z, g * a.w));
+  // one dword per lane, consecutive lanes on consecutive addresses: each atomic wave-instruction
+  // covers whole 128-byte row segments (the shape the memory-side atomic units run at full rate)
+  for (int c = lane; c < D; c += G) {
+    const float a = z[u * D + c], b = z[v * D + c];
+    atomicAdd(g_z + u * D + c, g * b);
+    atomicAdd(g_z + v * D + c, g * a);
   }
 }
 
@@ -96,11 +97,10 @@ k_edge_concat_bwd(const float* __restrict__ g_out, int64_t N, int D, const int64
   if (e >= E) return;
   int64_t u, v;
   if (!load_edge(ei, E, e, N, &u, &v)) return;
-  const int nvec = D / 4;
   const float* g = g_out + e * 2 * D;
-  for (int c = lane; c < nvec; c += G) {
-    atomic_add4(g_z + u * D + 4 * c, ld4(g + 4 * c));
-    atomic_add4(g_z + v * D + 4 * c, ld4(g + D + 4 * c));
+  for (int c = lane; c < D; c += G) {
+    atomicAdd(g_z + u * D + c, g[c]);
+    atomicAdd(g_z + v * D + c, g[D + c]);
   }
 }
 
