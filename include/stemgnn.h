@@ -134,6 +134,14 @@ int stemgnn_sage_agg_bwd(const float* g_agg, const float* x, int64_t num_nodes, 
 
 int stemgnn_inv_degree(const int32_t* rowptr, int64_t num_nodes, float* inv_deg, void* stream);
 
+/* Plain mean aggregation agg[i] = mean_{slots of i} x[src] (no edge term, no relu) and its
+ * backward: torch_scatter.scatter_mean(x[col], row) of MixtureSageLayer (model/encoder.py:124),
+ * evaluated on the CSR of the FLIPPED graph. */
+int stemgnn_mean_agg_fwd(const float* x, int64_t num_nodes, int64_t dim, const int32_t* rowptr, const int32_t* src,
+                         float* agg, void* stream);
+int stemgnn_mean_agg_bwd(const float* g_agg, int64_t num_nodes, int64_t dim, const int32_t* rowptr_t,
+                         const int32_t* dst_t, const float* inv_deg, float* g_x, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * K4: BatchNorm1d (training statistics) + ReLU/LeakyReLU + Dropout
  * (model/encoder.py:173,313-317).
@@ -182,8 +190,10 @@ int stemgnn_dropout_keep_mask(int64_t n, float p, uint64_t seed, uint64_t offset
 
 /* y [M, N] = x1 [M, K1] w1[N, K1]^T (+ x2 [M, K2] w2 [N, K2]^T when K2 > 0) + bias [N] (NULL: none).
  * stats_partial (may be NULL): receives per-row-block column sums / sums of squares of y,
- * [ceil(M/128)][2][N]; *stats_blocks_host (host pointer, may be NULL) = ceil(M/128). */
+ * [stemgnn_linear_stats_blocks(M, k1 + k2)][2][N]; *stats_blocks_host (host pointer, may be NULL)
+ * receives that block count. */
 size_t stemgnn_linear_stats_partial_bytes(int64_t num_rows, int64_t out_dim);
+int64_t stemgnn_linear_stats_blocks(int64_t num_rows, int64_t k_total);
 int stemgnn_linear_fwd(const float* x1, const float* w1, int64_t k1, const float* x2, const float* w2, int64_t k2,
                        const float* bias, int64_t num_rows, int64_t out_dim, float* y, float* stats_partial,
                        int64_t* stats_blocks_host, void* stream);

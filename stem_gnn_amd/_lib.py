@@ -47,6 +47,8 @@ _SIGNATURES = {
     "stemgnn_group_by_key": (c_int, [P, I64, I64, P, P, P, c_size_t, P]),
     "stemgnn_sage_agg_fwd": (c_int, [P, I64, I64, P, P, P, P, P, P, I64, P, P]),
     "stemgnn_sage_agg_bwd": (c_int, [P, P, I64, I64, P, P, P, P, P, P, P, I64, P, P]),
+    "stemgnn_mean_agg_fwd": (c_int, [P, I64, I64, P, P, P, P]),
+    "stemgnn_mean_agg_bwd": (c_int, [P, I64, I64, P, P, P, P, P]),
     "stemgnn_profile_k1": (c_int, [c_int]),
     "stemgnn_profile_k1_collect": (c_int, [P, P]),
     "stemgnn_inv_degree": (c_int, [P, I64, P, P]),
@@ -54,6 +56,7 @@ _SIGNATURES = {
     "stemgnn_bn_stats": (c_int, [P, I64, I64, c_float, P, P, P, P, c_float, P, c_size_t, P]),
     "stemgnn_bn_stats_from_partials": (c_int, [P, I64, I64, I64, c_float, P, P, P, P, c_float, P]),
     "stemgnn_linear_stats_partial_bytes": (c_size_t, [I64, I64]),
+    "stemgnn_linear_stats_blocks": (I64, [I64, I64]),
     "stemgnn_linear_fwd": (c_int, [P, P, I64, P, P, I64, P, I64, I64, P, P, P, P]),
     "stemgnn_linear_bwd_weight_workspace_bytes": (c_size_t, [I64, I64, I64]),
     "stemgnn_linear_bwd_weight": (c_int, [P, P, I64, I64, I64, P, P, P, c_size_t, P]),

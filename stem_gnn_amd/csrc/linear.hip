@@ -177,6 +177,181 @@ k_linear_fwd(const float* __restrict__ x1, const float* __restrict__ w1, int K1,
 }
 
 // ---------------------------------------------------------------------------------------
+// forward, weight-resident variant (K1 + K2 <= 256): the 128-column weight tile stays in LDS
+// for the whole life of a PERSISTENT block (one 512-thread block per CU, 2 waves per SIMD),
+// which then only streams activation chunks: BM x 32 floats per step through a double-buffered
+// LDS ring with ONE barrier per step and the next chunk's global loads in flight behind the
+// MFMAs, continuously across row-tile boundaries (no per-tile prologue bubble).
+//   BM = 128 (K <= 128): waves 4(m) x 2(n), 32x64 per wave;  BM = 64 (K <= 256): 2 x 4, 32x32.
+// ---------------------------------------------------------------------------------------
+constexpr int kResThreads = 512;
+
+template <int BM, bool STATS>
+__global__ void __launch_bounds__(kResThreads)
+k_linear_fwd_res(const float* __restrict__ x1, const float* __restrict__ w1, int K1, const float* __restrict__ x2,
+                 const float* __restrict__ w2, int K2, const float* __restrict__ bias, int64_t M, int N,
+                 float* __restrict__ y, float* __restrict__ stats_partial /*[ceil(M/BM)][2][N]*/) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int WM = BM / 32;          // waves along m (each wave owns 32 rows)
+  constexpr int WN = 8 / WM;           // waves along n
+  constexpr int TN = 4 / WN;           // 32-column accumulator tiles per wave
+  constexpr int FPT = BM * 8 / kResThreads;  // float4 of an activation chunk per thread
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN, hi = lane >> 5, lj = lane & 31;
+  const int Ktot = K1 + K2;
+  const int chunks = (Ktot + kKC - 1) / kKC;
+  const int ldb = chunks * kKC + 4;
+  float* sB = smem;                               // [128][ldb]
+  float* sA = sB + kBN * ldb;                     // [2][BM][kLd]
+  float* s_stats = sA + 2 * BM * kLd;             // [WM][2][128]
+  const int n0 = blockIdx.y * kBN;
+
+  // resident weight tile (zero beyond N and beyond Ktot)
+  {
+    const int vec_per_row = chunks * kKC / 4;
+    for (int idx = tid; idx < kBN * vec_per_row; idx += kResThreads) {
+      const int r = idx / vec_per_row, k = 4 * (idx - r * vec_per_row);
+      const int n = n0 + r;
+      float4 v = zero4();
+      if (n < N && k < Ktot)
+        v = k < K1 ? ld4(w1 + static_cast<int64_t>(n) * K1 + k) : ld4(w2 + static_cast<int64_t>(n) * K2 + (k - K1));
+      st4(sB + r * ldb + k, v);
+    }
+  }
+  float bias_v[TN];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int n = n0 + wn * 32 * TN + tn * 32 + lj;
+    bias_v[tn] = (bias != nullptr && n < N) ? bias[n] : 0.f;
+  }
+
+  const int64_t num_tiles = (M + BM - 1) / BM;
+  const int64_t my_tiles = blockIdx.x < num_tiles ? (num_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+  const int64_t total = my_tiles * chunks;
+
+  // Register ring three chunks deep: the loads of chunk s+3 are issued while chunk s is being
+  // multiplied, so an HBM round trip has three chunk times to land (a single persistent block
+  // per CU has no other block to hide it behind).
+  auto fetch = [&](int64_t step, float4 (&slot)[FPT]) {
+    const int64_t tile = blockIdx.x + (step / chunks) * gridDim.x;
+    const int k0 = static_cast<int>(step % chunks) * kKC;
+#pragma unroll
+    for (int t = 0; t < FPT; ++t) {
+      const int idx = t * kResThreads + tid;
+      const int r = idx >> 3, k = k0 + 4 * (idx & 7);
+      const int64_t m = tile * BM + r;
+      float4 v = zero4();
+      if (m < M && k < Ktot) v = k < K1 ? ld4(x1 + m * K1 + k) : ld4(x2 + m * K2 + (k - K1));
+      slot[t] = v;
+    }
+  };
+
+  floatx16 acc[TN];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[tn][r] = 0.f;
+
+  auto body = [&](int64_t step, float4 (&slot)[FPT]) {
+    float* buf = sA + (step & 1) * BM * kLd;
+#pragma unroll
+    for (int t = 0; t < FPT; ++t) {
+      const int idx = t * kResThreads + tid;
+      st4(buf + (idx >> 3) * kLd + 4 * (idx & 7), slot[t]);
+    }
+    __syncthreads();  // the only barrier of the step (also fences the first use of the resident tile)
+    if (step + 3 < total) fetch(step + 3, slot);
+    const int kc = static_cast<int>(step % chunks);
+    const float* bbase = sB + kc * kKC;
+#pragma unroll
+    for (int ms = 0; ms < kKC / 8; ++ms) {
+      const int ko = ms * 8 + hi * 4;
+      const float4 a = ld4(buf + (wm * 32 + lj) * kLd + ko);
+      float4 b[TN];
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) b[tn] = ld4(bbase + (wn * 32 * TN + tn * 32 + lj) * ldb + ko);
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) acc[tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[tn].x, acc[tn], 0, 0, 0);
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) acc[tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[tn].y, acc[tn], 0, 0, 0);
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) acc[tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[tn].z, acc[tn], 0, 0, 0);
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) acc[tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[tn].w, acc[tn], 0, 0, 0);
+    }
+    if (kc == chunks - 1) {
+      // ---- tile epilogue (stores only; the bias was loaded up front)
+      const int64_t tile = blockIdx.x + (step / chunks) * gridDim.x;
+      const int64_t mrow0 = tile * BM + wm * 32 + 4 * hi;
+      const bool interior = (tile * BM + BM <= M) && (n0 + kBN <= N);
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const int nl = wn * 32 * TN + tn * 32 + lj;
+        const int n = n0 + nl;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t m = mrow0 + (r & 3) + 8 * (r >> 2);
+          const float v = acc[tn][r] + bias_v[tn];
+          if (interior || (m < M && n < N)) {
+            y[m * N + n] = v;
+            if (STATS) { s1 += v; s2 += v * v; }
+          }
+          acc[tn][r] = 0.f;
+        }
+        if (STATS) {
+          s1 += __shfl_xor(s1, 32, 64);
+          s2 += __shfl_xor(s2, 32, 64);
+          if (hi == 0) { s_stats[(wm * 2 + 0) * kBN + nl] = s1; s_stats[(wm * 2 + 1) * kBN + nl] = s2; }
+        }
+      }
+      if (STATS) {
+        __syncthreads();
+        if (tid < kBN && n0 + tid < N) {
+          float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+          for (int w = 0; w < WM; ++w) { t1 += s_stats[(w * 2 + 0) * kBN + tid]; t2 += s_stats[(w * 2 + 1) * kBN + tid]; }
+          float* p = stats_partial + tile * 2 * N;
+          p[n0 + tid] = t1;
+          p[N + n0 + tid] = t2;
+        }
+      }
+    }
+  };
+
+  float4 r0[FPT], r1[FPT], r2[FPT];
+  if (total > 0) fetch(0, r0);
+  if (total > 1) fetch(1, r1);
+  if (total > 2) fetch(2, r2);
+  for (int64_t step = 0; step < total; step += 3) {
+    body(step, r0);
+    if (step + 1 < total) body(step + 1, r1);
+    if (step + 2 < total) body(step + 2, r2);
+  }
+}
+
+inline size_t res_lds_bytes(int BM, int Ktot) {
+  const int chunks = (Ktot + kKC - 1) / kKC;
+  return static_cast<size_t>(kBN * (chunks * kKC + 4) + 2 * BM * kLd + (BM / 32) * 2 * kBN) * sizeof(float);
+}
+
+template <int BM, bool STATS>
+int launch_res(dim3 grid, hipStream_t st, const float* x1, const float* w1, int K1, const float* x2, const float* w2,
+               int K2, const float* bias, int64_t M, int N, float* y, float* stats) {
+  const size_t lds = res_lds_bytes(BM, K1 + K2);
+  static bool configured = false;  // per instantiation
+  if (!configured) {
+    STEMGNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linear_fwd_res<BM, STATS>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    configured = true;
+  }
+  k_linear_fwd_res<BM, STATS><<<grid, kResThreads, lds, st>>>(x1, w1, K1, x2, w2, K2, bias, M, N, y, stats);
+  STEMGNN_LAUNCH_CHECK();
+  return STEMGNN_OK;
+}
+
+// ---------------------------------------------------------------------------------------
 // backward-W: partial[s] = dY[rows of split s]^T X[rows of split s]; partial_db[s] = colsum dY
 // C[i = n][j = k]; the reduction index (row m) is the slow dimension of BOTH operands, so the
 // MFMA fragments are 4-byte LDS reads along a row (conflict-free: 32 consecutive dwords).
@@ -318,6 +493,9 @@ inline bool lin_dims_ok(int64_t M, int64_t N, int64_t K) {
   return M >= 0 && N > 0 && K > 0 && K % 4 == 0 && N <= 65536 && K <= 65536;
 }
 
+// rows per tile of the weight-resident forward variant (also the granularity of its statistics partials)
+inline int res_block_rows(int64_t Ktot) { return Ktot <= 128 ? 128 : 64; }
+
 inline int pick_splits(int64_t M) {
   int64_t s = (M + 223) / 224;  // ~7 chunks of 32 rows per split: ~2 blocks per CU at M = 1e5
   if (s < 1) s = 1;
@@ -334,7 +512,13 @@ extern "C" {
 
 size_t stemgnn_linear_stats_partial_bytes(int64_t M, int64_t N) {
   if (M < 0 || N <= 0) return 0;
-  return static_cast<size_t>((M + kBM - 1) / kBM) * 2 * N * sizeof(float) + 256;
+  return static_cast<size_t>((M + 63) / 64) * 2 * N * sizeof(float) + 256;  // upper bound over both variants
+}
+
+int64_t stemgnn_linear_stats_blocks(int64_t M, int64_t k_total) {
+  if (M < 0 || k_total <= 0) return 0;
+  const int64_t rows = k_total <= 256 ? res_block_rows(k_total) : kBM;
+  return (M + rows - 1) / rows;
 }
 
 int stemgnn_linear_fwd(const float* x1, const float* w1, int64_t K1, const float* x2, const float* w2, int64_t K2,
@@ -343,11 +527,28 @@ int stemgnn_linear_fwd(const float* x1, const float* w1, int64_t K1, const float
   hipStream_t st = static_cast<hipStream_t>(stream_);
   if (!lin_dims_ok(M, N, K1) || K2 < 0 || K2 % 4 != 0) return STEMGNN_ERR_INVALID_ARG;
   if (!fits_i32(M)) return STEMGNN_ERR_TOO_LARGE;
-  if (stats_blocks_host) *stats_blocks_host = (M + kBM - 1) / kBM;
+  if (stats_blocks_host) *stats_blocks_host = stemgnn_linear_stats_blocks(M, K1 + K2);
   if (M == 0) return STEMGNN_OK;
   if (!x1 || !w1 || !y || (K2 > 0 && (!x2 || !w2))) return STEMGNN_ERR_INVALID_ARG;
   if (N % 4 != 0) return STEMGNN_ERR_INVALID_ARG;
-  dim3 grid(static_cast<unsigned>((M + kBM - 1) / kBM), static_cast<unsigned>((N + kBN - 1) / kBN));
+  const int gy = static_cast<int>((N + kBN - 1) / kBN);
+  const int64_t Ktot = K1 + K2;
+  if (Ktot <= 256 && (K2 == 0 || K1 % 4 == 0)) {
+    // weight-resident persistent variant: one 512-thread block per CU
+    const int BM = res_block_rows(Ktot);
+    const int64_t tiles = (M + BM - 1) / BM;
+    int gx = 256 / gy;
+    if (gx < 1) gx = 1;
+    if (gx > tiles) gx = static_cast<int>(tiles);
+    dim3 grid(static_cast<unsigned>(gx), static_cast<unsigned>(gy));
+    const int k1 = static_cast<int>(K1), k2 = static_cast<int>(K2), n = static_cast<int>(N);
+    if (BM == 128)
+      return stats_partial ? launch_res<128, true>(grid, st, x1, w1, k1, x2, w2, k2, bias, M, n, y, stats_partial)
+                           : launch_res<128, false>(grid, st, x1, w1, k1, x2, w2, k2, bias, M, n, y, nullptr);
+    return stats_partial ? launch_res<64, true>(grid, st, x1, w1, k1, x2, w2, k2, bias, M, n, y, stats_partial)
+                         : launch_res<64, false>(grid, st, x1, w1, k1, x2, w2, k2, bias, M, n, y, nullptr);
+  }
+  dim3 grid(static_cast<unsigned>((M + kBM - 1) / kBM), static_cast<unsigned>(gy));
   if (stats_partial)
     k_linear_fwd<true><<<grid, kBlock, 0, st>>>(x1, w1, static_cast<int>(K1), x2, w2, static_cast<int>(K2), bias, M,
                                                 static_cast<int>(N), y, stats_partial);

@@ -41,6 +41,9 @@ __device__ inline float4 ld4(const float* p) { return *reinterpret_cast<const fl
 __device__ inline void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
 __device__ inline float relu_keep_nan(float v) { return v < 0.f ? 0.f : v; }
+__device__ inline float msg(float v, int relu) { return relu ? relu_keep_nan(v) : v; }
+
+constexpr int kRowsPerGroup = 1;  // measured: 2 and 4 rows per group are slower (fewer groups in flight)
 
 // Load the edge-type table [T, D] into LDS (all threads of the block).
 __device__ inline void stage_table(float* lds, const float* __restrict__ etab, int64_t T, int64_t D) {
@@ -57,73 +60,81 @@ __global__ void __launch_bounds__(kBlock)
 k_sage_agg_fwd(const float* __restrict__ x, int64_t N, int D, const int32_t* __restrict__ rowptr,
                const int32_t* __restrict__ src, const int32_t* __restrict__ aux,  // eid (dense) or etype per slot
                const float* __restrict__ edge_attr, const float* __restrict__ etab, int64_t T,
-               float* __restrict__ agg) {
+               float* __restrict__ agg, int relu) {
   extern __shared__ __attribute__((aligned(16))) float lds_tab[];
   if (MODE == kTableLds) stage_table(lds_tab, etab, T, D);
 
   constexpr int kGroups = kBlock / G;
+  constexpr int R = kRowsPerGroup;                  // consecutive destination rows per group
+  constexpr int U = V <= 3 ? 4 : (V == 4 ? 2 : 1);  // neighbour rows in flight per group
   const int lane = threadIdx.x % G;
   const int group = threadIdx.x / G;
-  const int64_t row = static_cast<int64_t>(blockIdx.x) * kGroups + group;
-  if (row >= N) return;
+  const int64_t row0 = (static_cast<int64_t>(blockIdx.x) * kGroups + group) * R;
+  if (row0 >= N) return;
   const int nvec = D / 4;
+  // one coalesced read of the R+1 segment offsets, then broadcast (G >= 8 > R)
+  int my_ptr = 0;
+  if (lane <= R && row0 + lane <= N) my_ptr = rowptr[row0 + lane];
 
-  constexpr int U = V <= 3 ? 4 : (V == 4 ? 2 : 1);  // neighbour rows in flight per group
-  const int beg = rowptr[row], end = rowptr[row + 1];
-  float4 acc[V];
+  for (int rr = 0; rr < R; ++rr) {
+    const int64_t row = row0 + rr;
+    const int beg = __shfl(my_ptr, rr, G), end = __shfl(my_ptr, rr + 1, G);
+    if (row >= N) break;
+    float4 acc[V];
 #pragma unroll
-  for (int v = 0; v < V; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int v = 0; v < V; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  for (int base = beg; base < end; base += G) {
-    const int cnt = min(G, end - base);
-    int my_src = 0, my_aux = 0;
-    if (lane < cnt) {
-      my_src = src[base + lane];
-      if (MODE != kNoEdge) my_aux = aux[base + lane];
-    }
-    for (int j = 0; j < cnt; j += U) {
-      float4 xv[U][V], ev[U][V];
-#pragma unroll
-      for (int k = 0; k < U; ++k) {
-        const int jj = (j + k < cnt) ? j + k : j;  // clamp: duplicate load, contribution masked below
-        const int s = __shfl(my_src, jj, G);
-        const int a = __shfl(my_aux, jj, G);
-        const float* xr = x + static_cast<int64_t>(s) * D;
-#pragma unroll
-        for (int v = 0; v < V; ++v) {
-          const int c = lane + G * v;
-          if (c < nvec) {
-            xv[k][v] = ld4(xr + 4 * c);
-            if (MODE == kDenseEdge) ev[k][v] = ld4(edge_attr + static_cast<int64_t>(a) * D + 4 * c);
-            else if (MODE == kTableLds) ev[k][v] = ld4(lds_tab + static_cast<int64_t>(a) * D + 4 * c);
-            else if (MODE == kTableGlobal) ev[k][v] = ld4(etab + static_cast<int64_t>(a) * D + 4 * c);
-            else ev[k][v] = make_float4(0.f, 0.f, 0.f, 0.f);
-          }
-        }
+    for (int base = beg; base < end; base += G) {
+      const int cnt = min(G, end - base);
+      int my_src = 0, my_aux = 0;
+      if (lane < cnt) {
+        my_src = src[base + lane];
+        if (MODE != kNoEdge) my_aux = aux[base + lane];
       }
+      for (int j = 0; j < cnt; j += U) {
+        float4 xv[U][V], ev[U][V];
 #pragma unroll
-      for (int k = 0; k < U; ++k) {
-        if (j + k < cnt) {
+        for (int k = 0; k < U; ++k) {
+          const int jj = (j + k < cnt) ? j + k : j;  // clamp: duplicate load, contribution masked below
+          const int s = __shfl(my_src, jj, G);
+          const int a = __shfl(my_aux, jj, G);
+          const float* xr = x + static_cast<int64_t>(s) * D;
 #pragma unroll
           for (int v = 0; v < V; ++v) {
-            if (lane + G * v < nvec) {
-              acc[v].x += relu_keep_nan(xv[k][v].x + ev[k][v].x);
-              acc[v].y += relu_keep_nan(xv[k][v].y + ev[k][v].y);
-              acc[v].z += relu_keep_nan(xv[k][v].z + ev[k][v].z);
-              acc[v].w += relu_keep_nan(xv[k][v].w + ev[k][v].w);
+            const int c = lane + G * v;
+            if (c < nvec) {
+              xv[k][v] = ld4(xr + 4 * c);
+              if (MODE == kDenseEdge) ev[k][v] = ld4(edge_attr + static_cast<int64_t>(a) * D + 4 * c);
+              else if (MODE == kTableLds) ev[k][v] = ld4(lds_tab + static_cast<int64_t>(a) * D + 4 * c);
+              else if (MODE == kTableGlobal) ev[k][v] = ld4(etab + static_cast<int64_t>(a) * D + 4 * c);
+              else ev[k][v] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+          if (j + k < cnt) {
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+              if (lane + G * v < nvec) {
+                acc[v].x += msg(xv[k][v].x + ev[k][v].x, relu);
+                acc[v].y += msg(xv[k][v].y + ev[k][v].y, relu);
+                acc[v].z += msg(xv[k][v].z + ev[k][v].z, relu);
+                acc[v].w += msg(xv[k][v].w + ev[k][v].w, relu);
+              }
             }
           }
         }
       }
     }
-  }
-  const int deg = end - beg;
-  const float inv = 1.0f / static_cast<float>(deg < 1 ? 1 : deg);
-  float* out = agg + row * D;
+    const int deg = end - beg;
+    const float inv = 1.0f / static_cast<float>(deg < 1 ? 1 : deg);
+    float* out = agg + row * D;
 #pragma unroll
-  for (int v = 0; v < V; ++v) {
-    const int c = lane + G * v;
-    if (c < nvec) st4(out + 4 * c, make_float4(acc[v].x * inv, acc[v].y * inv, acc[v].z * inv, acc[v].w * inv));
+    for (int v = 0; v < V; ++v) {
+      const int c = lane + G * v;
+      if (c < nvec) st4(out + 4 * c, make_float4(acc[v].x * inv, acc[v].y * inv, acc[v].z * inv, acc[v].w * inv));
+    }
   }
 }
 
@@ -137,7 +148,7 @@ k_sage_agg_bwd(const float* __restrict__ g_agg, const float* __restrict__ x, int
                const int32_t* __restrict__ rowptr_t, const int32_t* __restrict__ dst_t,
                const int32_t* __restrict__ aux, const float* __restrict__ inv_deg,
                const float* __restrict__ edge_attr, const float* __restrict__ etab, int64_t T,
-               float* __restrict__ g_x) {
+               float* __restrict__ g_x, int relu) {
   extern __shared__ __attribute__((aligned(16))) float lds_tab[];
   if (MODE == kTableLds) stage_table(lds_tab, etab, T, D);
 
@@ -195,10 +206,10 @@ k_sage_agg_bwd(const float* __restrict__ g_agg, const float* __restrict__ x, int
 #pragma unroll
           for (int v = 0; v < V; ++v) {
             if (lane + G * v < nvec) {
-              acc[v].x += (xs[v].x + ev[k][v].x > 0.f) ? gv[k][v].x * w[k] : 0.f;
-              acc[v].y += (xs[v].y + ev[k][v].y > 0.f) ? gv[k][v].y * w[k] : 0.f;
-              acc[v].z += (xs[v].z + ev[k][v].z > 0.f) ? gv[k][v].z * w[k] : 0.f;
-              acc[v].w += (xs[v].w + ev[k][v].w > 0.f) ? gv[k][v].w * w[k] : 0.f;
+              acc[v].x += (!relu || xs[v].x + ev[k][v].x > 0.f) ? gv[k][v].x * w[k] : 0.f;
+              acc[v].y += (!relu || xs[v].y + ev[k][v].y > 0.f) ? gv[k][v].y * w[k] : 0.f;
+              acc[v].z += (!relu || xs[v].z + ev[k][v].z > 0.f) ? gv[k][v].z * w[k] : 0.f;
+              acc[v].w += (!relu || xs[v].w + ev[k][v].w > 0.f) ? gv[k][v].w * w[k] : 0.f;
             }
           }
         }
@@ -235,7 +246,7 @@ inline bool pick_geometry(int64_t D, Geometry* g) {
 template <int G, int V, int MODE>
 int launch_fwd_one(size_t lds, dim3 grid, hipStream_t st, const float* x, int64_t N, int D, const int32_t* rowptr,
                    const int32_t* src, const int32_t* aux, const float* ea, const float* etab, int64_t T,
-                   float* agg) {
+                   float* agg, int relu) {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   {
     std::lock_guard<std::mutex> lock(g_k1_profile.mu);
@@ -247,9 +258,9 @@ int launch_fwd_one(size_t lds, dim3 grid, hipStream_t st, const float* x, int64_
   }
   if (ev0) {
     hipExtLaunchKernelGGL((k_sage_agg_fwd<G, V, MODE>), grid, dim3(kBlock), lds, st, ev0, ev1, 0, x, N, D, rowptr, src,
-                          aux, ea, etab, T, agg);
+                          aux, ea, etab, T, agg, relu);
   } else {
-    k_sage_agg_fwd<G, V, MODE><<<grid, kBlock, lds, st>>>(x, N, D, rowptr, src, aux, ea, etab, T, agg);
+    k_sage_agg_fwd<G, V, MODE><<<grid, kBlock, lds, st>>>(x, N, D, rowptr, src, aux, ea, etab, T, agg, relu);
   }
   STEMGNN_LAUNCH_CHECK();
   return STEMGNN_OK;
@@ -258,24 +269,24 @@ int launch_fwd_one(size_t lds, dim3 grid, hipStream_t st, const float* x, int64_
 template <int G, int V>
 int launch_fwd_mode(int mode, size_t lds, dim3 grid, hipStream_t st, const float* x, int64_t N, int D,
                     const int32_t* rowptr, const int32_t* src, const int32_t* aux, const float* ea,
-                    const float* etab, int64_t T, float* agg) {
+                    const float* etab, int64_t T, float* agg, int relu) {
   switch (mode) {
-    case kNoEdge: return launch_fwd_one<G, V, kNoEdge>(0, grid, st, x, N, D, rowptr, src, aux, ea, etab, T, agg);
-    case kDenseEdge: return launch_fwd_one<G, V, kDenseEdge>(0, grid, st, x, N, D, rowptr, src, aux, ea, etab, T, agg);
-    case kTableLds: return launch_fwd_one<G, V, kTableLds>(lds, grid, st, x, N, D, rowptr, src, aux, ea, etab, T, agg);
-    default: return launch_fwd_one<G, V, kTableGlobal>(0, grid, st, x, N, D, rowptr, src, aux, ea, etab, T, agg);
+    case kNoEdge: return launch_fwd_one<G, V, kNoEdge>(0, grid, st, x, N, D, rowptr, src, aux, ea, etab, T, agg, relu);
+    case kDenseEdge: return launch_fwd_one<G, V, kDenseEdge>(0, grid, st, x, N, D, rowptr, src, aux, ea, etab, T, agg, relu);
+    case kTableLds: return launch_fwd_one<G, V, kTableLds>(lds, grid, st, x, N, D, rowptr, src, aux, ea, etab, T, agg, relu);
+    default: return launch_fwd_one<G, V, kTableGlobal>(0, grid, st, x, N, D, rowptr, src, aux, ea, etab, T, agg, relu);
   }
 }
 
 template <int G, int V>
 int launch_bwd_mode(int mode, size_t lds, dim3 grid, hipStream_t st, const float* g_agg, const float* x, int64_t N,
                     int D, const int32_t* rowptr_t, const int32_t* dst_t, const int32_t* aux, const float* inv_deg,
-                    const float* ea, const float* etab, int64_t T, float* g_x) {
+                    const float* ea, const float* etab, int64_t T, float* g_x, int relu) {
   switch (mode) {
-    case kNoEdge: k_sage_agg_bwd<G, V, kNoEdge><<<grid, kBlock, 0, st>>>(g_agg, x, N, D, rowptr_t, dst_t, aux, inv_deg, ea, etab, T, g_x); break;
-    case kDenseEdge: k_sage_agg_bwd<G, V, kDenseEdge><<<grid, kBlock, 0, st>>>(g_agg, x, N, D, rowptr_t, dst_t, aux, inv_deg, ea, etab, T, g_x); break;
-    case kTableLds: k_sage_agg_bwd<G, V, kTableLds><<<grid, kBlock, lds, st>>>(g_agg, x, N, D, rowptr_t, dst_t, aux, inv_deg, ea, etab, T, g_x); break;
-    default: k_sage_agg_bwd<G, V, kTableGlobal><<<grid, kBlock, 0, st>>>(g_agg, x, N, D, rowptr_t, dst_t, aux, inv_deg, ea, etab, T, g_x); break;
+    case kNoEdge: k_sage_agg_bwd<G, V, kNoEdge><<<grid, kBlock, 0, st>>>(g_agg, x, N, D, rowptr_t, dst_t, aux, inv_deg, ea, etab, T, g_x, relu); break;
+    case kDenseEdge: k_sage_agg_bwd<G, V, kDenseEdge><<<grid, kBlock, 0, st>>>(g_agg, x, N, D, rowptr_t, dst_t, aux, inv_deg, ea, etab, T, g_x, relu); break;
+    case kTableLds: k_sage_agg_bwd<G, V, kTableLds><<<grid, kBlock, lds, st>>>(g_agg, x, N, D, rowptr_t, dst_t, aux, inv_deg, ea, etab, T, g_x, relu); break;
+    default: k_sage_agg_bwd<G, V, kTableGlobal><<<grid, kBlock, 0, st>>>(g_agg, x, N, D, rowptr_t, dst_t, aux, inv_deg, ea, etab, T, g_x, relu); break;
   }
   STEMGNN_LAUNCH_CHECK();
   return STEMGNN_OK;
@@ -319,9 +330,9 @@ using namespace stemgnn;
 
 extern "C" {
 
-int stemgnn_sage_agg_fwd(const float* x, int64_t N, int64_t D, const int32_t* rowptr, const int32_t* src,
-                         const int32_t* eid, const float* edge_attr, const float* etab, const int32_t* etype_slot,
-                         int64_t T, float* agg, void* stream_) {
+static int sage_agg_fwd_impl(const float* x, int64_t N, int64_t D, const int32_t* rowptr, const int32_t* src,
+                             const int32_t* eid, const float* edge_attr, const float* etab,
+                             const int32_t* etype_slot, int64_t T, float* agg, int relu, void* stream_) {
   hipStream_t st = static_cast<hipStream_t>(stream_);
   Geometry geo;
   if (N < 0 || !pick_geometry(D, &geo)) return STEMGNN_ERR_INVALID_ARG;
@@ -331,10 +342,22 @@ int stemgnn_sage_agg_fwd(const float* x, int64_t N, int64_t D, const int32_t* ro
   int mode; const int32_t* aux; size_t lds;
   int rc = resolve_mode(edge_attr, etab, etype_slot, eid, T, D, &mode, &aux, &lds);
   if (rc != STEMGNN_OK) return rc;
-  const int groups = kBlock / geo.G;
-  dim3 grid(static_cast<unsigned>((N + groups - 1) / groups));
+  const int rows_per_block = (kBlock / geo.G) * kRowsPerGroup;
+  dim3 grid(static_cast<unsigned>((N + rows_per_block - 1) / rows_per_block));
   const int Di = static_cast<int>(D);
-  STEMGNN_GEOM_DISPATCH(launch_fwd_mode, mode, lds, grid, st, x, N, Di, rowptr, src, aux, edge_attr, etab, T, agg);
+  STEMGNN_GEOM_DISPATCH(launch_fwd_mode, mode, lds, grid, st, x, N, Di, rowptr, src, aux, edge_attr, etab, T, agg,
+                        relu);
+}
+
+int stemgnn_sage_agg_fwd(const float* x, int64_t N, int64_t D, const int32_t* rowptr, const int32_t* src,
+                         const int32_t* eid, const float* edge_attr, const float* etab, const int32_t* etype_slot,
+                         int64_t T, float* agg, void* stream_) {
+  return sage_agg_fwd_impl(x, N, D, rowptr, src, eid, edge_attr, etab, etype_slot, T, agg, 1, stream_);
+}
+
+int stemgnn_mean_agg_fwd(const float* x, int64_t N, int64_t D, const int32_t* rowptr, const int32_t* src, float* agg,
+                         void* stream_) {
+  return sage_agg_fwd_impl(x, N, D, rowptr, src, nullptr, nullptr, nullptr, nullptr, 0, agg, 0, stream_);
 }
 
 int stemgnn_profile_k1(int enable) {
@@ -363,9 +386,10 @@ int stemgnn_profile_k1_collect(double* total_ms_host, int64_t* launches_host) {
   return STEMGNN_OK;
 }
 
-int stemgnn_sage_agg_bwd(const float* g_agg, const float* x, int64_t N, int64_t D, const int32_t* rowptr_t,
-                         const int32_t* dst_t, const int32_t* eid_t, const float* inv_deg, const float* edge_attr,
-                         const float* etab, const int32_t* etype_slot_t, int64_t T, float* g_x, void* stream_) {
+static int sage_agg_bwd_impl(const float* g_agg, const float* x, int64_t N, int64_t D, const int32_t* rowptr_t,
+                             const int32_t* dst_t, const int32_t* eid_t, const float* inv_deg,
+                             const float* edge_attr, const float* etab, const int32_t* etype_slot_t, int64_t T,
+                             float* g_x, int relu, void* stream_) {
   hipStream_t st = static_cast<hipStream_t>(stream_);
   Geometry geo;
   if (N < 0 || !pick_geometry(D, &geo)) return STEMGNN_ERR_INVALID_ARG;
@@ -379,7 +403,21 @@ int stemgnn_sage_agg_bwd(const float* g_agg, const float* x, int64_t N, int64_t 
   dim3 grid(static_cast<unsigned>((N + groups - 1) / groups));
   const int Di = static_cast<int>(D);
   STEMGNN_GEOM_DISPATCH(launch_bwd_mode, mode, lds, grid, st, g_agg, x, N, Di, rowptr_t, dst_t, aux, inv_deg,
-                        edge_attr, etab, T, g_x);
+                        edge_attr, etab, T, g_x, relu);
+}
+
+int stemgnn_sage_agg_bwd(const float* g_agg, const float* x, int64_t N, int64_t D, const int32_t* rowptr_t,
+                         const int32_t* dst_t, const int32_t* eid_t, const float* inv_deg, const float* edge_attr,
+                         const float* etab, const int32_t* etype_slot_t, int64_t T, float* g_x, void* stream_) {
+  return sage_agg_bwd_impl(g_agg, x, N, D, rowptr_t, dst_t, eid_t, inv_deg, edge_attr, etab, etype_slot_t, T, g_x, 1,
+                           stream_);
+}
+
+int stemgnn_mean_agg_bwd(const float* g_agg, int64_t N, int64_t D, const int32_t* rowptr_t, const int32_t* dst_t,
+                         const float* inv_deg, float* g_x, void* stream_) {
+  // the relu mask is not evaluated: x is only dereferenced for rows with out-edges, any valid [N, D] buffer serves
+  return sage_agg_bwd_impl(g_agg, g_agg, N, D, rowptr_t, dst_t, nullptr, inv_deg, nullptr, nullptr, nullptr, 0, g_x, 0,
+                           stream_);
 }
 
 }  // extern "C"

@@ -137,9 +137,8 @@ class MixtureSageLayer(nn.Module):
     def forward(self, x: Tensor, edge_index, edge_attr: EdgeAttr = None) -> Tensor:
         ei = edge_index.edge_index if isinstance(edge_index, GraphStructure) else edge_index
         flipped = _flipped_graph(ei, x.size(0))
-        # scatter_mean(x[col], row) == mean aggregation of relu-free messages over the flipped graph;
-        # x >= 0 is not guaranteed, so the relu-free form is obtained as mean(relu(x)) - mean(relu(-x)).
-        agg = ops.SageAggFn.apply(x, flipped, None, None) - ops.SageAggFn.apply(-x, flipped, None, None)
+        # scatter_mean(x[col], row) == plain mean aggregation over the flipped graph
+        agg = ops.MeanAggFn.apply(x, flipped)
         combined = torch.cat([agg, x], dim=-1)
         outputs = torch.einsum("nd,kdo->nko", combined, self.weights)
         if self.residual:

@@ -248,6 +248,34 @@ class SageAggFn(torch.autograd.Function):
         return g_x, None, None, None
 
 
+class MeanAggFn(torch.autograd.Function):
+    """agg[i] = mean_{j -> i} x_j without edge term or relu: scatter_mean(x[col], row) of
+    MixtureSageLayer (reference model/encoder.py:124) on the CSR of the flipped graph."""
+
+    @staticmethod
+    def forward(ctx, x, graph):
+        x = x.contiguous()
+        _req(x, torch.float32, "x", 2)
+        N, D = x.shape
+        if N != graph.num_nodes:
+            raise RuntimeError("x / graph size mismatch")
+        agg = torch.empty_like(x)
+        check(lib.stemgnn_mean_agg_fwd(_p(x), N, D, _p(graph.rowptr), _p(graph.src), _p(agg), _stream()), "mean_agg_fwd")
+        ctx.graph = graph
+        return agg
+
+    @staticmethod
+    def backward(ctx, g_agg):
+        g = ctx.graph
+        g.ensure_transpose()
+        g_agg = g_agg.contiguous()
+        N, D = g_agg.shape
+        g_x = torch.empty_like(g_agg)
+        check(lib.stemgnn_mean_agg_bwd(_p(g_agg), N, D, _p(g.rowptr_t), _p(g.dst_t), _p(g.inv_deg), _p(g_x), _stream()),
+              "mean_agg_bwd")
+        return g_x, None
+
+
 # ----------------------------------------------------------------------------------------
 # K4
 # ----------------------------------------------------------------------------------------
@@ -344,7 +372,7 @@ def linear_fwd(x1: Tensor, w1: Tensor, x2: Optional[Tensor], w2: Optional[Tensor
         _req(bias, torch.float32, "bias", 1)
     y = torch.empty(M, N, dtype=torch.float32, device=x1.device)
     partial = None
-    blocks = (M + 127) // 128
+    blocks = int(lib.stemgnn_linear_stats_blocks(M, K1 + K2))
     if want_stats:
         partial = torch.empty(max(blocks, 1), 2, N, dtype=torch.float32, device=x1.device)
     check(lib.stemgnn_linear_fwd(_p(x1), _p(w1), K1, _p(x2), _p(w2), K2, _p(bias), M, N, _p(y), _p(partial), None,

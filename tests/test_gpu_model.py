@@ -237,3 +237,29 @@ def test_pretrain_steps_loss_parity(dev):
             # rounding noise, which Adam's normalisation turns into +-lr steps on both sides
             continue
         torch.testing.assert_close(p2.detach().cpu(), p1.detach(), rtol=2e-3, atol=2e-4, msg=lambda m: f"{n1}: {m}")
+
+
+def test_moe_encoder_vs_oracle(dev):
+    """--moe --moe_layers all (reference encoder.py:109-129,292-309): reversed-direction plain
+    mean aggregation + K-expert einsum + softmax routing; eval mode (no Gumbel noise) and the
+    mixture layer alone in train mode with gradients."""
+    from stem_gnn_amd.model.encoder import Encoder, MixtureSageLayer
+    N, E, D = 300, 2500, 32
+    torch.manual_seed(2)
+    oe = O.OracleEncoder(D, D, 2, normalize="batch", dropout=0.0, moe=True, num_experts=3, moe_layers="all")
+    ge = Encoder(D, D, nn.ReLU, 2, normalize="batch", dropout=0.0, moe=True, num_experts=3, moe_layers="all")
+    ge.load_state_dict(oe.state_dict())
+    ge = ge.to(dev)
+    x = torch.randn(N, D)
+    ei = torch.randint(0, N, (2, E))
+    oe.eval(); ge.eval()
+    with torch.no_grad():
+        torch.testing.assert_close(ge(x.to(dev), ei.to(dev)).cpu(), oe(x, ei), rtol=1e-4, atol=1e-4)
+    ol, gl = oe.layers[0], ge.layers[0]
+    xr = x.clone().requires_grad_(True)
+    xg = x.to(dev).requires_grad_(True)
+    w = torch.randn(N, 3, D)
+    (ol(xr, ei) * w).sum().backward()
+    (gl(xg, ei.to(dev)) * w.to(dev)).sum().backward()
+    torch.testing.assert_close(xg.grad.cpu(), xr.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(gl.weights.grad.cpu(), ol.weights.grad, rtol=1e-4, atol=1e-3)
