@@ -92,6 +92,26 @@ int stemgnn_graph_dropout_undirected(const int32_t* rowptr, const int32_t* src, 
 int stemgnn_negative_sample(const int32_t* rowptr, const int32_t* src, const int32_t* eid, const uint8_t* selected,
                             int64_t num_nodes, int64_t k, uint64_t seed, uint64_t offset, int64_t* out, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Mini-batch neighbour sampler (replaces NeighborLoader(num_neighbors=[f]*L) on the host,
+ * reference pretrain.py:151-153).  The full graph is given by its by-target CSR (int32, resident
+ * in HBM; etype = edge type per CSR slot, may be NULL); `local_of` [num_nodes] is a persistent
+ * scratch map initialised once by stemgnn_sampler_init_map and left clean by every call.
+ * Per hop each newly reached node draws min(deg, fanout) in-neighbours uniformly without
+ * replacement (Philox keyed by seed/offset); seeds come first in the local numbering, then new
+ * nodes hop by hop in order of first appearance.  Outputs: n_id [cap_nodes] (global id per
+ * local node), the batch's by-target CSR b_rowptr [cap_nodes+1] / b_src / b_type [cap_edges],
+ * its COO b_coo int64 [2, cap_edges] (row stride cap_edges; edge j == CSR slot j) and
+ * counts[2] = (N_b, E_b) on the device.  cap_nodes >= B(1 + f + .. + f^L), cap_edges >= B(f + .. + f^L).
+ * ------------------------------------------------------------------------------------ */
+int stemgnn_sampler_init_map(int32_t* local_of, int64_t num_nodes, void* stream);
+size_t stemgnn_sampler_workspace_bytes(int64_t batch_size, int64_t hops, int64_t max_fanout);
+int stemgnn_sample_batch(const int32_t* rowptr, const int32_t* src, const int32_t* etype, int64_t num_nodes,
+                         const int64_t* seeds, int64_t batch_size, const int32_t* fanouts_host, int64_t hops,
+                         uint64_t seed, uint64_t offset, int32_t* local_of, int64_t cap_nodes, int64_t cap_edges,
+                         int32_t* n_id, int32_t* b_rowptr, int32_t* b_src, int32_t* b_type, int64_t* b_coo,
+                         int32_t* counts, void* workspace, size_t workspace_bytes, void* stream);
+
 /* out[i] = table[index[i]] for int32 tables (edge-type id per CSR slot = xe[eid[slot]]). */
 int stemgnn_gather_i32(const int32_t* table, const int32_t* index, int64_t n, int32_t* out, void* stream);
 

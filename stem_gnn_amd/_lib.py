@@ -43,6 +43,10 @@ _SIGNATURES = {
     "stemgnn_negative_sample": (c_int, [P, P, P, P, I64, I64, c_uint64, c_uint64, P, P]),
     "stemgnn_edge_bce_loss": (c_int, [P, I64, I64, P, P, P]),
     "stemgnn_edge_dot_bwd_scaled": (c_int, [P, P, P, I64, I64, P, I64, P, P]),
+    "stemgnn_sampler_init_map": (c_int, [P, I64, P]),
+    "stemgnn_sampler_workspace_bytes": (c_size_t, [I64, I64, I64]),
+    "stemgnn_sample_batch": (c_int, [P, P, P, I64, P, I64, P, I64, c_uint64, c_uint64, P, I64, I64, P, P, P, P, P, P, P,
+                                     c_size_t, P]),
     "stemgnn_gather_i32": (c_int, [P, P, I64, P, P]),
     "stemgnn_group_by_key": (c_int, [P, I64, I64, P, P, P, c_size_t, P]),
     "stemgnn_sage_agg_fwd": (c_int, [P, I64, I64, P, P, P, P, P, P, I64, P, P]),

@@ -13,7 +13,7 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kMaxPartialBlocks = 512;
-constexpr int kFinCols = 16;    // finalize: 16 columns x 16 partial slices per 256-thread block
+constexpr int kFinCols = 4;     // finalize: 4 columns x 64 partial slices per 256-thread block
 constexpr int kFinSlices = kBlock / kFinCols;
 
 __device__ inline float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -135,7 +135,7 @@ k_col_partials(const float* __restrict__ y, const float* __restrict__ g_out, int
   }
 }
 
-// Combine block partials in fp64: 16 columns x 16 slices per block, LDS tree over the slices.
+// Combine block partials in fp64: kFinCols columns x kFinSlices slices per block, LDS tree over the slices.
 __device__ inline void reduce_partials(const float* __restrict__ partial, int blocks, int D, int c, int slice,
                                        double* s_out, double* q_out) {
   __shared__ double red_s[kBlock], red_q[kBlock];

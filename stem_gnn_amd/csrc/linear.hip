@@ -185,6 +185,10 @@ k_linear_fwd(const float* __restrict__ x1, const float* __restrict__ w1, int K1,
 //   BM = 128 (K <= 128): waves 4(m) x 2(n), 32x64 per wave;  BM = 64 (K <= 256): 2 x 4, 32x32.
 // ---------------------------------------------------------------------------------------
 constexpr int kResThreads = 512;
+// Measured on MI355X (tools/kbench.py linear, M = 102400): 55-56 us vs 45-47 us (K = 128) and 92 us vs
+// 81 us (K = 256) for the 3-blocks-per-CU tile kernel above, with or without a 3-deep prefetch
+// ring: kept for reference and further tuning, not dispatched.
+constexpr bool kUseResidentVariant = false;
 
 template <int BM, bool STATS>
 __global__ void __launch_bounds__(kResThreads)
@@ -517,7 +521,7 @@ size_t stemgnn_linear_stats_partial_bytes(int64_t M, int64_t N) {
 
 int64_t stemgnn_linear_stats_blocks(int64_t M, int64_t k_total) {
   if (M < 0 || k_total <= 0) return 0;
-  const int64_t rows = k_total <= 256 ? res_block_rows(k_total) : kBM;
+  const int64_t rows = (kUseResidentVariant && k_total <= 256) ? res_block_rows(k_total) : kBM;
   return (M + rows - 1) / rows;
 }
 
@@ -533,7 +537,7 @@ int stemgnn_linear_fwd(const float* x1, const float* w1, int64_t K1, const float
   if (N % 4 != 0) return STEMGNN_ERR_INVALID_ARG;
   const int gy = static_cast<int>((N + kBN - 1) / kBN);
   const int64_t Ktot = K1 + K2;
-  if (Ktot <= 256 && (K2 == 0 || K1 % 4 == 0)) {
+  if (kUseResidentVariant && Ktot <= 256 && (K2 == 0 || K1 % 4 == 0)) {
     // weight-resident persistent variant: one 512-thread block per CU
     const int BM = res_block_rows(Ktot);
     const int64_t tiles = (M + BM - 1) / BM;

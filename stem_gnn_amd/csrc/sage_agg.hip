@@ -66,7 +66,7 @@ k_sage_agg_fwd(const float* __restrict__ x, int64_t N, int D, const int32_t* __r
 
   constexpr int kGroups = kBlock / G;
   constexpr int R = kRowsPerGroup;                  // consecutive destination rows per group
-  constexpr int U = V <= 3 ? 4 : (V == 4 ? 2 : 1);  // neighbour rows in flight per group
+  constexpr int U = V <= 3 ? 4 : (V == 4 ? 2 : 1);  // neighbour rows in flight per group (8 measured slower)
   const int lane = threadIdx.x % G;
   const int group = threadIdx.x / G;
   const int64_t row0 = (static_cast<int64_t>(blockIdx.x) * kGroups + group) * R;

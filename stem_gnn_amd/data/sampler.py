@@ -96,6 +96,36 @@ class NeighborSampler:
                      node_text_feat=self.ntf, edge_text_feat=self.etf)
 
 
+class HipNeighborSampler:
+    """The same contract on the fused HIP sampler (csrc/sampler.hip): the full graph's by-target
+    CSR and edge types stay resident in HBM, a batch is a dozen small launches + one 8-byte
+    device->host copy, and the batch arrives with its by-target CSR already built
+    (``Batch.graph``)."""
+
+    def __init__(self, edge_index: Tensor, xe: Tensor, num_nodes: int, x: Tensor, node_text_feat: Tensor,
+                 edge_text_feat: Tensor, num_neighbors: List[int], seed: int = 0):
+        self.num_nodes = num_nodes
+        self.fanouts = [int(f) for f in num_neighbors]
+        rowptr, src, eid, _ = ops.csr_build(edge_index.contiguous(), num_nodes, 1)
+        self.rowptr, self.src = rowptr, src
+        self.etype = ops.gather_i32(xe.to(torch.int32).contiguous(), eid)
+        self.x, self.ntf, self.etf = x, node_text_feat, edge_text_feat
+        self.local_of = ops.sampler_init_map(num_nodes, edge_index.device)
+        self.seed, self.calls = int(seed), 0
+
+    def sample(self, seeds: Tensor) -> Batch:
+        from ..graph import GraphStructure
+        self.calls += 1
+        n_id, rowptr, src, etype, coo, nb, eb = ops.sample_batch(self.rowptr, self.src, self.etype, self.num_nodes,
+                                                                 seeds.contiguous(), self.fanouts, self.seed,
+                                                                 self.calls * 64, self.local_of)
+        n_id64 = n_id.long()
+        b = Batch(batch_size=seeds.numel(), n_id=n_id64, x=self.x[n_id64], edge_index=coo, xe=etype.long(),
+                  node_text_feat=self.ntf, edge_text_feat=self.etf)
+        b.graph = GraphStructure.from_csr(rowptr, src, coo, nb, etype_slot=etype)
+        return b
+
+
 class NeighborLoader:
     """Iterates shuffled seed batches (one epoch), sharded round-robin across ranks."""
 

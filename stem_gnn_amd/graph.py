@@ -82,6 +82,21 @@ class GraphStructure:
             if bad:
                 raise IndexError(f"edge_index has {bad} entries outside [0, {self.num_nodes})")
 
+    @classmethod
+    def from_csr(cls, rowptr: Tensor, src: Tensor, edge_index: Tensor, num_nodes: int,
+                 etype_slot: Optional[Tensor] = None) -> "GraphStructure":
+        """Adopt a by-target CSR whose slot j IS edge j of `edge_index` (what the HIP sampler emits)."""
+        g = cls(None, num_nodes)
+        g.num_edges = int(src.numel())
+        g._edge_index = edge_index
+        g.rowptr, g.src = rowptr, src
+        g.eid = torch.arange(g.num_edges, dtype=torch.int32, device=src.device)
+        g._bad = None
+        if etype_slot is not None:
+            g._edge_type = etype_slot  # edge j == slot j
+            g.etype_slot = etype_slot
+        return g
+
     @property
     def edge_index(self) -> Tensor:
         """int64 COO [2, E] (row 0 = source, row 1 = target).  For an augmented graph it is

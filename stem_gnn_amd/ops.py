@@ -139,6 +139,40 @@ def negative_sample(g, selected: Tensor, k: int, seed: int, offset: int) -> Tens
     return out
 
 
+def sampler_init_map(num_nodes: int, device) -> Tensor:
+    local_of = torch.empty(num_nodes, dtype=torch.int32, device=device)
+    check(lib.stemgnn_sampler_init_map(_p(local_of), num_nodes, _stream()), "sampler_init_map")
+    return local_of
+
+
+def sample_batch(rowptr: Tensor, src: Tensor, etype: Optional[Tensor], num_nodes: int, seeds: Tensor, fanouts,
+                 seed: int, offset: int, local_of: Tensor):
+    """One neighbour-sampled mini-batch on the device -> (n_id, b_rowptr, b_src, b_type, coo, N_b, E_b).
+    One 8-byte device->host copy per batch (the two counts)."""
+    import ctypes
+    _req(seeds, torch.int64, "seeds", 1)
+    B, L, dev = seeds.numel(), len(fanouts), seeds.device
+    level, cap_nodes, cap_edges = B, B, 0
+    for f in fanouts:
+        level *= int(f)
+        cap_nodes += level
+        cap_edges += level
+    i32 = dict(dtype=torch.int32, device=dev)
+    n_id = torch.empty(cap_nodes, **i32)
+    b_rowptr = torch.empty(cap_nodes + 1, **i32)
+    b_src = torch.empty(cap_edges, **i32)
+    b_type = torch.empty(cap_edges, **i32)
+    coo = torch.empty(2, cap_edges, dtype=torch.int64, device=dev)
+    counts = torch.empty(2, **i32)
+    ws = _workspace(lib.stemgnn_sampler_workspace_bytes(B, L, max(fanouts)), dev)
+    fan = (ctypes.c_int32 * L)(*[int(f) for f in fanouts])
+    check(lib.stemgnn_sample_batch(_p(rowptr), _p(src), _p(etype), num_nodes, _p(seeds), B, fan, L, seed, offset,
+                                   _p(local_of), cap_nodes, cap_edges, _p(n_id), _p(b_rowptr), _p(b_src), _p(b_type),
+                                   _p(coo), _p(counts), _p(ws), ws.numel(), _stream()), "sample_batch")
+    nb, eb = counts.tolist()
+    return n_id[:nb], b_rowptr[:nb + 1], b_src[:eb], b_type[:eb], coo[:, :eb].contiguous(), nb, eb
+
+
 def inv_degree(rowptr: Tensor) -> Tensor:
     _req(rowptr, torch.int32, "rowptr", 1)
     n = rowptr.numel() - 1

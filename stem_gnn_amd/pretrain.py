@@ -61,7 +61,9 @@ def build_model(params: Dict, device) -> PretrainModel:
 
 def build_optimizer(model: nn.Module, params: Dict):
     """reference pretrain.py:134-136: AdamW over ALL parameters (sem_encoder's never get grads)."""
-    opt = AdamW(model.parameters(), lr=params["pretrain_lr"], weight_decay=params["pretrain_weight_decay"])
+    # same update rule as the reference's AdamW; `fused=True` only changes how many kernels apply it
+    kw = {"fused": True} if next(model.parameters()).is_cuda else {}
+    opt = AdamW(model.parameters(), lr=params["pretrain_lr"], weight_decay=params["pretrain_weight_decay"], **kw)
     sched = get_scheduler(opt, params["use_schedular"], params["pretrain_epochs"])
     return opt, sched
 
