@@ -263,3 +263,44 @@ def test_moe_encoder_vs_oracle(dev):
     (gl(xg, ei.to(dev)) * w.to(dev)).sum().backward()
     torch.testing.assert_close(xg.grad.cpu(), xr.grad, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(gl.weights.grad.cpu(), ol.weights.grad, rtol=1e-4, atol=1e-3)
+
+
+def test_finetune_consumer_flow(dev):
+    """The downstream contract of reference finetune.py:131-181 / utils/others.py:160-171 /
+    model/ft_model.py:90-103: VectorQuantize(kmeans_init=True) -> dummy forward on randn(100, dim)
+    flips `initted` -> load_state_dict of a pretrained vq -> frozen, eval-free use inside
+    TaskModel.get_lin_logits (decoder over the per-head codes)."""
+    from stem_gnn_amd.model.vq import VectorQuantize
+    D, H, K = 64, 4, 32
+    torch.manual_seed(3)
+    ovq = O.OracleVectorQuantize(D, K, D, H, commitment_weight=10.0, orthogonal_reg_weight=1.0,
+                                 orthogonal_reg_max_codes=32, ema_update=False)
+    pretrained = ovq.state_dict()
+    vq = VectorQuantize(dim=D, codebook_size=K, codebook_dim=D, heads=H, separate_codebook_per_head=True, decay=0.8,
+                        commitment_weight=10, use_cosine_sim=True, orthogonal_reg_weight=1, orthogonal_reg_max_codes=32,
+                        kmeans_init=True, ema_update=False).to(dev)
+    assert float(vq._codebook.initted) == 0.0
+    vq(torch.randn(100, D, device=dev))            # others.py:168-169: k-means init on a dummy batch
+    assert float(vq._codebook.initted) == 1.0 and bool(torch.isfinite(vq._codebook.embed).all())
+    vq.load_state_dict(pretrained)                  # others.py:170
+    for p in vq.parameters():                       # finetune.py:179-181 freeze_params
+        p.requires_grad_(False)
+    z = torch.randn(300, D)
+    zg = z.to(dev).requires_grad_(True)
+    vq.train()                                      # TaskModel trains with the frozen vq in train mode
+    q, ind, loss, codes = vq(zg)
+    ovq.train()
+    qr, ir, lr, cr = ovq(z, ortho_ids=torch.arange(K))
+    with torch.no_grad():
+        x = torch.nn.functional.normalize(ovq.project_in(z).view(300, H, D), dim=-1)
+        top2 = torch.einsum("nhd,hcd->nhc", x, ovq._codebook.embed).topk(2, dim=-1).values
+    flips = assert_indices_match(ind.cpu(), ir, top2[..., 0] - top2[..., 1])
+    assert tuple(codes.shape) == (300, H * D)       # ft_model.py:94: decoder(codes).reshape(-1, H, C)
+    if flips == 0:
+        torch.testing.assert_close(codes.detach().cpu(), cr.detach(), rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(q.detach().cpu(), qr.detach(), rtol=1e-4, atol=1e-5)
+    head = nn.Linear(H * D, H * 7).to(dev)
+    logits = head(codes).reshape(-1, H, 7).mean(1)
+    torch.nn.functional.cross_entropy(logits, torch.randint(0, 7, (300,), device=dev)).backward()
+    assert zg.grad is not None and bool(torch.isfinite(zg.grad).all())
+    assert tuple(vq.codebook.shape) == (H, K, D)
