@@ -197,6 +197,11 @@ def main():
         achieved = k1_bytes / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
         peak = 8000.0  # MI355X HBM3E spec, GB/s (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
         nb = batches[args.warmup]
+        traffic = None  # HBM bytes per K1 launch from a separate rocprofv3 --pmc pass on this workload (profiles/)
+        tpath = os.path.join(ROOT, "profiles", "k1_traffic.json")
+        if args.workload == "c4" and args.batch_size == 1024 and os.path.exists(tpath):
+            with open(tpath) as fh:
+                traffic = json.load(fh).get("traffic_bytes_per_launch")
         out = {
             "metric": "pretrain edges/sec (fwd+bwd) on 1M-node/20M-edge synthetic graph, 1/2/4/8 GPUs",
             "value": edges / dt, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -210,7 +215,7 @@ def main():
                        "loader_ms_per_batch_outside_timed_region": round(sampler_ms, 3)},
             "roofline": {"bound": "hbm", "kernel": "k_sage_agg_fwd (K1, type-indexed edge attr)",
                          "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
-                         "traffic": None, "launches": k1_launches,
+                         "traffic": traffic, "launches": k1_launches,
                          "avg_launch_us": (k1_ms * 1e3 / k1_launches) if k1_launches else None,
                          "algorithmic_bytes_per_launch": (k1_bytes / k1_launches) if k1_launches else None},
         }
