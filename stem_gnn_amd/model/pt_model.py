@@ -8,6 +8,7 @@ step through the CPU oracle.  They can also be injected through ``draws=``.
 """
 from __future__ import annotations
 
+import os
 from copy import deepcopy
 from typing import Dict, Optional
 
@@ -54,6 +55,8 @@ class PretrainModel(nn.Module):
         self.topo_sem_recon_decoder = topo_sem_recon_decoder
         self.sem_encoder = deepcopy(self.encoder)  # pt_model.py:22
         self.sem_projector = nn.Linear(self.encoder.hidden_dim, self.encoder.hidden_dim)
+        self.teacher_side_stream = os.environ.get("STEMGNN_TEACHER_STREAM", "0") == "1"  # measured: no gain, K1 slower when overlapped
+        self._side_stream = None
         self._flat_student: Optional[Tensor] = None
         self._flat_teacher: Optional[Tensor] = None
         self.last_draws: Dict[str, Tensor] = {}
@@ -145,10 +148,28 @@ class PretrainModel(nn.Module):
         zz = ops.EdgeConcatFn.apply(z, edge_index.contiguous())  # cat([z[u], z[v]]), pt_model.py:80
         return F.mse_loss(self._lin(self.topo_sem_recon_decoder, zz), target)
 
-    def sem_recon_loss(self, g, quantize, eta=1.0, bs=None):
+    def _teacher_forward(self, g):
+        """sem_encoder(orig graph).detach() (pt_model.py:93).  Independent of the student until the
+        cosine term, so it is issued on a side HIP stream and overlaps the student / VQ kernels."""
         orig_x, orig_edge_index, orig_edge_attr = g[0], g[1], g[2]
-        with torch.no_grad():  # .detach() in the reference (pt_model.py:93); teacher stays in train mode
+        if not (self.teacher_side_stream and orig_x.is_cuda):
+            with torch.no_grad():
+                return self.sem_encoder(orig_x, orig_edge_index, orig_edge_attr), None
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=orig_x.device)
+        cur = torch.cuda.current_stream(orig_x.device)
+        self._side_stream.wait_stream(cur)
+        with torch.cuda.stream(self._side_stream), torch.no_grad():
             z = self.sem_encoder(orig_x, orig_edge_index, orig_edge_attr)
+        return z, self._side_stream
+
+    def sem_recon_loss(self, g, quantize, eta=1.0, bs=None, teacher=None):
+        if teacher is None:
+            teacher = self._teacher_forward(g)
+        z, side = teacher
+        if side is not None:
+            torch.cuda.current_stream(z.device).wait_stream(side)
+            z.record_stream(torch.cuda.current_stream(z.device))
         # the projector is row-wise and only rows [:bs] are used (pt_model.py:94-97): project those rows only
         h = self._lin(self.sem_projector, quantize[:bs])
         z = F.normalize(z[:bs], dim=-1, p=2)
@@ -184,6 +205,7 @@ class PretrainModel(nn.Module):
         x, edge_index, edge_attr = aug_g[0], aug_g[1], aug_g[2]
         orig_x, orig_edge_index, orig_edge_attr = g[0], g[1], g[2]
         self.last_draws = {}
+        teacher = self._teacher_forward(g) if self.teacher_side_stream else None  # optional side-stream overlap
         z, quantize, indices, commit_loss = self.quantize(x, edge_index, edge_attr)
         env_reg_loss = self.encoder.get_env_reg()
         if no_codebook:
@@ -195,7 +217,7 @@ class PretrainModel(nn.Module):
         topo_recon_loss = self.topo_recon_loss(query, orig_edge_index, ratio=topo_recon_ratio, draws=draws)
         topo_sem_recon_loss = self.topo_sem_recon_loss(query, orig_edge_index, orig_edge_attr,
                                                        ratio=topo_recon_ratio, draws=draws)
-        sem_recon_loss = self.sem_recon_loss(g, query, eta=1.0, bs=bs)
+        sem_recon_loss = self.sem_recon_loss(g, query, eta=1.0, bs=bs, teacher=teacher)
         losses = {
             "feat_recon_loss": feat_recon_loss,
             "topo_recon_loss": topo_recon_loss,
