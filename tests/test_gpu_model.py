@@ -194,6 +194,35 @@ def test_encoder_fwd_bwd_vs_oracle(dev, attr):
         torch.testing.assert_close(ge(x.to(dev), ei.to(dev), ea_gpu).cpu(), oe(x, ei, ea_cpu), rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("D,H,K,attr", [(768, 4, 128, "table"), (96, 2, 40, "dense")])
+def test_pretrain_step_other_widths(dev, D, H, K, attr):
+    """One full step at the reference's default width (config/pretrain.yaml: D = Dc = 768, H = 4,
+    K = 128; Cora-like size) and at a non-power-of-two width with the dense edge_attr API."""
+    from stem_gnn_amd import ops
+    from stem_gnn_amd.graph import EdgeTypeAttr
+    from stem_gnn_amd.pretrain import pretrain_step, default_params
+    N, E, bs = 500, 3000, 128
+    om, gm = make_models(D, 2, H, K, D, dev)
+    params = default_params()
+    torch.manual_seed(5)
+    x = torch.nn.functional.normalize(torch.randn(N, D), dim=-1)
+    half = torch.randint(0, N, (2, E // 2))
+    ei = torch.cat([half, half.flip(0)], dim=1)[:, torch.randperm(E)]
+    table = torch.nn.functional.normalize(torch.randn(5, D), dim=-1)
+    et = torch.randint(0, 5, (E,))
+    opt_o = torch.optim.AdamW(om.parameters(), lr=1e-4, weight_decay=1e-5)
+    opt_g = torch.optim.AdamW(gm.parameters(), lr=1e-4, weight_decay=1e-5)
+    ea_g = EdgeTypeAttr(table.to(dev), et.to(dev)) if attr == "table" else table[et].to(dev)
+    ops.manual_seed(7)
+    loss_g, losses_g, draws = pretrain_step(gm, opt_g, None, params, x.to(dev), ei.to(dev), ea_g, bs)
+    cpu_draws = {k: ([m.cpu() for m in v] if isinstance(v, list) else v.cpu()) for k, v in draws.items()}
+    loss_o, losses_o, _ = O.pretrain_step(om, opt_o, None, params, x, ei, table[et], bs, cpu_draws)
+    for k in losses_o:
+        torch.testing.assert_close(losses_g[k].cpu().reshape(-1), losses_o[k].reshape(-1), rtol=1e-4, atol=1e-5,
+                                   msg=lambda m: f"{k}: {m}")
+    torch.testing.assert_close(loss_g.cpu().reshape(-1), loss_o.reshape(-1), rtol=1e-4, atol=1e-5)
+
+
 def test_pretrain_steps_loss_parity(dev):
     """Several full pretraining steps (augment -> forward -> backward -> clip -> AdamW ->
     scheduler -> EMA teacher): the HIP path's loss curve against the CPU oracle replaying the
