@@ -85,6 +85,16 @@ int stemgnn_graph_dropout_undirected(const int32_t* rowptr, const int32_t* src, 
                                      int32_t* a_dst_t, int32_t* a_eid_t, int32_t* a_etype_slot_t, float* a_inv_deg,
                                      void* workspace, size_t workspace_bytes, void* stream);
 
+/* randperm(n)[:k] as the reference uses it (model/pt_model.py:55-57,75-78, model/vq.py:1024): k
+ * distinct ids of [0, n), the first k outputs of a keyed pseudo-random permutation (Feistel
+ * network + cycle walking); no sort.  out int64 [k]. */
+int stemgnn_sample_subset(int64_t n, int64_t k, uint64_t seed, uint64_t offset, int64_t* out, void* stream);
+
+/* mask_feature(x, p, mode='col') (reference pretrain.py:41): zero the feature columns whose
+ * Philox draw is < p (keep mask = stemgnn_dropout_keep_mask(D, p, seed, offset)). */
+int stemgnn_mask_columns(const float* x, int64_t num_rows, int64_t dim, float p, uint64_t seed, uint64_t offset,
+                         float* out, void* stream);
+
 /* negative_sampling(pos_edge_index, N) (reference model/pt_model.py:60; PyG structured sparse
  * sampling): k pairs (r, c), r != c, uniform over the N(N-1) non-loop pairs, rejecting pairs
  * that are SELECTED positive edges (selected[e] != 0 over the graph's edges, looked up through

@@ -123,6 +123,61 @@ k_negative_sample(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
   out[k + i] = c;
 }
 
+// Uniform k-subset of [0, n) without replacement = the first k outputs of a keyed pseudo-random
+// PERMUTATION of [0, n): a 6-round Feistel network on ceil(log2 n) bits (rounded up to even),
+// cycle-walked back into range (expected < 4 walks).  This is what randperm(n)[:k] is used for at
+// reference model/pt_model.py:55-57,75-78 and model/vq.py:1024, without sorting n keys.
+__device__ inline uint32_t feistel_round_fn(uint32_t v, uint32_t key) {
+  uint32_t x = v * 0x9E3779B1u + key;
+  x ^= x >> 15; x *= 0x85EBCA77u;
+  x ^= x >> 13; x *= 0xC2B2AE3Du;
+  x ^= x >> 16;
+  return x;
+}
+
+__global__ void __launch_bounds__(kThreads)
+k_sample_subset(int64_t n, int64_t k, int half_bits, uint64_t seed, uint64_t offset, int64_t* __restrict__ out) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+  if (i >= k) return;
+  uint32_t keys[8];
+  Philox::gen(seed, offset, 0, *reinterpret_cast<uint32_t(*)[4]>(&keys[0]));
+  Philox::gen(seed, offset, 1, *reinterpret_cast<uint32_t(*)[4]>(&keys[4]));
+  const uint64_t mask = (1ull << half_bits) - 1;
+  uint64_t x = static_cast<uint64_t>(i);
+  do {
+    uint64_t l = x >> half_bits, r = x & mask;
+#pragma unroll
+    for (int rd = 0; rd < 6; ++rd) {
+      const uint64_t nl = r;
+      r = l ^ (feistel_round_fn(static_cast<uint32_t>(r), keys[rd]) & mask);
+      l = nl;
+    }
+    x = (l << half_bits) | r;
+  } while (x >= static_cast<uint64_t>(n));
+  out[i] = static_cast<int64_t>(x);
+}
+
+// mask_feature(x, p, mode='col') (reference pretrain.py:41): out = x with column c zeroed when
+// philox(seed, offset)[c] < p  (the keep mask of stemgnn_dropout_keep_mask(D, p, seed, offset)).
+__global__ void __launch_bounds__(kThreads)
+k_mask_columns(const float* __restrict__ x, int64_t N, int D, float p, uint64_t seed, uint64_t offset,
+               float* __restrict__ out) {
+  const int nvec = D / 4;
+  const int64_t total = N * nvec;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < total;
+       i += static_cast<int64_t>(gridDim.x) * kThreads) {
+    const int c = static_cast<int>(i % nvec);
+    uint32_t r[4];
+    Philox::gen(seed, offset, static_cast<uint64_t>(c), r);
+    float4 v = *reinterpret_cast<const float4*>(x + 4 * i);
+    if (Philox::to_unit(r[0]) < p) v.x = 0.f;
+    if (Philox::to_unit(r[1]) < p) v.y = 0.f;
+    if (Philox::to_unit(r[2]) < p) v.z = 0.f;
+    if (Philox::to_unit(r[3]) < p) v.w = 0.f;
+    *reinterpret_cast<float4*>(out + 4 * i) = v;
+  }
+}
+
 }  // namespace
 }  // namespace stemgnn
 
@@ -181,6 +236,32 @@ int stemgnn_graph_dropout_undirected(const int32_t* rowptr, const int32_t* src, 
                                         offset, keep, cnt_a, deg, a_rowptr, a_src, a_eid,
                                         etype_slot ? a_etype_slot : nullptr, a_dst_t, a_eid_t,
                                         etype_slot ? a_etype_slot_t : nullptr, a_inv_deg);
+  STEMGNN_LAUNCH_CHECK();
+  return STEMGNN_OK;
+}
+
+int stemgnn_sample_subset(int64_t n, int64_t k, uint64_t seed, uint64_t offset, int64_t* out, void* stream_) {
+  if (n < 0 || k < 0 || k > n) return STEMGNN_ERR_INVALID_ARG;
+  if (k == 0) return STEMGNN_OK;
+  if (!out || n >= (1ll << 60)) return STEMGNN_ERR_INVALID_ARG;
+  int bits = 2;
+  while ((1ll << bits) < n) ++bits;
+  if (bits & 1) ++bits;
+  k_sample_subset<<<static_cast<unsigned>((k + kThreads - 1) / kThreads), kThreads, 0,
+                    static_cast<hipStream_t>(stream_)>>>(n, k, bits / 2, seed, offset, out);
+  STEMGNN_LAUNCH_CHECK();
+  return STEMGNN_OK;
+}
+
+int stemgnn_mask_columns(const float* x, int64_t N, int64_t D, float p, uint64_t seed, uint64_t offset, float* out,
+                         void* stream_) {
+  if (N < 0 || D <= 0 || D % 4 != 0 || p < 0.f || p > 1.f) return STEMGNN_ERR_INVALID_ARG;
+  if (N == 0) return STEMGNN_OK;
+  if (!x || !out) return STEMGNN_ERR_INVALID_ARG;
+  int64_t g = (N * (D / 4) + kThreads - 1) / kThreads;
+  if (g > 4096) g = 4096;
+  k_mask_columns<<<static_cast<unsigned>(g), kThreads, 0, static_cast<hipStream_t>(stream_)>>>(
+      x, N, static_cast<int>(D), p, seed, offset, out);
   STEMGNN_LAUNCH_CHECK();
   return STEMGNN_OK;
 }

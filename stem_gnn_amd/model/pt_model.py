@@ -93,10 +93,10 @@ class PretrainModel(nn.Module):
         if draws is not None and key in draws:
             perm = draws[key]
         else:
-            # a uniformly random k-subset (what randperm(E)[:k] is), drawn as the k largest of E
-            # uniform keys: a radix select instead of a full sort of E keys
+            # a random k-subset (what randperm(E)[:k] is): first k outputs of a keyed pseudo-random
+            # permutation of [0, E) -- one kernel instead of a sort of E keys
             k = max(int(num_edges * ratio), 1)
-            perm = torch.topk(torch.rand(num_edges, device=device), k, sorted=False).indices
+            perm = ops.sample_subset(num_edges, k, device)
         self.last_draws[key] = perm
         return perm
 

@@ -199,6 +199,13 @@ class VectorQuantize(nn.Module):
         return self.project_out(self.get_codes_from_indices(indices))
 
     @staticmethod
+    def _rand_code_ids(num_codes, k, device):
+        """torch.randperm(num_codes, device)[:k] (vq.py:1024): k distinct code ids."""
+        if device.type == "cuda":
+            return ops.sample_subset(num_codes, k, device)
+        return torch.randperm(num_codes, device=device)[:k]
+
+    @staticmethod
     def _project(lin, t):
         return ops.linear(t, lin) if isinstance(lin, nn.Linear) else lin(t)
 
@@ -228,7 +235,7 @@ class VectorQuantize(nn.Module):
                 codebook = cb.embed
                 num_codes = codebook.shape[-2]
                 if self.orthogonal_reg_max_codes is not None and num_codes > self.orthogonal_reg_max_codes:
-                    rand_ids = torch.randperm(num_codes, device=x.device)[: self.orthogonal_reg_max_codes]
+                    rand_ids = self._rand_code_ids(num_codes, self.orthogonal_reg_max_codes, x.device)
                     self.last_ortho_ids = rand_ids
                     codebook = codebook[:, rand_ids]
                 else:

@@ -130,6 +130,25 @@ def graph_dropout_undirected(g, p: float, seed: int, offset: int, keep: Optional
     return a_rowptr, a_src, a_eid, a_type, a_dst_t, a_eid_t, a_type_t, inv_deg
 
 
+def sample_subset(n: int, k: int, device, key=None) -> Tensor:
+    """k distinct ids of [0, n) (what randperm(n)[:k] is used for), one kernel, no sort."""
+    seed, offset = key if key is not None else next_dropout_key()
+    out = torch.empty(k, dtype=torch.int64, device=device)
+    check(lib.stemgnn_sample_subset(n, k, seed, offset, _p(out), _stream()), "sample_subset")
+    return out
+
+
+def mask_columns(x: Tensor, p: float, key=None):
+    """mask_feature(x, p, mode='col'): -> (masked copy, (seed, offset)); keep mask =
+    dropout_keep_mask(D, p, seed, offset)."""
+    _req(x, torch.float32, "x", 2)
+    seed, offset = key if key is not None else next_dropout_key()
+    out = torch.empty_like(x)
+    check(lib.stemgnn_mask_columns(_p(x), x.size(0), x.size(1), float(p), seed, offset, _p(out), _stream()),
+          "mask_columns")
+    return out, (seed, offset)
+
+
 def negative_sample(g, selected: Tensor, k: int, seed: int, offset: int) -> Tensor:
     """k negative pairs for the positives flagged in `selected` (uint8 per edge of graph g)."""
     _req(selected, torch.uint8, "selected", 1)

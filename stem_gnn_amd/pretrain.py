@@ -92,7 +92,12 @@ def pretrain_step(model: PretrainModel, optimizer, scheduler, params: Dict, x, e
     if etype is not None:
         g.ensure_transpose()
     graph = [x, g, edge_attr]
-    aug_x, fmask = mask_feature(x, p=params["feat_p"], keep=draws_in.get("feat_keep"))  # pretrain.py:41
+    if "feat_keep" in draws_in or params["feat_p"] <= 0:
+        aug_x, fmask = mask_feature(x, p=params["feat_p"], keep=draws_in.get("feat_keep"))  # pretrain.py:41
+        fkey = None
+    else:
+        aug_x, fkey = ops.mask_columns(x, params["feat_p"])  # mask_feature(mode='col'), one kernel
+        fmask = None
     # dropout_adj(..., force_undirected=True) (pretrain.py:42-44) straight from the CSR views: no COO
     # round trip, no re-sort, no host sync; the augmented slots address the ORIGINAL edge attributes
     g_aug = g.dropout_undirected(params["edge_p"], keep=draws_in.get("edge_keep"))
@@ -117,7 +122,11 @@ def pretrain_step(model: PretrainModel, optimizer, scheduler, params: Dict, x, e
     if record_draws:
         n, d = x.shape
         out_draws = dict(model.last_draws)
-        out_draws["feat_keep"] = fmask.view(-1) if params["feat_p"] > 0 else torch.ones(d, dtype=torch.bool, device=x.device)
+        if fkey is not None:
+            out_draws["feat_keep"] = ops.dropout_keep_mask(d, params["feat_p"], *fkey, x.device)
+        else:
+            out_draws["feat_keep"] = (fmask.view(-1) if params["feat_p"] > 0
+                                      else torch.ones(d, dtype=torch.bool, device=x.device))
         out_draws["edge_keep"] = (draws_in["edge_keep"] if "edge_keep" in draws_in else
                                   ops.dropout_keep_mask(g.num_edges, params["edge_p"], *g_aug.keep_key, x.device))
         p = params["dropout"]

@@ -366,3 +366,33 @@ def test_neighbor_sampler_contract(dev, impl):
         exp = {u: reps * fan[0] * m / deg for u, m in nbrs.items()}
         chi2 = sum((hits[u] - e) ** 2 / e for u, e in exp.items())
         assert chi2 < 3.0 * len(exp) + 50, (chi2, len(exp))
+
+
+@pytest.mark.parametrize("n,k", [(1, 1), (5, 5), (100, 10), (111897, 11189), (128, 32), (1000003, 1000)])
+def test_sample_subset_is_distinct_in_range_and_spread(dev, n, k):
+    from stem_gnn_amd import ops
+    a = ops.sample_subset(n, k, dev, key=(123, 1)).cpu()
+    assert a.dtype == torch.int64 and a.numel() == k
+    assert int(a.min()) >= 0 and int(a.max()) < n and a.unique().numel() == k  # without replacement
+    assert torch.equal(a, ops.sample_subset(n, k, dev, key=(123, 1)).cpu())   # pure function of the key
+    b = ops.sample_subset(n, k, dev, key=(123, 2)).cpu()
+    if n >= 100 and k < n:
+        assert not torch.equal(a, b)
+    if n == 111897:
+        # inclusion frequency over many keys ~ k/n for every element bucket (uniform subsets)
+        hits = torch.zeros(n)
+        reps = 200
+        for r in range(reps):
+            hits[ops.sample_subset(n, k, dev, key=(7, r)).cpu()] += 1
+        buckets = hits.view(-1)[: (n // 100) * 100].view(100, -1).sum(1)
+        exp = reps * k / n * (n // 100)
+        assert float((buckets - exp).abs().max()) < 6 * exp ** 0.5
+
+
+def test_mask_columns(dev):
+    from stem_gnn_amd import ops
+    x = torch.randn(333, 64)
+    out, key = ops.mask_columns(x.to(dev), 0.3, key=(5, 9))
+    keep = ops.dropout_keep_mask(64, 0.3, *key, dev).cpu()
+    assert 0 < int(keep.sum()) < 64
+    assert torch.equal(out.cpu(), O.mask_feature_col(x, keep))

@@ -50,13 +50,9 @@ def test_vq_matches_reference_golden(dev, path):
     vq.train()
     z = fx["z"].to(dev).requires_grad_(True)
     # replay the reference's randperm draw for the orthogonal loss
-    orig_randperm = torch.randperm
-    try:
-        if K > ortho_max:
-            torch.randperm = lambda n, device=None, **kw: fx["ortho_ids"].to(device) if n == K else orig_randperm(n, device=device, **kw)
-        q, ind, loss, oq = vq(z)
-    finally:
-        torch.randperm = orig_randperm
+    if K > ortho_max:
+        vq._rand_code_ids = lambda n, k, device: fx["ortho_ids"].to(device)
+    q, ind, loss, oq = vq(z)
     assert ind.dtype == torch.int64 and tuple(ind.shape) == tuple(fx["train.embed_ind"].shape)
     flips = assert_indices_match(ind.cpu(), fx["train.embed_ind"], fx["top2_gap"])
     if flips == 0:
@@ -107,13 +103,9 @@ def test_vq_vs_oracle_sizes(dev, N, D, H, K, Dc):
         top2 = sim.topk(2, dim=-1).values
         gap = top2[..., 0] - top2[..., 1]
     zg = z.to(dev).requires_grad_(True)
-    orig_randperm = torch.randperm
-    try:
-        if ids is not None:
-            torch.randperm = lambda n, device=None, **kw: ids.to(device)
-        qg, ig, lg, oqg = vq(zg)
-    finally:
-        torch.randperm = orig_randperm
+    if ids is not None:
+        vq._rand_code_ids = lambda n, k, device: ids.to(device)
+    qg, ig, lg, oqg = vq(zg)
     flips = assert_indices_match(ig.cpu(), ir, gap)
     if flips == 0:
         torch.testing.assert_close(qg.detach().cpu(), qr.detach(), rtol=1e-4, atol=1e-5)
@@ -234,8 +226,9 @@ def test_pretrain_steps_loss_parity(dev):
     N, E, D, L, H, K = 600, 5000, 64, 2, 4, 64
     bs = 200
     om, gm = make_models(D, L, H, K, D, dev)
-    params = default_params()
-    params.update(pretrain_lr=1e-3)
+    params = default_params()  # the reference's lr 1e-4 (config/pretrain.yaml:18).  Adam turns rounding-level gradient
+    # differences on near-zero-gradient elements into +-lr steps, so at a 10x larger lr a single such
+    # element shows up as a transient 1e-4 loss difference (tools/parity_probe.py prints both regimes).
     torch.manual_seed(11)
     x = torch.nn.functional.normalize(torch.randn(N, D), dim=-1)
     half = torch.randint(0, N, (2, E // 2))
@@ -248,7 +241,7 @@ def test_pretrain_steps_loss_parity(dev):
     xg, eig = x.to(dev), ei.to(dev)
     eag = EdgeTypeAttr(table.to(dev), et.to(dev))
     ops.manual_seed(99)
-    for step in range(4):
+    for step in range(6):
         loss_g, losses_g, draws = pretrain_step(gm, opt_g, sch_g, params, xg, eig, eag, bs)
         cpu_draws = {}
         for k, v in draws.items():
@@ -258,14 +251,14 @@ def test_pretrain_steps_loss_parity(dev):
             torch.testing.assert_close(losses_g[k].cpu().reshape(-1), losses_o[k].reshape(-1), rtol=1e-4, atol=1e-5,
                                        msg=lambda m: f"step {step} {k}: {m}")
         torch.testing.assert_close(loss_g.cpu().reshape(-1), loss_o.reshape(-1), rtol=1e-4, atol=1e-5)
-    # parameters after 4 optimiser steps and the EMA teacher
+    # parameters after 6 optimiser steps and the EMA teacher
     for (n1, p1), (n2, p2) in zip(om.named_parameters(), gm.named_parameters()):
         assert n1 == n2
         if n1.endswith("lin_l.bias"):
             # a bias in front of BatchNorm has an exactly-zero true gradient: what reaches AdamW is
             # rounding noise, which Adam's normalisation turns into +-lr steps on both sides
             continue
-        torch.testing.assert_close(p2.detach().cpu(), p1.detach(), rtol=2e-3, atol=2e-4, msg=lambda m: f"{n1}: {m}")
+        torch.testing.assert_close(p2.detach().cpu(), p1.detach(), rtol=1e-4, atol=2e-5, msg=lambda m: f"{n1}: {m}")
 
 
 def test_moe_encoder_vs_oracle(dev):
