@@ -220,10 +220,10 @@ int stemgnn_dropout_keep_mask(int64_t n, float p, uint64_t seed, uint64_t offset
 
 /* y [M, N] = x1 [M, K1] w1[N, K1]^T (+ x2 [M, K2] w2 [N, K2]^T when K2 > 0) + bias [N] (NULL: none).
  * stats_partial (may be NULL): receives per-row-block column sums / sums of squares of y,
- * [stemgnn_linear_stats_blocks(M, k1 + k2)][2][N]; *stats_blocks_host (host pointer, may be NULL)
+ * [stemgnn_linear_stats_blocks(M, N)][2][N]; *stats_blocks_host (host pointer, may be NULL)
  * receives that block count. */
 size_t stemgnn_linear_stats_partial_bytes(int64_t num_rows, int64_t out_dim);
-int64_t stemgnn_linear_stats_blocks(int64_t num_rows, int64_t k_total);
+int64_t stemgnn_linear_stats_blocks(int64_t num_rows, int64_t out_dim);
 int stemgnn_linear_fwd(const float* x1, const float* w1, int64_t k1, const float* x2, const float* w2, int64_t k2,
                        const float* bias, int64_t num_rows, int64_t out_dim, float* y, float* stats_partial,
                        int64_t* stats_blocks_host, void* stream);

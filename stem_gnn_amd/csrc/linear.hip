@@ -43,23 +43,30 @@ __device__ inline int acc_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4
 // ---------------------------------------------------------------------------------------
 // forward: Y = X1 W1^T (+ X2 W2^T) + b
 // ---------------------------------------------------------------------------------------
-template <bool STATS>
+template <int BM, bool STATS>
 __global__ void __launch_bounds__(kBlock, 2)
 k_linear_fwd(const float* __restrict__ x1, const float* __restrict__ w1, int K1, const float* __restrict__ x2,
              const float* __restrict__ w2, int K2, const float* __restrict__ bias, int64_t M, int N,
-             float* __restrict__ y, float* __restrict__ stats_partial /*[gridDim.x][2][N]*/) {
-  __shared__ __attribute__((aligned(16))) float sA[kBM * kLd];
+             float* __restrict__ y, float* __restrict__ stats_partial /*[blocks][2][N]*/, int64_t row_base,
+             int64_t stats_block0) {
+  // BM = 128: waves 2(m) x 2(n), 64x64 per wave.  BM = 32 (tail tiles): waves 1 x 4, 32x32 per wave.
+  constexpr int WM = BM == 128 ? 2 : 1;
+  constexpr int WN = 4 / WM;
+  constexpr int TM = BM / (32 * WM);
+  constexpr int TN = kBN / (32 * WN);
+  constexpr int FA = BM * 8 / kBlock;  // float4 of an activation chunk per thread
+  __shared__ __attribute__((aligned(16))) float sA[BM * kLd];
   __shared__ __attribute__((aligned(16))) float sB[kBN * kLd];
-  __shared__ float s_stats[2][2][kBN];  // [wave_m][sum|sumsq][n]
+  __shared__ float s_stats[WM][2][kBN];  // [wave_m][sum|sumsq][n]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1, hi = lane >> 5, lj = lane & 31;
-  const int64_t m0 = static_cast<int64_t>(blockIdx.x) * kBM;
+  const int wm = wave / WN, wn = wave % WN, hi = lane >> 5, lj = lane & 31;
+  const int64_t m0 = row_base + static_cast<int64_t>(blockIdx.x) * BM;
   const int n0 = blockIdx.y * kBN;
   const int c1 = (K1 + kKC - 1) / kKC, c2 = (K2 + kKC - 1) / kKC;
   const int steps = c1 + c2;
 
-  float4 ra[4], rb[4];
+  float4 ra[FA], rb[4];
   auto fetch = [&](int step) {
     const bool second = step >= c1;
     const float* xs = second ? x2 : x1;
@@ -68,35 +75,37 @@ k_linear_fwd(const float* __restrict__ x1, const float* __restrict__ w1, int K1,
     const int k0 = (second ? step - c1 : step) * kKC;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const int idx = t * kBlock + tid;  // 1024 float4 per operand chunk: row = idx / 8, 16-byte column = idx % 8
+      const int idx = t * kBlock + tid;  // 16-byte column = idx % 8, row = idx / 8
       const int r = idx >> 3, k = k0 + 4 * (idx & 7);
-      const int64_t m = m0 + r;
       const int n = n0 + r;
-      ra[t] = (m < M && k < K) ? ld4(xs + m * K + k) : zero4();
       rb[t] = (n < N && k < K) ? ld4(ws + static_cast<int64_t>(n) * K + k) : zero4();
+      if (t < FA) {
+        const int64_t m = m0 + r;
+        ra[t] = (m < M && k < K) ? ld4(xs + m * K + k) : zero4();
+      }
     }
   };
   auto stash = [&]() {
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int idx = t * kBlock + tid;
-      st4(sA + (idx >> 3) * kLd + 4 * (idx & 7), ra[t]);
       st4(sB + (idx >> 3) * kLd + 4 * (idx & 7), rb[t]);
+      if (t < FA) st4(sA + (idx >> 3) * kLd + 4 * (idx & 7), ra[t]);
     }
   };
 
-  floatx16 acc[2][2];
+  floatx16 acc[TM][TN];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < TM; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < TN; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  float bias_v[2];
+  float bias_v[TN];
 #pragma unroll
-  for (int tn = 0; tn < 2; ++tn) {
-    const int n = n0 + wn * 64 + tn * 32 + lj;
+  for (int tn = 0; tn < TN; ++tn) {
+    const int n = n0 + wn * 32 * TN + tn * 32 + lj;
     bias_v[tn] = (bias != nullptr && n < N) ? bias[n] : 0.f;
   }
 
@@ -108,16 +117,15 @@ k_linear_fwd(const float* __restrict__ x1, const float* __restrict__ w1, int K1,
 #pragma unroll
     for (int ms = 0; ms < kKC / 8; ++ms) {
       const int ko = ms * 8 + hi * 4;  // lane half 0 takes k 0..3, half 1 takes k 4..7 of the micro-step
-      float4 a[2], b[2];
+      float4 a[TM], b[TN];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        a[t] = ld4(sA + (wm * 64 + t * 32 + lj) * kLd + ko);
-        b[t] = ld4(sB + (wn * 64 + t * 32 + lj) * kLd + ko);
-      }
+      for (int t = 0; t < TM; ++t) a[t] = ld4(sA + (wm * 32 * TM + t * 32 + lj) * kLd + ko);
 #pragma unroll
-      for (int tm = 0; tm < 2; ++tm)
+      for (int t = 0; t < TN; ++t) b[t] = ld4(sB + (wn * 32 * TN + t * 32 + lj) * kLd + ko);
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
           acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].x, b[tn].x, acc[tm][tn], 0, 0, 0);
           acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].y, b[tn].y, acc[tm][tn], 0, 0, 0);
           acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].z, b[tn].z, acc[tm][tn], 0, 0, 0);
@@ -130,35 +138,23 @@ k_linear_fwd(const float* __restrict__ x1, const float* __restrict__ w1, int K1,
   // ---- epilogue: bias, store (two 128-byte row segments per store instruction), column stats.
   // The bias was loaded before the main loop: the epilogue issues stores only, so no
   // s_waitcnt vmcnt(0) ever serialises them (vmcnt counts stores too).
-  const bool interior = (m0 + kBM <= M) && (n0 + kBN <= N);
+  const bool interior = (m0 + BM <= M) && (n0 + kBN <= N);
 #pragma unroll
-  for (int tn = 0; tn < 2; ++tn) {
-    const int nl = wn * 64 + tn * 32 + lj;
+  for (int tn = 0; tn < TN; ++tn) {
+    const int nl = wn * 32 * TN + tn * 32 + lj;
     const int n = n0 + nl;
     const float bv = bias_v[tn];
     float s1 = 0.f, s2 = 0.f;
-    if (interior) {
 #pragma unroll
-      for (int tm = 0; tm < 2; ++tm) {
-        float* yp = y + (m0 + wm * 64 + tm * 32 + 4 * hi) * N + n;
+    for (int tm = 0; tm < TM; ++tm) {
+      const int64_t mrow0 = m0 + wm * 32 * TM + tm * 32 + 4 * hi;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float v = acc[tm][tn][r] + bv;
-          yp[static_cast<int64_t>((r & 3) + 8 * (r >> 2)) * N] = v;
+      for (int r = 0; r < 16; ++r) {
+        const int64_t m = mrow0 + (r & 3) + 8 * (r >> 2);
+        const float v = acc[tm][tn][r] + bv;
+        if (interior || (m < M && n < N)) {
+          y[m * N + n] = v;
           if (STATS) { s1 += v; s2 += v * v; }
-        }
-      }
-    } else {
-#pragma unroll
-      for (int tm = 0; tm < 2; ++tm) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int64_t m = m0 + wm * 64 + tm * 32 + acc_row(r, hi);
-          const float v = acc[tm][tn][r] + bv;
-          if (m < M && n < N) {
-            y[m * N + n] = v;
-            if (STATS) { s1 += v; s2 += v * v; }
-          }
         }
       }
     }
@@ -171,191 +167,20 @@ k_linear_fwd(const float* __restrict__ x1, const float* __restrict__ w1, int K1,
   if (STATS) {
     __syncthreads();
     if (tid < kBN && n0 + tid < N) {
-      float* p = stats_partial + static_cast<int64_t>(blockIdx.x) * 2 * N;
-      p[n0 + tid] = s_stats[0][0][tid] + s_stats[1][0][tid];
-      p[N + n0 + tid] = s_stats[0][1][tid] + s_stats[1][1][tid];
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) { t1 += s_stats[w][0][tid]; t2 += s_stats[w][1][tid]; }
+      float* p = stats_partial + (stats_block0 + blockIdx.x) * 2 * N;
+      p[n0 + tid] = t1;
+      p[N + n0 + tid] = t2;
     }
   }
 }
 
-// ---------------------------------------------------------------------------------------
-// forward, weight-resident variant (K1 + K2 <= 256): the 128-column weight tile stays in LDS
-// for the whole life of a PERSISTENT block (one 512-thread block per CU, 2 waves per SIMD),
-// which then only streams activation chunks: BM x 32 floats per step through a double-buffered
-// LDS ring with ONE barrier per step and the next chunk's global loads in flight behind the
-// MFMAs, continuously across row-tile boundaries (no per-tile prologue bubble).
-//   BM = 128 (K <= 128): waves 4(m) x 2(n), 32x64 per wave;  BM = 64 (K <= 256): 2 x 4, 32x32.
-// ---------------------------------------------------------------------------------------
-constexpr int kResThreads = 512;
-// Measured on MI355X (tools/kbench.py linear, M = 102400): 55-56 us vs 45-47 us (K = 128) and 92 us vs
-// 81 us (K = 256) for the 3-blocks-per-CU tile kernel above, with or without a 3-deep prefetch
-// ring: kept for reference and further tuning, not dispatched.
-constexpr bool kUseResidentVariant = false;
-
-template <int BM, bool STATS>
-__global__ void __launch_bounds__(kResThreads)
-k_linear_fwd_res(const float* __restrict__ x1, const float* __restrict__ w1, int K1, const float* __restrict__ x2,
-                 const float* __restrict__ w2, int K2, const float* __restrict__ bias, int64_t M, int N,
-                 float* __restrict__ y, float* __restrict__ stats_partial /*[ceil(M/BM)][2][N]*/) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int WM = BM / 32;          // waves along m (each wave owns 32 rows)
-  constexpr int WN = 8 / WM;           // waves along n
-  constexpr int TN = 4 / WN;           // 32-column accumulator tiles per wave
-  constexpr int FPT = BM * 8 / kResThreads;  // float4 of an activation chunk per thread
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN, hi = lane >> 5, lj = lane & 31;
-  const int Ktot = K1 + K2;
-  const int chunks = (Ktot + kKC - 1) / kKC;
-  const int ldb = chunks * kKC + 4;
-  float* sB = smem;                               // [128][ldb]
-  float* sA = sB + kBN * ldb;                     // [2][BM][kLd]
-  float* s_stats = sA + 2 * BM * kLd;             // [WM][2][128]
-  const int n0 = blockIdx.y * kBN;
-
-  // resident weight tile (zero beyond N and beyond Ktot)
-  {
-    const int vec_per_row = chunks * kKC / 4;
-    for (int idx = tid; idx < kBN * vec_per_row; idx += kResThreads) {
-      const int r = idx / vec_per_row, k = 4 * (idx - r * vec_per_row);
-      const int n = n0 + r;
-      float4 v = zero4();
-      if (n < N && k < Ktot)
-        v = k < K1 ? ld4(w1 + static_cast<int64_t>(n) * K1 + k) : ld4(w2 + static_cast<int64_t>(n) * K2 + (k - K1));
-      st4(sB + r * ldb + k, v);
-    }
-  }
-  float bias_v[TN];
-#pragma unroll
-  for (int tn = 0; tn < TN; ++tn) {
-    const int n = n0 + wn * 32 * TN + tn * 32 + lj;
-    bias_v[tn] = (bias != nullptr && n < N) ? bias[n] : 0.f;
-  }
-
-  const int64_t num_tiles = (M + BM - 1) / BM;
-  const int64_t my_tiles = blockIdx.x < num_tiles ? (num_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
-  const int64_t total = my_tiles * chunks;
-
-  // Register ring three chunks deep: the loads of chunk s+3 are issued while chunk s is being
-  // multiplied, so an HBM round trip has three chunk times to land (a single persistent block
-  // per CU has no other block to hide it behind).
-  auto fetch = [&](int64_t step, float4 (&slot)[FPT]) {
-    const int64_t tile = blockIdx.x + (step / chunks) * gridDim.x;
-    const int k0 = static_cast<int>(step % chunks) * kKC;
-#pragma unroll
-    for (int t = 0; t < FPT; ++t) {
-      const int idx = t * kResThreads + tid;
-      const int r = idx >> 3, k = k0 + 4 * (idx & 7);
-      const int64_t m = tile * BM + r;
-      float4 v = zero4();
-      if (m < M && k < Ktot) v = k < K1 ? ld4(x1 + m * K1 + k) : ld4(x2 + m * K2 + (k - K1));
-      slot[t] = v;
-    }
-  };
-
-  floatx16 acc[TN];
-#pragma unroll
-  for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[tn][r] = 0.f;
-
-  auto body = [&](int64_t step, float4 (&slot)[FPT]) {
-    float* buf = sA + (step & 1) * BM * kLd;
-#pragma unroll
-    for (int t = 0; t < FPT; ++t) {
-      const int idx = t * kResThreads + tid;
-      st4(buf + (idx >> 3) * kLd + 4 * (idx & 7), slot[t]);
-    }
-    __syncthreads();  // the only barrier of the step (also fences the first use of the resident tile)
-    if (step + 3 < total) fetch(step + 3, slot);
-    const int kc = static_cast<int>(step % chunks);
-    const float* bbase = sB + kc * kKC;
-#pragma unroll
-    for (int ms = 0; ms < kKC / 8; ++ms) {
-      const int ko = ms * 8 + hi * 4;
-      const float4 a = ld4(buf + (wm * 32 + lj) * kLd + ko);
-      float4 b[TN];
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn) b[tn] = ld4(bbase + (wn * 32 * TN + tn * 32 + lj) * ldb + ko);
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn) acc[tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[tn].x, acc[tn], 0, 0, 0);
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn) acc[tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[tn].y, acc[tn], 0, 0, 0);
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn) acc[tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[tn].z, acc[tn], 0, 0, 0);
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn) acc[tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[tn].w, acc[tn], 0, 0, 0);
-    }
-    if (kc == chunks - 1) {
-      // ---- tile epilogue (stores only; the bias was loaded up front)
-      const int64_t tile = blockIdx.x + (step / chunks) * gridDim.x;
-      const int64_t mrow0 = tile * BM + wm * 32 + 4 * hi;
-      const bool interior = (tile * BM + BM <= M) && (n0 + kBN <= N);
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn) {
-        const int nl = wn * 32 * TN + tn * 32 + lj;
-        const int n = n0 + nl;
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int64_t m = mrow0 + (r & 3) + 8 * (r >> 2);
-          const float v = acc[tn][r] + bias_v[tn];
-          if (interior || (m < M && n < N)) {
-            y[m * N + n] = v;
-            if (STATS) { s1 += v; s2 += v * v; }
-          }
-          acc[tn][r] = 0.f;
-        }
-        if (STATS) {
-          s1 += __shfl_xor(s1, 32, 64);
-          s2 += __shfl_xor(s2, 32, 64);
-          if (hi == 0) { s_stats[(wm * 2 + 0) * kBN + nl] = s1; s_stats[(wm * 2 + 1) * kBN + nl] = s2; }
-        }
-      }
-      if (STATS) {
-        __syncthreads();
-        if (tid < kBN && n0 + tid < N) {
-          float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-          for (int w = 0; w < WM; ++w) { t1 += s_stats[(w * 2 + 0) * kBN + tid]; t2 += s_stats[(w * 2 + 1) * kBN + tid]; }
-          float* p = stats_partial + tile * 2 * N;
-          p[n0 + tid] = t1;
-          p[N + n0 + tid] = t2;
-        }
-      }
-    }
-  };
-
-  float4 r0[FPT], r1[FPT], r2[FPT];
-  if (total > 0) fetch(0, r0);
-  if (total > 1) fetch(1, r1);
-  if (total > 2) fetch(2, r2);
-  for (int64_t step = 0; step < total; step += 3) {
-    body(step, r0);
-    if (step + 1 < total) body(step + 1, r1);
-    if (step + 2 < total) body(step + 2, r2);
-  }
-}
-
-inline size_t res_lds_bytes(int BM, int Ktot) {
-  const int chunks = (Ktot + kKC - 1) / kKC;
-  return static_cast<size_t>(kBN * (chunks * kKC + 4) + 2 * BM * kLd + (BM / 32) * 2 * kBN) * sizeof(float);
-}
-
-template <int BM, bool STATS>
-int launch_res(dim3 grid, hipStream_t st, const float* x1, const float* w1, int K1, const float* x2, const float* w2,
-               int K2, const float* bias, int64_t M, int N, float* y, float* stats) {
-  const size_t lds = res_lds_bytes(BM, K1 + K2);
-  static bool configured = false;  // per instantiation
-  if (!configured) {
-    STEMGNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linear_fwd_res<BM, STATS>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    configured = true;
-  }
-  k_linear_fwd_res<BM, STATS><<<grid, kResThreads, lds, st>>>(x1, w1, K1, x2, w2, K2, bias, M, N, y, stats);
-  STEMGNN_LAUNCH_CHECK();
-  return STEMGNN_OK;
-}
+// (A weight-resident persistent variant -- 128-column weight tile kept in LDS, one 512-thread block
+// per CU streaming activation chunks through a ring with one barrier per step -- was built and
+// measured slower than the kernel above: 55 vs 46 us at K = 128, 92 vs 81 us at K = 256, M = 102400,
+// with or without a three-chunk-deep prefetch.  Removed; see git history.)
 
 // ---------------------------------------------------------------------------------------
 // backward-W: partial[s] = dY[rows of split s]^T X[rows of split s]; partial_db[s] = colsum dY
@@ -499,8 +324,42 @@ inline bool lin_dims_ok(int64_t M, int64_t N, int64_t K) {
   return M >= 0 && N > 0 && K > 0 && K % 4 == 0 && N <= 65536 && K <= 65536;
 }
 
-// rows per tile of the weight-resident forward variant (also the granularity of its statistics partials)
-inline int res_block_rows(int64_t Ktot) { return Ktot <= 128 ? 128 : 64; }
+// Resident-block slots of the 128-row forward tile kernel on this device (blocks per CU x CUs).
+inline int64_t fwd_slots() {
+  static const int64_t slots = [] {
+    int per_cu = 0, cus = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_linear_fwd<128, false>, kBlock, 0) != hipSuccess ||
+        per_cu <= 0 || cus <= 0) {
+      (void)hipGetLastError();
+      return static_cast<int64_t>(3 * 256);
+    }
+    return static_cast<int64_t>(per_cu) * cus;
+  }();
+  return slots;
+}
+
+// Tile plan of the forward product: whole rounds of 128-row tiles, and (when the last round
+// would be mostly empty) its rows as 32-row tiles.  Measured at N = 128 on MI355X: 768 tiles (one
+// full round) run at 84 / 101 / 116 TFLOP/s for K = 128 / 256 / 512, 800 tiles at 66 / 85 / 95.
+struct FwdPlan {
+  int64_t main_tiles, tail_tiles;
+};
+inline FwdPlan plan_fwd(int64_t M, int64_t N) {
+  const int64_t gy = (N + kBN - 1) / kBN;
+  const int64_t tiles = (M + kBM - 1) / kBM;
+  const int64_t slots = fwd_slots();
+  const int64_t per_round = slots / gy > 0 ? slots / gy : 1;  // row tiles per resident round
+  const int64_t rem = tiles % per_round;
+  FwdPlan p{tiles, 0};
+  if (tiles > per_round && rem > 0 && rem * 4 <= per_round) {
+    p.main_tiles = tiles - rem;
+    const int64_t rem_rows = M - p.main_tiles * kBM;
+    p.tail_tiles = (rem_rows + 31) / 32;
+  }
+  return p;
+}
 
 // Row splits of the weight-gradient product.  Measured on MI355X (M = 102400): the kernel wants
 // ~512 blocks in total (2 resident per CU) but the partial slabs (S * N * K floats, written and
@@ -530,13 +389,13 @@ extern "C" {
 
 size_t stemgnn_linear_stats_partial_bytes(int64_t M, int64_t N) {
   if (M < 0 || N <= 0) return 0;
-  return static_cast<size_t>((M + 63) / 64) * 2 * N * sizeof(float) + 256;  // upper bound over both variants
+  return static_cast<size_t>((M + 31) / 32) * 2 * N * sizeof(float) + 256;  // upper bound over every tile plan
 }
 
-int64_t stemgnn_linear_stats_blocks(int64_t M, int64_t k_total) {
-  if (M < 0 || k_total <= 0) return 0;
-  const int64_t rows = (kUseResidentVariant && k_total <= 256) ? res_block_rows(k_total) : kBM;
-  return (M + rows - 1) / rows;
+int64_t stemgnn_linear_stats_blocks(int64_t M, int64_t N) {
+  if (M < 0 || N <= 0) return 0;
+  const FwdPlan p = plan_fwd(M, N);
+  return p.main_tiles + p.tail_tiles;
 }
 
 int stemgnn_linear_fwd(const float* x1, const float* w1, int64_t K1, const float* x2, const float* w2, int64_t K2,
@@ -545,35 +404,34 @@ int stemgnn_linear_fwd(const float* x1, const float* w1, int64_t K1, const float
   hipStream_t st = static_cast<hipStream_t>(stream_);
   if (!lin_dims_ok(M, N, K1) || K2 < 0 || K2 % 4 != 0) return STEMGNN_ERR_INVALID_ARG;
   if (!fits_i32(M)) return STEMGNN_ERR_TOO_LARGE;
-  if (stats_blocks_host) *stats_blocks_host = stemgnn_linear_stats_blocks(M, K1 + K2);
+  if (stats_blocks_host) *stats_blocks_host = stemgnn_linear_stats_blocks(M, N);
   if (M == 0) return STEMGNN_OK;
   if (!x1 || !w1 || !y || (K2 > 0 && (!x2 || !w2))) return STEMGNN_ERR_INVALID_ARG;
   if (N % 4 != 0) return STEMGNN_ERR_INVALID_ARG;
   const int gy = static_cast<int>((N + kBN - 1) / kBN);
-  const int64_t Ktot = K1 + K2;
-  if (kUseResidentVariant && Ktot <= 256 && (K2 == 0 || K1 % 4 == 0)) {
-    // weight-resident persistent variant: one 512-thread block per CU
-    const int BM = res_block_rows(Ktot);
-    const int64_t tiles = (M + BM - 1) / BM;
-    int gx = 256 / gy;
-    if (gx < 1) gx = 1;
-    if (gx > tiles) gx = static_cast<int>(tiles);
-    dim3 grid(static_cast<unsigned>(gx), static_cast<unsigned>(gy));
-    const int k1 = static_cast<int>(K1), k2 = static_cast<int>(K2), n = static_cast<int>(N);
-    if (BM == 128)
-      return stats_partial ? launch_res<128, true>(grid, st, x1, w1, k1, x2, w2, k2, bias, M, n, y, stats_partial)
-                           : launch_res<128, false>(grid, st, x1, w1, k1, x2, w2, k2, bias, M, n, y, nullptr);
-    return stats_partial ? launch_res<64, true>(grid, st, x1, w1, k1, x2, w2, k2, bias, M, n, y, stats_partial)
-                         : launch_res<64, false>(grid, st, x1, w1, k1, x2, w2, k2, bias, M, n, y, nullptr);
+  const FwdPlan plan = plan_fwd(M, N);
+  const int k1 = static_cast<int>(K1), k2 = static_cast<int>(K2), n = static_cast<int>(N);
+  if (plan.main_tiles > 0) {
+    dim3 grid(static_cast<unsigned>(plan.main_tiles), static_cast<unsigned>(gy));
+    if (stats_partial)
+      k_linear_fwd<128, true><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, stats_partial, 0, 0);
+    else
+      k_linear_fwd<128, false><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, nullptr, 0, 0);
+    STEMGNN_LAUNCH_CHECK();
   }
-  dim3 grid(static_cast<unsigned>((M + kBM - 1) / kBM), static_cast<unsigned>(gy));
-  if (stats_partial)
-    k_linear_fwd<true><<<grid, kBlock, 0, st>>>(x1, w1, static_cast<int>(K1), x2, w2, static_cast<int>(K2), bias, M,
-                                                static_cast<int>(N), y, stats_partial);
-  else
-    k_linear_fwd<false><<<grid, kBlock, 0, st>>>(x1, w1, static_cast<int>(K1), x2, w2, static_cast<int>(K2), bias, M,
-                                                 static_cast<int>(N), y, nullptr);
-  STEMGNN_LAUNCH_CHECK();
+  if (plan.tail_tiles > 0) {
+    // the rows of the last, mostly empty round of 128-row tiles run as 32-row tiles: 4x the blocks,
+    // a quarter of the latency each, instead of a handful of full-size stragglers
+    dim3 grid(static_cast<unsigned>(plan.tail_tiles), static_cast<unsigned>(gy));
+    const int64_t row_base = plan.main_tiles * kBM;
+    if (stats_partial)
+      k_linear_fwd<32, true><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, stats_partial, row_base,
+                                                      plan.main_tiles);
+    else
+      k_linear_fwd<32, false><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, nullptr, row_base,
+                                                       plan.main_tiles);
+    STEMGNN_LAUNCH_CHECK();
+  }
   return STEMGNN_OK;
 }
 

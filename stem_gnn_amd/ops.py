@@ -425,7 +425,7 @@ def linear_fwd(x1: Tensor, w1: Tensor, x2: Optional[Tensor], w2: Optional[Tensor
         _req(bias, torch.float32, "bias", 1)
     y = torch.empty(M, N, dtype=torch.float32, device=x1.device)
     partial = None
-    blocks = int(lib.stemgnn_linear_stats_blocks(M, K1 + K2))
+    blocks = int(lib.stemgnn_linear_stats_blocks(M, N))
     if want_stats:
         partial = torch.empty(max(blocks, 1), 2, N, dtype=torch.float32, device=x1.device)
     check(lib.stemgnn_linear_fwd(_p(x1), _p(w1), K1, _p(x2), _p(w2), K2, _p(bias), M, N, _p(y), _p(partial), None,
