@@ -213,11 +213,24 @@ class PretrainModel(nn.Module):
             commit_loss = torch.tensor(0.0, device=z.device)
         else:
             query = quantize
-        feat_recon_loss = self.feat_recon_loss(query, orig_x, bs=bs)
-        topo_recon_loss = self.topo_recon_loss(query, orig_edge_index, ratio=topo_recon_ratio, draws=draws)
-        topo_sem_recon_loss = self.topo_sem_recon_loss(query, orig_edge_index, orig_edge_attr,
-                                                       ratio=topo_recon_ratio, draws=draws)
-        sem_recon_loss = self.sem_recon_loss(g, query, eta=1.0, bs=bs, teacher=teacher)
+        if topo_recon_ratio not in (0.0, 1.0) and query.is_cuda:
+            # fused fan-out of the query: one dense gradient buffer for its three consumers
+            full_ei = _edge_index_of(orig_edge_index)
+            perm = self._sample_edges(full_ei.size(1), topo_recon_ratio, z.device, "topo_sem_perm", draws)
+            sem_ei = full_ei[:, perm]
+            q_all, q_head, zz = ops.QueryFanOutFn.apply(query, query.size(0) if bs is None else bs, sem_ei)
+            feat_recon_loss = F.mse_loss(self.feat_recon(q_head), orig_x[:bs])  # pt_model.py:42-43
+            topo_recon_loss = self.topo_recon_loss(q_all, orig_edge_index, ratio=topo_recon_ratio, draws=draws)
+            attr = orig_edge_attr[perm]
+            target = attr.dense() if isinstance(attr, EdgeTypeAttr) else attr
+            topo_sem_recon_loss = F.mse_loss(self._lin(self.topo_sem_recon_decoder, zz), target)  # pt_model.py:80-81
+            sem_recon_loss = self.sem_recon_loss(g, q_head, eta=1.0, bs=bs, teacher=teacher)
+        else:
+            feat_recon_loss = self.feat_recon_loss(query, orig_x, bs=bs)
+            topo_recon_loss = self.topo_recon_loss(query, orig_edge_index, ratio=topo_recon_ratio, draws=draws)
+            topo_sem_recon_loss = self.topo_sem_recon_loss(query, orig_edge_index, orig_edge_attr,
+                                                           ratio=topo_recon_ratio, draws=draws)
+            sem_recon_loss = self.sem_recon_loss(g, query, eta=1.0, bs=bs, teacher=teacher)
         losses = {
             "feat_recon_loss": feat_recon_loss,
             "topo_recon_loss": topo_recon_loss,

@@ -651,6 +651,45 @@ class EdgeConcatFn(torch.autograd.Function):
         return g_z, None
 
 
+class QueryFanOutFn(torch.autograd.Function):
+    """The three consumers of the decoder query in PretrainModel.forward (reference
+    model/pt_model.py:128-131): q itself (topology decoder), its first `bs` rows (feature and
+    semantic terms) and cat([q[u], q[v]]) over the sampled edges (topo-sem term).  Forward is a
+    slice copy + the edge-concat kernel.  Backward folds the three gradients into ONE dense
+    buffer: the sparse contributions are scattered / added into the dense one in place, instead
+    of autograd materialising three zero-filled [N, D] tensors and summing them with three
+    full-size add kernels."""
+
+    @staticmethod
+    def forward(ctx, q, bs, edge_index):
+        q = q.contiguous()
+        _req(q, torch.float32, "q", 2)
+        ei = _req(edge_index.contiguous(), torch.int64, "edge_index", 2)
+        N, D = q.shape
+        E = ei.size(1)
+        head = q[:bs].clone()
+        zz = torch.empty(E, 2 * D, dtype=torch.float32, device=q.device)
+        check(lib.stemgnn_edge_concat_fwd(_p(q), N, D, _p(ei), E, _p(zz), _stream()), "edge_concat_fwd")
+        ctx.save_for_backward(ei)
+        ctx.meta = (N, D, int(head.size(0)))
+        return q.view_as(q), head, zz
+
+    @staticmethod
+    def backward(ctx, g_q, g_head, g_zz):
+        (ei,) = ctx.saved_tensors
+        N, D, nh = ctx.meta
+        if g_q is None:
+            g = torch.zeros(N, D, dtype=torch.float32, device=ei.device)
+        else:
+            g = g_q.contiguous()  # freshly produced by the topology decoder's backward-data product
+        if g_zz is not None:
+            check(lib.stemgnn_edge_concat_bwd(_p(g_zz.contiguous()), N, D, _p(ei), ei.size(1), _p(g), _stream()),
+                  "edge_concat_bwd")
+        if g_head is not None:
+            g[:nh] += g_head
+        return g, None, None
+
+
 def gather_rows(table: Tensor, index: Tensor) -> Tensor:
     """out[i] = table[index[i]] (device-side node_text_feat[x] of reference pretrain.py:33-38)."""
     _req(table, torch.float32, "table", 2)
