@@ -172,6 +172,8 @@ class PretrainModel(nn.Module):
             z.record_stream(torch.cuda.current_stream(z.device))
         # the projector is row-wise and only rows [:bs] are used (pt_model.py:94-97): project those rows only
         h = self._lin(self.sem_projector, quantize[:bs])
+        if eta == 1.0 and h.is_cuda:
+            return ops.CosineLossFn.apply(z[:bs], h)  # mean(1 - <z/|z|, h/|h|>), fused forward + backward
         z = F.normalize(z[:bs], dim=-1, p=2)
         h = F.normalize(h, dim=-1, p=2)
         loss = (1 - (z * h).sum(dim=-1)).pow_(eta)
@@ -219,11 +221,11 @@ class PretrainModel(nn.Module):
             perm = self._sample_edges(full_ei.size(1), topo_recon_ratio, z.device, "topo_sem_perm", draws)
             sem_ei = full_ei[:, perm]
             q_all, q_head, zz = ops.QueryFanOutFn.apply(query, query.size(0) if bs is None else bs, sem_ei)
-            feat_recon_loss = F.mse_loss(self.feat_recon(q_head), orig_x[:bs])  # pt_model.py:42-43
+            feat_recon_loss = ops.MseLossFn.apply(self.feat_recon(q_head), orig_x[:bs])  # pt_model.py:42-43
             topo_recon_loss = self.topo_recon_loss(q_all, orig_edge_index, ratio=topo_recon_ratio, draws=draws)
             attr = orig_edge_attr[perm]
             target = attr.dense() if isinstance(attr, EdgeTypeAttr) else attr
-            topo_sem_recon_loss = F.mse_loss(self._lin(self.topo_sem_recon_decoder, zz), target)  # pt_model.py:80-81
+            topo_sem_recon_loss = ops.MseLossFn.apply(self._lin(self.topo_sem_recon_decoder, zz), target)  # :80-81
             sem_recon_loss = self.sem_recon_loss(g, q_head, eta=1.0, bs=bs, teacher=teacher)
         else:
             feat_recon_loss = self.feat_recon_loss(query, orig_x, bs=bs)

@@ -229,18 +229,27 @@ class VectorQuantize(nn.Module):
             cb.ema_update_(xp.detach().contiguous(), embed_ind)
         loss = torch.zeros(1, device=x.device, requires_grad=self.training)  # vq.py:983
         if self.training:
+            terms = []
             if self.commitment_weight > 0:
-                loss = loss + mse * self.commitment_weight  # vq.py:1007-1009
+                terms.append(mse * self.commitment_weight)  # vq.py:1007-1009
             if self.has_codebook_orthogonal_loss:  # vq.py:1011-1028
                 codebook = cb.embed
                 num_codes = codebook.shape[-2]
                 if self.orthogonal_reg_max_codes is not None and num_codes > self.orthogonal_reg_max_codes:
                     rand_ids = self._rand_code_ids(num_codes, self.orthogonal_reg_max_codes, x.device)
                     self.last_ortho_ids = rand_ids
-                    codebook = codebook[:, rand_ids]
                 else:
+                    rand_ids = None
                     self.last_ortho_ids = None
-                loss = loss + orthogonal_loss_fn(codebook) * self.orthogonal_reg_weight
+                if codebook.is_cuda:
+                    ids = rand_ids if rand_ids is not None else torch.arange(num_codes, device=x.device)
+                    terms.append(ops.OrthoLossFn.apply(codebook, ids, self.orthogonal_reg_weight))  # fused fwd+bwd
+                else:
+                    sel = codebook if rand_ids is None else codebook[:, rand_ids]
+                    terms.append(orthogonal_loss_fn(sel) * self.orthogonal_reg_weight)
+            if terms:
+                total = terms[0] if len(terms) == 1 else terms[0] + terms[1]
+                loss = total.reshape(1)
         if h == 1:
             embed_ind = embed_ind.view(n)  # heads == 1 is not "multiheaded" (vq.py:865)
         orig_quantize = quant  # [N, H*Dc], heads already merged 'b n (h d)' (vq.py:1034)

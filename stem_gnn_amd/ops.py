@@ -651,6 +651,83 @@ class EdgeConcatFn(torch.autograd.Function):
         return g_z, None
 
 
+class MseLossFn(torch.autograd.Function):
+    """F.mse_loss(pred, target) (reference model/pt_model.py:43,81): one kernel forward, one backward."""
+
+    @staticmethod
+    def forward(ctx, pred, target):
+        pred = pred.contiguous()
+        target = target.contiguous()
+        _req(pred, torch.float32, "pred")
+        _req(target, torch.float32, "target")
+        if pred.shape != target.shape:
+            raise RuntimeError(f"mse_loss: shape mismatch {tuple(pred.shape)} vs {tuple(target.shape)}")
+        loss = torch.empty(1, dtype=torch.float32, device=pred.device)
+        check(lib.stemgnn_mse_loss_fwd(_p(pred), _p(target), pred.numel(), 1.0, _p(loss), _stream()), "mse_loss_fwd")
+        ctx.save_for_backward(pred, target)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, target = ctx.saved_tensors
+        gp = torch.empty_like(pred)
+        check(lib.stemgnn_mse_loss_bwd(_p(pred), _p(target), pred.numel(), 1.0, _p(g.reshape(1).contiguous()), _p(gp),
+                                       _stream()), "mse_loss_bwd")
+        return gp, None
+
+
+class CosineLossFn(torch.autograd.Function):
+    """mean(1 - cos(z, h)) with z detached (reference model/pt_model.py:93-100)."""
+
+    @staticmethod
+    def forward(ctx, z, h):
+        z = z.contiguous()
+        h = h.contiguous()
+        _req(z, torch.float32, "z", 2)
+        _req(h, torch.float32, "h", 2)
+        rows, D = h.shape
+        loss = torch.empty(1, dtype=torch.float32, device=h.device)
+        save = torch.empty(max(rows, 1), 3, dtype=torch.float32, device=h.device)
+        check(lib.stemgnn_cosine_loss_fwd(_p(z), _p(h), rows, D, 1.0, _p(loss), _p(save), _stream()), "cosine_loss_fwd")
+        ctx.save_for_backward(z, h, save)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        z, h, save = ctx.saved_tensors
+        gh = torch.empty_like(h)
+        check(lib.stemgnn_cosine_loss_bwd(_p(z), _p(h), h.size(0), h.size(1), 1.0, _p(g.reshape(1).contiguous()),
+                                          _p(save), _p(gh), _stream()), "cosine_loss_bwd")
+        return None, gh
+
+
+class OrthoLossFn(torch.autograd.Function):
+    """orthogonal_loss_fn(embed[:, ids]) * weight (reference model/vq.py:232-237,1011-1028)."""
+
+    @staticmethod
+    def forward(ctx, embed, ids, weight):
+        e = embed.contiguous()
+        _req(e, torch.float32, "embed", 3)
+        ids = _req(ids.contiguous(), torch.int64, "ids", 1)
+        H, K, Dc = e.shape
+        loss = torch.empty(1, dtype=torch.float32, device=e.device)
+        ws = _workspace(lib.stemgnn_ortho_loss_workspace_bytes(H), e.device)
+        check(lib.stemgnn_ortho_loss_fwd(_p(e), _p(ids), H, K, Dc, ids.numel(), float(weight), _p(loss), _p(ws),
+                                         ws.numel(), _stream()), "ortho_loss_fwd")
+        ctx.save_for_backward(e, ids)
+        ctx.weight = float(weight)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        e, ids = ctx.saved_tensors
+        H, K, Dc = e.shape
+        ge = torch.empty_like(e)
+        check(lib.stemgnn_ortho_loss_bwd(_p(e), _p(ids), H, K, Dc, ids.numel(), ctx.weight,
+                                         _p(g.reshape(1).contiguous()), _p(ge), _stream()), "ortho_loss_bwd")
+        return ge, None, None
+
+
 class QueryFanOutFn(torch.autograd.Function):
     """The three consumers of the decoder query in PretrainModel.forward (reference
     model/pt_model.py:128-131): q itself (topology decoder), its first `bs` rows (feature and

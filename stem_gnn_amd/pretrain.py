@@ -10,6 +10,7 @@ gfx950 kernels.  Differences from the reference's host loop, all outside the ari
 """
 from __future__ import annotations
 
+import gc
 from typing import Dict, Optional
 
 import torch
@@ -68,11 +69,25 @@ def build_optimizer(model: nn.Module, params: Dict):
     return opt, sched
 
 
+_LOSS_KEYS = ("feat_recon_loss", "topo_recon_loss", "topo_sem_recon_loss", "sem_recon_loss", "commit_loss",
+              "env_reg_loss")
+
+
 def total_loss(losses: Dict[str, torch.Tensor], params: Dict) -> torch.Tensor:
-    """reference pretrain.py:51-58."""
-    return (params["feat_lambda"] * losses["feat_recon_loss"] + params["topo_lambda"] * losses["topo_recon_loss"]
-            + params["topo_sem_lambda"] * losses["topo_sem_recon_loss"] + params["sem_lambda"] * losses["sem_recon_loss"]
-            + losses["commit_loss"] + params.get("lamda_env", 0.0) * losses["env_reg_loss"])
+    """reference pretrain.py:51-58: feat_lambda*feat + topo_lambda*topo + topo_sem_lambda*topo_sem +
+    sem_lambda*sem + commit + lamda_env*env, as one stacked weighted sum (3 kernels instead of 11)."""
+    w = (float(params["feat_lambda"]), float(params["topo_lambda"]), float(params["topo_sem_lambda"]),
+         float(params["sem_lambda"]), 1.0, float(params.get("lamda_env", 0.0)))
+    dev = losses["feat_recon_loss"].device
+    key = (w, dev)
+    wt = _WEIGHT_CACHE.get(key)
+    if wt is None:
+        wt = _WEIGHT_CACHE[key] = torch.tensor(w, dtype=torch.float32, device=dev)
+    stacked = torch.stack([losses[k].reshape(()).float() for k in _LOSS_KEYS])
+    return (stacked * wt).sum().reshape(1)
+
+
+_WEIGHT_CACHE: Dict = {}
 
 
 def pretrain_step(model: PretrainModel, optimizer, scheduler, params: Dict, x, edge_index, edge_attr, bs: int,
@@ -146,6 +161,21 @@ def pretrain(model, loader, optimizer, params, scheduler=None, no_codebook=False
     (reference dataset/process_datasets.py:92-108).  Feature tables should live on the device."""
     model.train()
     device = next(model.parameters()).device
+    last = None
+    # keep the cyclic collector off the hot loop (a generation-2 pass costs tens of ms when it fires in a
+    # step); autograd graphs are reference-counted away each step, the epoch end collects the rest
+    gc_was_enabled = gc.isenabled()
+    gc.collect()
+    gc.disable()
+    try:
+        last = _pretrain_epoch(model, loader, optimizer, params, scheduler, no_codebook, log_fn, grad_sync, device)
+    finally:
+        if gc_was_enabled:
+            gc.enable()
+    return last
+
+
+def _pretrain_epoch(model, loader, optimizer, params, scheduler, no_codebook, log_fn, grad_sync, device):
     last = None
     for data in loader:
         bs = data.batch_size

@@ -396,3 +396,58 @@ def test_mask_columns(dev):
     keep = ops.dropout_keep_mask(64, 0.3, *key, dev).cpu()
     assert 0 < int(keep.sum()) < 64
     assert torch.equal(out.cpu(), O.mask_feature_col(x, keep))
+
+
+# ---------------------------------------------------------------------------- fused scalar losses
+@pytest.mark.parametrize("shape", [(1, 4), (1024, 128), (11189, 128), (37, 33)])
+def test_mse_loss_fn(dev, shape):
+    from stem_gnn_amd import ops
+    torch.manual_seed(shape[0])
+    p, t = torch.randn(*shape), torch.randn(*shape)
+    pr = p.clone().requires_grad_(True)
+    ref = torch.nn.functional.mse_loss(pr, t)
+    (ref * 3.0).backward()
+    pg = p.to(dev).requires_grad_(True)
+    out = ops.MseLossFn.apply(pg, t.to(dev))
+    (out * 3.0).backward()
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(pg.grad.cpu(), pr.grad, rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.parametrize("rows,d", [(1, 8), (1024, 128), (200, 768), (77, 48)])
+def test_cosine_loss_fn(dev, rows, d):
+    from stem_gnn_amd import ops
+    torch.manual_seed(rows + d)
+    z, h = torch.randn(rows, d), torch.randn(rows, d)
+    if rows > 2:
+        h[1] = 0.0  # exercises the eps clamp of F.normalize
+    hr = h.clone().requires_grad_(True)
+    zn = torch.nn.functional.normalize(z, dim=-1, p=2)
+    hn = torch.nn.functional.normalize(hr, dim=-1, p=2)
+    ref = (1 - (zn * hn).sum(dim=-1)).mean()
+    (ref * 2.0).backward()
+    hg = h.to(dev).requires_grad_(True)
+    out = ops.CosineLossFn.apply(z.to(dev), hg)
+    (out * 2.0).backward()
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-5, atol=1e-6)
+    mask = torch.ones(rows, dtype=torch.bool)
+    if rows > 2:
+        mask[1] = False  # d/dh at h = 0 is 1/eps * z in both; compared separately below with a relative bound
+        torch.testing.assert_close(hg.grad.cpu()[1], hr.grad[1], rtol=1e-3, atol=0)
+    torch.testing.assert_close(hg.grad.cpu()[mask], hr.grad[mask], rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("H,K,Dc,M", [(1, 8, 16, 8), (4, 128, 128, 32), (4, 128, 768, 32), (2, 40, 48, 17)])
+def test_ortho_loss_fn(dev, H, K, Dc, M):
+    from stem_gnn_amd import ops
+    torch.manual_seed(K + Dc)
+    embed = torch.randn(H, K, Dc) * 0.7
+    ids = torch.randperm(K)[:M]
+    er = embed.clone().requires_grad_(True)
+    ref = O.orthogonal_loss(er[:, ids]) * 1.5
+    (ref * 2.0).backward()
+    eg = embed.to(dev).requires_grad_(True)
+    out = ops.OrthoLossFn.apply(eg, ids.to(dev), 1.5)
+    (out * 2.0).backward()
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(eg.grad.cpu(), er.grad, rtol=1e-3, atol=1e-6)
