@@ -298,18 +298,20 @@ int stemgnn_edge_dot_bwd_scaled(const float* coef, const float* g_scalar, const 
  * loss / g_loss are 1-element device scalars; reductions are fixed-order (reproducible).
  * ------------------------------------------------------------------------------------ */
 /* loss = scale * mean((pred - target)^2) over n elements (F.mse_loss, model/pt_model.py:43,81) */
-int stemgnn_mse_loss_fwd(const float* pred, const float* target, int64_t n, float scale, float* loss, void* stream);
+size_t stemgnn_loss_workspace_bytes(int64_t n);  /* n = elements of the largest reduction list (rows, heads * ids, 256) */
+int stemgnn_mse_loss_fwd(const float* pred, const float* target, int64_t n, float scale, float* loss, void* workspace,
+                         size_t workspace_bytes, void* stream);
 int stemgnn_mse_loss_bwd(const float* pred, const float* target, int64_t n, float scale, const float* g_loss,
                          float* g_pred, void* stream);
 /* loss = scale * mean_r (1 - cos(z_r, h_r)) with F.normalize's eps clamp (model/pt_model.py:96-100);
  * save [rows, 3] carries (cos, 1/|z|, |h|) to the backward, which returns the gradient w.r.t. h. */
 int stemgnn_cosine_loss_fwd(const float* z, const float* h, int64_t rows, int64_t dim, float scale, float* loss,
-                            float* save, void* stream);
+                            float* save, void* workspace, size_t workspace_bytes, void* stream);
 int stemgnn_cosine_loss_bwd(const float* z, const float* h, int64_t rows, int64_t dim, float scale,
                             const float* g_loss, const float* save, float* g_h, void* stream);
 /* orthogonal_loss_fn(embed[:, ids]) * scale (model/vq.py:232-237,1011-1028): embed [H, K, Dc], ids
- * int64 [M] distinct.  The backward writes the dense gradient g_embed [H, K, Dc] (zero off the ids). */
-size_t stemgnn_ortho_loss_workspace_bytes(int64_t heads);
+ * int64 [M] distinct, Dc <= 1024.  The backward writes the dense gradient g_embed [H, K, Dc] (zero off the ids).
+ * Workspace: stemgnn_loss_workspace_bytes(H * M). */
 int stemgnn_ortho_loss_fwd(const float* embed, const int64_t* ids, int64_t heads, int64_t codebook_size,
                            int64_t code_dim, int64_t num_ids, float scale, float* loss, void* workspace,
                            size_t workspace_bytes, void* stream);

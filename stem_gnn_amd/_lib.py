@@ -76,11 +76,11 @@ _SIGNATURES = {
     "stemgnn_vq_assign_bwd": (c_int, [P, P, c_float, P, P, P, P, I64, I64, I64, I64, P, P]),
     "stemgnn_vq_ema_workspace_bytes": (c_size_t, [I64, I64, I64, I64]),
     "stemgnn_vq_ema_stats": (c_int, [P, P, P, I64, I64, I64, I64, P, P, P, c_size_t, P]),
-    "stemgnn_mse_loss_fwd": (c_int, [P, P, I64, c_float, P, P]),
+    "stemgnn_loss_workspace_bytes": (c_size_t, [I64]),
+    "stemgnn_mse_loss_fwd": (c_int, [P, P, I64, c_float, P, P, c_size_t, P]),
     "stemgnn_mse_loss_bwd": (c_int, [P, P, I64, c_float, P, P, P]),
-    "stemgnn_cosine_loss_fwd": (c_int, [P, P, I64, I64, c_float, P, P, P]),
+    "stemgnn_cosine_loss_fwd": (c_int, [P, P, I64, I64, c_float, P, P, P, c_size_t, P]),
     "stemgnn_cosine_loss_bwd": (c_int, [P, P, I64, I64, c_float, P, P, P, P]),
-    "stemgnn_ortho_loss_workspace_bytes": (c_size_t, [I64]),
     "stemgnn_ortho_loss_fwd": (c_int, [P, P, I64, I64, I64, I64, c_float, P, P, c_size_t, P]),
     "stemgnn_ortho_loss_bwd": (c_int, [P, P, I64, I64, I64, I64, c_float, P, P, P]),
     "stemgnn_edge_dot_fwd": (c_int, [P, I64, I64, P, I64, P, P]),

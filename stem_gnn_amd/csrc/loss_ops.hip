@@ -25,23 +25,44 @@ __device__ inline double block_sum(double v, double* red) {
   return r;
 }
 
-// loss[0] = scale * mean((p - t)^2)
-__global__ void __launch_bounds__(kRed) k_mse_fwd(const float* __restrict__ p, const float* __restrict__ t, int64_t n,
-                                                  float scale, float* __restrict__ loss) {
-  __shared__ double red[kRed];
+// partial[b] = sum over the block's grid-stride share of (p - t)^2
+__global__ void __launch_bounds__(256) k_mse_partial(const float* __restrict__ p, const float* __restrict__ t, int64_t n,
+                                                     double* __restrict__ partial) {
+  __shared__ double red[256];
   double s = 0.0;
   const int64_t n4 = n / 4;
-  for (int64_t i = threadIdx.x; i < n4; i += kRed) {
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n4; i += static_cast<int64_t>(gridDim.x) * 256) {
     const float4 a = *reinterpret_cast<const float4*>(p + 4 * i), b = *reinterpret_cast<const float4*>(t + 4 * i);
     const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z, dw = a.w - b.w;
     s += static_cast<double>(dx * dx + dy * dy + dz * dz + dw * dw);
   }
-  for (int64_t i = 4 * n4 + threadIdx.x; i < n; i += kRed) {
-    const float d = p[i] - t[i];
-    s += static_cast<double>(d * d);
+  if (blockIdx.x == 0)
+    for (int64_t i = 4 * n4 + threadIdx.x; i < n; i += 256) {
+      const float d = p[i] - t[i];
+      s += static_cast<double>(d * d);
+    }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
   }
-  const double tot = block_sum(s, red);
-  if (threadIdx.x == 0) loss[0] = static_cast<float>(tot / static_cast<double>(n > 0 ? n : 1)) * scale;
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+// loss[0] = (sum_b partial[b]) * mul + add   (fixed order)
+__global__ void __launch_bounds__(256) k_finish_sum(const double* __restrict__ partial, int n, double mul, double add,
+                                                    float* __restrict__ loss) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[0] = static_cast<float>(red[0] * mul + add);
 }
 
 // g_p = g[0] * scale * 2 (p - t) / n
@@ -52,31 +73,26 @@ __global__ void __launch_bounds__(256) k_mse_bwd(const float* __restrict__ p, co
     gp[i] = c * (p[i] - t[i]);
 }
 
-// loss = scale * mean_r (1 - <z_r, h_r> / (max(|z_r|,eps) max(|h_r|,eps))); one wave per row.
-// Saves per row: dot of the normalised vectors (cos), 1/max(|z|,eps), |h| for the backward.
-__global__ void __launch_bounds__(kRed) k_cos_fwd(const float* __restrict__ z, const float* __restrict__ h, int64_t rows,
-                                                  int D, float scale, float* __restrict__ loss,
-                                                  float* __restrict__ save /*[rows][3]*/) {
-  __shared__ double red[kRed];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  double acc = 0.0;
-  for (int64_t r = wave; r < rows; r += kRed / 64) {
-    float zz = 0.f, hh = 0.f, zh = 0.f;
-    for (int c = lane; c < D; c += 64) {
-      const float a = z[r * D + c], b = h[r * D + c];
-      zz += a * a; hh += b * b; zh += a * b;
-    }
-    zz = wave_sum(zz); hh = wave_sum(hh); zh = wave_sum(zh);
-    const float nz = sqrtf(zz), nh = sqrtf(hh);
-    const float cz = fmaxf(nz, kNormEps), ch = fmaxf(nh, kNormEps);
-    const float cosv = zh / (cz * ch);
-    if (lane == 0) {
-      save[r * 3 + 0] = cosv; save[r * 3 + 1] = 1.0f / cz; save[r * 3 + 2] = nh;
-      acc += static_cast<double>(1.0f - cosv);
-    }
+// One wave per row: cos of the normalised rows (F.normalize eps clamp); save [rows][3] = (cos, 1/|z|, |h|),
+// row_loss[r] = 1 - cos.
+__global__ void __launch_bounds__(256) k_cos_rows(const float* __restrict__ z, const float* __restrict__ h, int64_t rows,
+                                                  int D, float* __restrict__ save, double* __restrict__ row_loss) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  float zz = 0.f, hh = 0.f, zh = 0.f;
+  for (int c = lane; c < D; c += 64) {
+    const float a = z[r * D + c], b = h[r * D + c];
+    zz += a * a; hh += b * b; zh += a * b;
   }
-  const double tot = block_sum(acc, red);
-  if (threadIdx.x == 0) loss[0] = static_cast<float>(tot / static_cast<double>(rows > 0 ? rows : 1)) * scale;
+  zz = wave_sum(zz); hh = wave_sum(hh); zh = wave_sum(zh);
+  const float nz = sqrtf(zz), nh = sqrtf(hh);
+  const float cz = fmaxf(nz, kNormEps), ch = fmaxf(nh, kNormEps);
+  const float cosv = zh / (cz * ch);
+  if (lane == 0) {
+    save[r * 3 + 0] = cosv; save[r * 3 + 1] = 1.0f / cz; save[r * 3 + 2] = nh;
+    row_loss[r] = static_cast<double>(1.0f - cosv);
+  }
 }
 
 // g_h[r] = -(g scale / rows) * d cos / d h,  cos = <zn, h / max(|h|, eps)>
@@ -97,74 +113,69 @@ __global__ void __launch_bounds__(256) k_cos_bwd(const float* __restrict__ z, co
   }
 }
 
-// Orthogonal regulariser on embed[:, ids] ([H, M, Dc] selected codes): one block per head.
-//   c_i = e_i / max(|e_i|, eps);  loss = scale * (sum_h sum_ij <c_i, c_j>^2 / (H M^2) - 1/M)
-// Backward (same kernel family): d/dc_i = 4/(H M^2) sum_j <c_i,c_j> c_j, pushed through the
-// normalisation and scattered into the dense codebook gradient (zero elsewhere).
+// Orthogonal regulariser on embed[:, ids] ([H, M, Dc] selected codes).  One WAVE per (head, i):
+//   c_i = e_i / max(|e_i|, eps);  g_ij = <c_i, c_j>;  loss = scale * (sum_h sum_ij g_ij^2 / (H M^2) - 1/M)
+// forward: partial[h*M + i] = sum_j g_ij^2.
+// backward: d/dc_i = 4/(H M^2) sum_j g_ij c_j, pushed through the normalisation of e_i and written to
+// row ids[i] of the dense codebook gradient (zero elsewhere; ids are distinct).
+constexpr int kOrthoMaxPerLane = 16;  // Dc <= 1024
+
 template <bool BWD>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64)
 k_ortho(const float* __restrict__ embed, const int64_t* __restrict__ ids, int H, int K, int Dc, int M, float scale,
-        const float* __restrict__ g, float* __restrict__ loss_partial /*[H]*/, float* __restrict__ g_embed) {
-  extern __shared__ float sm[];  // cn [M][Dc], gram [M][M], inv_norm [M]
-  float* cn = sm;
-  float* gram = cn + M * Dc;
-  float* inv = gram + M * M;
-  __shared__ double red[256];
-  const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        const float* __restrict__ g, double* __restrict__ partial /*[H*M]*/, float* __restrict__ g_embed) {
+  const int h = blockIdx.x / M, i = blockIdx.x - h * M, lane = threadIdx.x;
   const float* eh = embed + static_cast<int64_t>(h) * K * Dc;
-  for (int i = wave; i < M; i += 4) {
-    const float* e = eh + ids[i] * Dc;
-    float ss = 0.f;
-    for (int c = lane; c < Dc; c += 64) ss += e[c] * e[c];
-    ss = wave_sum(ss);
-    const float iv = 1.0f / fmaxf(sqrtf(ss), kNormEps);
-    if (lane == 0) inv[i] = iv;
-    for (int c = lane; c < Dc; c += 64) cn[i * Dc + c] = e[c] * iv;
+  const float* ei = eh + ids[i] * Dc;
+  float ci[kOrthoMaxPerLane], gc[kOrthoMaxPerLane];
+  float ss = 0.f;
+#pragma unroll
+  for (int q = 0; q < kOrthoMaxPerLane; ++q) {
+    const int c = lane + 64 * q;
+    ci[q] = c < Dc ? ei[c] : 0.f;
+    gc[q] = 0.f;
+    ss += ci[q] * ci[q];
   }
-  __syncthreads();
-  for (int p = tid; p < M * M; p += 256) {
-    const int i = p / M, j = p - i * M;
-    float d = 0.f;
-    for (int c = 0; c < Dc; ++c) d += cn[i * Dc + c] * cn[j * Dc + c];
-    gram[p] = d;
-  }
-  __syncthreads();
-  if (!BWD) {
-    double s = 0.0;
-    for (int p = tid; p < M * M; p += 256) s += static_cast<double>(gram[p]) * gram[p];
-    red[tid] = s;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-      if (tid < o) red[tid] += red[tid + o];
-      __syncthreads();
+  ss = wave_sum(ss);
+  const float inv_i = 1.0f / fmaxf(sqrtf(ss), kNormEps);
+#pragma unroll
+  for (int q = 0; q < kOrthoMaxPerLane; ++q) ci[q] *= inv_i;
+  double acc = 0.0;
+  for (int j = 0; j < M; ++j) {
+    const float* ej = eh + ids[j] * Dc;
+    float ej_v[kOrthoMaxPerLane];
+    float sj = 0.f, dij = 0.f;
+#pragma unroll
+    for (int q = 0; q < kOrthoMaxPerLane; ++q) {
+      const int c = lane + 64 * q;
+      ej_v[q] = c < Dc ? ej[c] : 0.f;
+      sj += ej_v[q] * ej_v[q];
+      dij += ci[q] * ej_v[q];
     }
-    if (tid == 0) loss_partial[h] = static_cast<float>(red[0]);
+    sj = wave_sum(sj);
+    dij = wave_sum(dij);
+    const float inv_j = 1.0f / fmaxf(sqrtf(sj), kNormEps);
+    const float gij = dij * inv_j;
+    acc += static_cast<double>(gij) * gij;
+    if (BWD) {
+#pragma unroll
+      for (int q = 0; q < kOrthoMaxPerLane; ++q) gc[q] += gij * ej_v[q] * inv_j;
+    }
+  }
+  if (!BWD) {
+    if (lane == 0) partial[blockIdx.x] = acc;
   } else {
     const float coef = g[0] * scale * 4.0f / (static_cast<float>(H) * M * M);
-    for (int i = wave; i < M; i += 4) {
-      // gc = coef * sum_j gram[i][j] c_j ;  ge = (gc - c_i <gc, c_i>) * inv_i
-      float dotp = 0.f;
-      for (int c = lane; c < Dc; c += 64) {
-        float gc = 0.f;
-        for (int j = 0; j < M; ++j) gc += gram[i * M + j] * cn[j * Dc + c];
-        dotp += gc * cn[i * Dc + c];
-      }
-      dotp = wave_sum(dotp);
-      float* ge = g_embed + (static_cast<int64_t>(h) * K + ids[i]) * Dc;
-      for (int c = lane; c < Dc; c += 64) {
-        float gc = 0.f;
-        for (int j = 0; j < M; ++j) gc += gram[i * M + j] * cn[j * Dc + c];
-        ge[c] = coef * (gc - cn[i * Dc + c] * dotp) * inv[i];
-      }
+    float dotp = 0.f;
+#pragma unroll
+    for (int q = 0; q < kOrthoMaxPerLane; ++q) dotp += gc[q] * ci[q];
+    dotp = wave_sum(dotp);
+    float* ge = g_embed + (static_cast<int64_t>(h) * K + ids[i]) * Dc;
+#pragma unroll
+    for (int q = 0; q < kOrthoMaxPerLane; ++q) {
+      const int c = lane + 64 * q;
+      if (c < Dc) ge[c] = coef * (gc[q] - ci[q] * dotp) * inv_i;
     }
-  }
-}
-
-__global__ void k_ortho_finish(const float* __restrict__ partial, int H, int M, float scale, float* __restrict__ loss) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    double s = 0.0;
-    for (int h = 0; h < H; ++h) s += partial[h];
-    loss[0] = static_cast<float>(s / (static_cast<double>(H) * M * M) - 1.0 / M) * scale;
   }
 }
 
@@ -175,9 +186,24 @@ using namespace stemgnn;
 
 extern "C" {
 
-int stemgnn_mse_loss_fwd(const float* pred, const float* target, int64_t n, float scale, float* loss, void* stream_) {
-  if (n < 0 || !loss || (n > 0 && (!pred || !target))) return STEMGNN_ERR_INVALID_ARG;
-  k_mse_fwd<<<1, kRed, 0, static_cast<hipStream_t>(stream_)>>>(pred, target, n, scale, loss);
+size_t stemgnn_loss_workspace_bytes(int64_t n) {
+  // mse: <= 256 block partials; cosine: one double per row; ortho: one per (head, id)
+  return static_cast<size_t>(n < 256 ? 256 : n) * sizeof(double) + 512;
+}
+
+int stemgnn_mse_loss_fwd(const float* pred, const float* target, int64_t n, float scale, float* loss, void* workspace,
+                         size_t workspace_bytes, void* stream_) {
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  if (n < 0 || !loss || !workspace || (n > 0 && (!pred || !target))) return STEMGNN_ERR_INVALID_ARG;
+  if (workspace_bytes < stemgnn_loss_workspace_bytes(256)) return STEMGNN_ERR_WORKSPACE;
+  double* partial = reinterpret_cast<double*>(align_up(reinterpret_cast<uintptr_t>(workspace), 256));
+  int64_t blocks = (n / 4 + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 256) blocks = 256;
+  k_mse_partial<<<static_cast<unsigned>(blocks), 256, 0, st>>>(pred, target, n, partial);
+  STEMGNN_LAUNCH_CHECK();
+  k_finish_sum<<<1, 256, 0, st>>>(partial, static_cast<int>(blocks), static_cast<double>(scale) / (n > 0 ? n : 1), 0.0,
+                                  loss);
   STEMGNN_LAUNCH_CHECK();
   return STEMGNN_OK;
 }
@@ -196,9 +222,18 @@ int stemgnn_mse_loss_bwd(const float* pred, const float* target, int64_t n, floa
 }
 
 int stemgnn_cosine_loss_fwd(const float* z, const float* h, int64_t rows, int64_t dim, float scale, float* loss,
-                            float* save, void* stream_) {
-  if (rows < 0 || dim <= 0 || !loss || (rows > 0 && (!z || !h || !save))) return STEMGNN_ERR_INVALID_ARG;
-  k_cos_fwd<<<1, kRed, 0, static_cast<hipStream_t>(stream_)>>>(z, h, rows, static_cast<int>(dim), scale, loss, save);
+                            float* save, void* workspace, size_t workspace_bytes, void* stream_) {
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  if (rows < 0 || dim <= 0 || !loss || !workspace || (rows > 0 && (!z || !h || !save))) return STEMGNN_ERR_INVALID_ARG;
+  if (rows >= (1 << 30)) return STEMGNN_ERR_TOO_LARGE;
+  if (workspace_bytes < stemgnn_loss_workspace_bytes(rows)) return STEMGNN_ERR_WORKSPACE;
+  double* row_loss = reinterpret_cast<double*>(align_up(reinterpret_cast<uintptr_t>(workspace), 256));
+  if (rows > 0) {
+    k_cos_rows<<<static_cast<unsigned>((rows + 3) / 4), 256, 0, st>>>(z, h, rows, static_cast<int>(dim), save, row_loss);
+    STEMGNN_LAUNCH_CHECK();
+  }
+  k_finish_sum<<<1, 256, 0, st>>>(row_loss, static_cast<int>(rows), static_cast<double>(scale) / (rows > 0 ? rows : 1),
+                                  0.0, loss);
   STEMGNN_LAUNCH_CHECK();
   return STEMGNN_OK;
 }
@@ -214,36 +249,22 @@ int stemgnn_cosine_loss_bwd(const float* z, const float* h, int64_t rows, int64_
   return STEMGNN_OK;
 }
 
-size_t stemgnn_ortho_loss_workspace_bytes(int64_t heads) { return heads > 0 ? static_cast<size_t>(heads) * 4 + 256 : 0; }
-
-static size_t ortho_lds(int64_t M, int64_t Dc) { return static_cast<size_t>(M * Dc + M * M + M) * sizeof(float); }
-
 int stemgnn_ortho_loss_fwd(const float* embed, const int64_t* ids, int64_t heads, int64_t codebook_size,
                            int64_t code_dim, int64_t num_ids, float scale, float* loss, void* workspace,
                            size_t workspace_bytes, void* stream_) {
   hipStream_t st = static_cast<hipStream_t>(stream_);
-  if (heads <= 0 || codebook_size <= 0 || code_dim <= 0 || num_ids <= 0 || !embed || !ids || !loss || !workspace)
+  if (heads <= 0 || codebook_size <= 0 || code_dim <= 0 || code_dim > 64 * kOrthoMaxPerLane || num_ids <= 0 ||
+      heads * num_ids > (1 << 20) || !embed || !ids || !loss || !workspace)
     return STEMGNN_ERR_INVALID_ARG;
-  if (ortho_lds(num_ids, code_dim) > 150 * 1024) return STEMGNN_ERR_INVALID_ARG;
-  if (workspace_bytes < stemgnn_ortho_loss_workspace_bytes(heads)) return STEMGNN_ERR_WORKSPACE;
-  float* partial = reinterpret_cast<float*>(align_up(reinterpret_cast<uintptr_t>(workspace), 256));
-  const size_t lds = ortho_lds(num_ids, code_dim);
-  if (lds > 64 * 1024) {
-    static bool configured = false;
-    if (!configured) {
-      STEMGNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ortho<false>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-      STEMGNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ortho<true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-      configured = true;
-    }
-  }
-  k_ortho<false><<<static_cast<unsigned>(heads), 256, lds, st>>>(embed, ids, static_cast<int>(heads),
-                                                                 static_cast<int>(codebook_size),
-                                                                 static_cast<int>(code_dim), static_cast<int>(num_ids),
-                                                                 scale, nullptr, partial, nullptr);
+  if (workspace_bytes < stemgnn_loss_workspace_bytes(heads * num_ids)) return STEMGNN_ERR_WORKSPACE;
+  double* partial = reinterpret_cast<double*>(align_up(reinterpret_cast<uintptr_t>(workspace), 256));
+  const int H = static_cast<int>(heads), M = static_cast<int>(num_ids);
+  k_ortho<false><<<static_cast<unsigned>(H * M), 64, 0, st>>>(embed, ids, H, static_cast<int>(codebook_size),
+                                                              static_cast<int>(code_dim), M, scale, nullptr, partial,
+                                                              nullptr);
   STEMGNN_LAUNCH_CHECK();
-  k_ortho_finish<<<1, 64, 0, st>>>(partial, static_cast<int>(heads), static_cast<int>(num_ids), scale, loss);
+  k_finish_sum<<<1, 256, 0, st>>>(partial, H * M, static_cast<double>(scale) / (static_cast<double>(H) * M * M),
+                                  -static_cast<double>(scale) / M, loss);
   STEMGNN_LAUNCH_CHECK();
   return STEMGNN_OK;
 }
@@ -252,13 +273,14 @@ int stemgnn_ortho_loss_bwd(const float* embed, const int64_t* ids, int64_t heads
                            int64_t code_dim, int64_t num_ids, float scale, const float* g_loss, float* g_embed,
                            void* stream_) {
   hipStream_t st = static_cast<hipStream_t>(stream_);
-  if (heads <= 0 || codebook_size <= 0 || code_dim <= 0 || num_ids <= 0 || !embed || !ids || !g_loss || !g_embed)
+  if (heads <= 0 || codebook_size <= 0 || code_dim <= 0 || code_dim > 64 * kOrthoMaxPerLane || num_ids <= 0 ||
+      !embed || !ids || !g_loss || !g_embed)
     return STEMGNN_ERR_INVALID_ARG;
-  if (ortho_lds(num_ids, code_dim) > 150 * 1024) return STEMGNN_ERR_INVALID_ARG;
   STEMGNN_HIP_TRY(hipMemsetAsync(g_embed, 0, sizeof(float) * heads * codebook_size * code_dim, st));
-  k_ortho<true><<<static_cast<unsigned>(heads), 256, ortho_lds(num_ids, code_dim), st>>>(
-      embed, ids, static_cast<int>(heads), static_cast<int>(codebook_size), static_cast<int>(code_dim),
-      static_cast<int>(num_ids), scale, g_loss, nullptr, g_embed);
+  const int H = static_cast<int>(heads), M = static_cast<int>(num_ids);
+  k_ortho<true><<<static_cast<unsigned>(H * M), 64, 0, st>>>(embed, ids, H, static_cast<int>(codebook_size),
+                                                             static_cast<int>(code_dim), M, scale, g_loss, nullptr,
+                                                             g_embed);
   STEMGNN_LAUNCH_CHECK();
   return STEMGNN_OK;
 }

@@ -663,7 +663,9 @@ class MseLossFn(torch.autograd.Function):
         if pred.shape != target.shape:
             raise RuntimeError(f"mse_loss: shape mismatch {tuple(pred.shape)} vs {tuple(target.shape)}")
         loss = torch.empty(1, dtype=torch.float32, device=pred.device)
-        check(lib.stemgnn_mse_loss_fwd(_p(pred), _p(target), pred.numel(), 1.0, _p(loss), _stream()), "mse_loss_fwd")
+        ws = _workspace(lib.stemgnn_loss_workspace_bytes(256), pred.device)
+        check(lib.stemgnn_mse_loss_fwd(_p(pred), _p(target), pred.numel(), 1.0, _p(loss), _p(ws), ws.numel(), _stream()),
+              "mse_loss_fwd")
         ctx.save_for_backward(pred, target)
         return loss.view(())
 
@@ -688,7 +690,9 @@ class CosineLossFn(torch.autograd.Function):
         rows, D = h.shape
         loss = torch.empty(1, dtype=torch.float32, device=h.device)
         save = torch.empty(max(rows, 1), 3, dtype=torch.float32, device=h.device)
-        check(lib.stemgnn_cosine_loss_fwd(_p(z), _p(h), rows, D, 1.0, _p(loss), _p(save), _stream()), "cosine_loss_fwd")
+        ws = _workspace(lib.stemgnn_loss_workspace_bytes(rows), h.device)
+        check(lib.stemgnn_cosine_loss_fwd(_p(z), _p(h), rows, D, 1.0, _p(loss), _p(save), _p(ws), ws.numel(), _stream()),
+              "cosine_loss_fwd")
         ctx.save_for_backward(z, h, save)
         return loss.view(())
 
@@ -711,7 +715,7 @@ class OrthoLossFn(torch.autograd.Function):
         ids = _req(ids.contiguous(), torch.int64, "ids", 1)
         H, K, Dc = e.shape
         loss = torch.empty(1, dtype=torch.float32, device=e.device)
-        ws = _workspace(lib.stemgnn_ortho_loss_workspace_bytes(H), e.device)
+        ws = _workspace(lib.stemgnn_loss_workspace_bytes(H * ids.numel()), e.device)
         check(lib.stemgnn_ortho_loss_fwd(_p(e), _p(ids), H, K, Dc, ids.numel(), float(weight), _p(loss), _p(ws),
                                          ws.numel(), _stream()), "ortho_loss_fwd")
         ctx.save_for_backward(e, ids)
