@@ -172,6 +172,35 @@ int stemgnn_mean_agg_fwd(const float* x, int64_t num_nodes, int64_t dim, const i
 int stemgnn_mean_agg_bwd(const float* g_agg, int64_t num_nodes, int64_t dim, const int32_t* rowptr_t,
                          const int32_t* dst_t, const float* inv_deg, float* g_x, void* stream);
 
+/* K1 / K2 on skewed graphs: rows with more than `heavy_above` edges (hubs) are cut into chunks of
+ * `chunk` edges, reduced by separate groups into `partial` rows and summed per row in chunk order
+ * (bit-reproducible).  Same operands and results (to fp32 summation order) as
+ * stemgnn_sage_agg_fwd/bwd; relu = 0 gives the plain mean of stemgnn_mean_agg_fwd/bwd (pass NULL
+ * edge operands; x may be NULL in the backward).  num_edges bounds the CSR's live edge count.
+ * Caller-allocated plan buffers, sized so they cannot overflow:
+ *   cap_items >= 2*(num_edges/chunk) + 2 : item_row, item_beg [cap_items], partial [cap_items, dim]
+ *   cap_heavy >=    num_edges/chunk  + 1 : heavy_row [cap_heavy], heavy_span [cap_heavy, 2]
+ *   counts [2]
+ * build_plan != 0: the call fills the plan from rowptr as it goes; 0: reuse the plan an earlier
+ * call over the SAME rowptr/chunk/heavy_above filled.  heavy_above >= chunk > 0. */
+int stemgnn_sage_agg_fwd_split(const float* x, int64_t num_nodes, int64_t dim, int64_t num_edges,
+                               const int32_t* rowptr, const int32_t* src, const int32_t* eid,
+                               const float* edge_attr, const float* etab, const int32_t* etype_slot,
+                               int64_t num_types, float* agg, int32_t relu,
+                               int32_t chunk, int32_t heavy_above, int32_t build_plan,
+                               int64_t cap_items, int64_t cap_heavy,
+                               int32_t* item_row, int32_t* item_beg, int32_t* heavy_row, int32_t* heavy_span,
+                               int32_t* counts, float* partial, void* stream);
+int stemgnn_sage_agg_bwd_split(const float* g_agg, const float* x, int64_t num_nodes, int64_t dim, int64_t num_edges,
+                               const int32_t* rowptr_t, const int32_t* dst_t, const int32_t* eid_t,
+                               const float* inv_deg,
+                               const float* edge_attr, const float* etab, const int32_t* etype_slot_t,
+                               int64_t num_types, float* g_x, int32_t relu,
+                               int32_t chunk, int32_t heavy_above, int32_t build_plan,
+                               int64_t cap_items, int64_t cap_heavy,
+                               int32_t* item_row, int32_t* item_beg, int32_t* heavy_row, int32_t* heavy_span,
+                               int32_t* counts, float* partial, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * K4: BatchNorm1d (training statistics) + ReLU/LeakyReLU + Dropout
  * (model/encoder.py:173,313-317).

@@ -30,6 +30,7 @@ lib = _load()
 
 P = c_void_p
 I64 = c_int64
+I32 = ctypes.c_int32
 
 _SIGNATURES = {
     "stemgnn_abi_version": (c_int, []),
@@ -53,6 +54,10 @@ _SIGNATURES = {
     "stemgnn_group_by_key": (c_int, [P, I64, I64, P, P, P, c_size_t, P]),
     "stemgnn_sage_agg_fwd": (c_int, [P, I64, I64, P, P, P, P, P, P, I64, P, P]),
     "stemgnn_sage_agg_bwd": (c_int, [P, P, I64, I64, P, P, P, P, P, P, P, I64, P, P]),
+    "stemgnn_sage_agg_fwd_split": (c_int, [P, I64, I64, I64, P, P, P, P, P, P, I64, P, I32, I32, I32, I32, I64, I64,
+                                           P, P, P, P, P, P, P]),
+    "stemgnn_sage_agg_bwd_split": (c_int, [P, P, I64, I64, I64, P, P, P, P, P, P, P, I64, P, I32, I32, I32, I32, I64,
+                                           I64, P, P, P, P, P, P, P]),
     "stemgnn_mean_agg_fwd": (c_int, [P, I64, I64, P, P, P, P]),
     "stemgnn_mean_agg_bwd": (c_int, [P, I64, I64, P, P, P, P, P]),
     "stemgnn_profile_k1": (c_int, [c_int]),

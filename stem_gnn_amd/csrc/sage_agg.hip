@@ -43,13 +43,53 @@ __device__ inline void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) =
 __device__ inline float relu_keep_nan(float v) { return v < 0.f ? 0.f : v; }
 __device__ inline float msg(float v, int relu) { return relu ? relu_keep_nan(v) : v; }
 
-constexpr int kRowsPerGroup = 1;  // measured: 2 and 4 rows per group are slower (fewer groups in flight)
 
 // Load the edge-type table [T, D] into LDS (all threads of the block).
 __device__ inline void stage_table(float* lds, const float* __restrict__ etab, int64_t T, int64_t D) {
   const int64_t n4 = T * D / 4;
   for (int64_t i = threadIdx.x; i < n4; i += kBlock) st4(lds + 4 * i, ld4(etab + 4 * i));
   __syncthreads();
+}
+
+// Heavy rows (hubs of a skewed graph) are not walked by one group: they are cut into chunks of
+// `chunk` edges that separate groups reduce into partial rows, summed per row in chunk order by a
+// combine pass (deterministic: only the PLACE of a row's items in the list depends on atomics).
+// The same kernels serve both passes.  ROW mode: rows with more than `skip_above` edges are
+// skipped, and with `fill` set the skipping group appends the row's chunk items to the plan.
+// ITEM mode (`items` set): a group's unit of work is one chunk, its output an unscaled partial row.
+struct SplitArgs {
+  int32_t* item_row;    // [cap_items]
+  int32_t* item_beg;    // [cap_items] first CSR slot of the chunk
+  int32_t* heavy_row;   // [cap_heavy]
+  int32_t* heavy_span;  // [cap_heavy][2] first item, item count
+  int32_t* counts;      // counts[0] = items, counts[1] = heavy rows
+  float* partial;       // [cap_items][D]
+  int chunk;
+  int skip_above;
+  int fill;
+  int items;
+};
+
+inline SplitArgs no_split() {
+  return SplitArgs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0x7fffffff, 0, 0};
+}
+
+template <int G>
+__device__ __forceinline__ void plan_append(const SplitArgs& sp, int row, int beg, int deg, int lane) {
+  const int n = (deg + sp.chunk - 1) / sp.chunk;
+  int i0 = 0, h = 0;
+  if (lane == 0) {
+    i0 = atomicAdd(sp.counts, n);
+    h = atomicAdd(sp.counts + 1, 1);
+    sp.heavy_row[h] = row;
+    sp.heavy_span[2 * h] = i0;
+    sp.heavy_span[2 * h + 1] = n;
+  }
+  i0 = __shfl(i0, 0, G);
+  for (int c = lane; c < n; c += G) {
+    sp.item_row[i0 + c] = row;
+    sp.item_beg[i0 + c] = beg + c * sp.chunk;
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -60,26 +100,39 @@ __global__ void __launch_bounds__(kBlock)
 k_sage_agg_fwd(const float* __restrict__ x, int64_t N, int D, const int32_t* __restrict__ rowptr,
                const int32_t* __restrict__ src, const int32_t* __restrict__ aux,  // eid (dense) or etype per slot
                const float* __restrict__ edge_attr, const float* __restrict__ etab, int64_t T,
-               float* __restrict__ agg, int relu) {
+               float* __restrict__ agg, int relu, SplitArgs sp) {
   extern __shared__ __attribute__((aligned(16))) float lds_tab[];
   if (MODE == kTableLds) stage_table(lds_tab, etab, T, D);
 
   constexpr int kGroups = kBlock / G;
-  constexpr int R = kRowsPerGroup;                  // consecutive destination rows per group
   constexpr int U = V <= 3 ? 4 : (V == 4 ? 2 : 1);  // neighbour rows in flight per group (8 measured slower)
   const int lane = threadIdx.x % G;
   const int group = threadIdx.x / G;
-  const int64_t row0 = (static_cast<int64_t>(blockIdx.x) * kGroups + group) * R;
-  if (row0 >= N) return;
+  const int64_t unit = static_cast<int64_t>(blockIdx.x) * kGroups + group;
   const int nvec = D / 4;
-  // one coalesced read of the R+1 segment offsets, then broadcast (G >= 8 > R)
-  int my_ptr = 0;
-  if (lane <= R && row0 + lane <= N) my_ptr = rowptr[row0 + lane];
-
-  for (int rr = 0; rr < R; ++rr) {
-    const int64_t row = row0 + rr;
-    const int beg = __shfl(my_ptr, rr, G), end = __shfl(my_ptr, rr + 1, G);
-    if (row >= N) break;
+  {
+    int beg, end;
+    float* out;
+    float inv;
+    if (sp.items) {  // ITEM mode: one chunk of a heavy row -> unscaled partial row
+      if (unit >= sp.counts[0]) return;
+      const int r = sp.item_row[unit];
+      beg = sp.item_beg[unit];
+      end = min(beg + sp.chunk, rowptr[r + 1]);
+      out = sp.partial + unit * D;
+      inv = 1.0f;
+    } else {
+      if (unit >= N) return;
+      beg = rowptr[unit];
+      end = rowptr[unit + 1];
+      if (end - beg > sp.skip_above) {  // left to the item + combine passes
+        if (sp.fill) plan_append<G>(sp, static_cast<int>(unit), beg, end - beg, lane);
+        return;
+      }
+      out = agg + unit * D;
+      const int deg = end - beg;
+      inv = 1.0f / static_cast<float>(deg < 1 ? 1 : deg);
+    }
     float4 acc[V];
 #pragma unroll
     for (int v = 0; v < V; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -127,13 +180,59 @@ k_sage_agg_fwd(const float* __restrict__ x, int64_t N, int D, const int32_t* __r
         }
       }
     }
-    const int deg = end - beg;
-    const float inv = 1.0f / static_cast<float>(deg < 1 ? 1 : deg);
-    float* out = agg + row * D;
 #pragma unroll
     for (int v = 0; v < V; ++v) {
       const int c = lane + G * v;
       if (c < nvec) st4(out + 4 * c, make_float4(acc[v].x * inv, acc[v].y * inv, acc[v].z * inv, acc[v].w * inv));
+    }
+  }
+}
+
+// out[heavy_row[h]] = scale * sum of the row's chunk partials.  One block per heavy row: kBlock/G
+// sub-groups each sum a strided subset of the partials (in order), then sub-group 0 adds the
+// kBlock/G sub-sums from LDS in index order -> the same bits on every run.
+template <int G>
+__global__ void __launch_bounds__(kBlock)
+k_split_combine(const float* __restrict__ partial, const int32_t* __restrict__ heavy_row,
+                const int32_t* __restrict__ heavy_span, const int32_t* __restrict__ counts,
+                const int32_t* __restrict__ rowptr, int D, int mean, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float lds_sub[];  // [S][D]
+  constexpr int S = kBlock / G;
+  const int h = blockIdx.x;
+  if (h >= counts[1]) return;
+  const int lane = threadIdx.x % G, sub = threadIdx.x / G;
+  const int row = heavy_row[h];
+  const int i0 = heavy_span[2 * h], i1 = i0 + heavy_span[2 * h + 1];
+  const int nvec = D / 4;
+  for (int c = lane; c < nvec; c += G) {
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    int i = i0 + sub;
+    for (; i + 3 * S < i1; i += 4 * S) {
+      const float4 v0 = ld4(partial + static_cast<int64_t>(i) * D + 4 * c);
+      const float4 v1 = ld4(partial + static_cast<int64_t>(i + S) * D + 4 * c);
+      const float4 v2 = ld4(partial + static_cast<int64_t>(i + 2 * S) * D + 4 * c);
+      const float4 v3 = ld4(partial + static_cast<int64_t>(i + 3 * S) * D + 4 * c);
+      a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w;
+      a.x += v1.x; a.y += v1.y; a.z += v1.z; a.w += v1.w;
+      a.x += v2.x; a.y += v2.y; a.z += v2.z; a.w += v2.w;
+      a.x += v3.x; a.y += v3.y; a.z += v3.z; a.w += v3.w;
+    }
+    for (; i < i1; i += S) {
+      const float4 v = ld4(partial + static_cast<int64_t>(i) * D + 4 * c);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    st4(lds_sub + static_cast<int64_t>(sub) * D + 4 * c, a);
+  }
+  __syncthreads();
+  if (sub == 0) {
+    const float scale = mean ? 1.0f / static_cast<float>(rowptr[row + 1] - rowptr[row]) : 1.0f;
+    for (int c = lane; c < nvec; c += G) {
+      float4 a = ld4(lds_sub + 4 * c);
+      for (int k = 1; k < S; ++k) {
+        const float4 v = ld4(lds_sub + static_cast<int64_t>(k) * D + 4 * c);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+      }
+      st4(out + static_cast<int64_t>(row) * D + 4 * c, make_float4(a.x * scale, a.y * scale, a.z * scale, a.w * scale));
     }
   }
 }
@@ -148,19 +247,36 @@ k_sage_agg_bwd(const float* __restrict__ g_agg, const float* __restrict__ x, int
                const int32_t* __restrict__ rowptr_t, const int32_t* __restrict__ dst_t,
                const int32_t* __restrict__ aux, const float* __restrict__ inv_deg,
                const float* __restrict__ edge_attr, const float* __restrict__ etab, int64_t T,
-               float* __restrict__ g_x, int relu) {
+               float* __restrict__ g_x, int relu, SplitArgs sp) {
   extern __shared__ __attribute__((aligned(16))) float lds_tab[];
   if (MODE == kTableLds) stage_table(lds_tab, etab, T, D);
 
   constexpr int kGroups = kBlock / G;
   const int lane = threadIdx.x % G;
   const int group = threadIdx.x / G;
-  const int64_t row = static_cast<int64_t>(blockIdx.x) * kGroups + group;
-  if (row >= N) return;
+  const int64_t unit = static_cast<int64_t>(blockIdx.x) * kGroups + group;
   const int nvec = D / 4;
-
   constexpr int U = V <= 3 ? 4 : (V == 4 ? 2 : 1);
-  const int beg = rowptr_t[row], end = rowptr_t[row + 1];
+  int64_t row;
+  int beg, end;
+  float* out;
+  if (sp.items) {  // ITEM mode (see SplitArgs)
+    if (unit >= sp.counts[0]) return;
+    row = sp.item_row[unit];
+    beg = sp.item_beg[unit];
+    end = min(beg + sp.chunk, rowptr_t[row + 1]);
+    out = sp.partial + unit * D;
+  } else {
+    if (unit >= N) return;
+    row = unit;
+    beg = rowptr_t[row];
+    end = rowptr_t[row + 1];
+    if (end - beg > sp.skip_above) {
+      if (sp.fill) plan_append<G>(sp, static_cast<int>(row), beg, end - beg, lane);
+      return;
+    }
+    out = g_x + row * D;
+  }
   float4 acc[V], xs[V];
 #pragma unroll
   for (int v = 0; v < V; ++v) {
@@ -216,7 +332,6 @@ k_sage_agg_bwd(const float* __restrict__ g_agg, const float* __restrict__ x, int
       }
     }
   }
-  float* out = g_x + row * D;
 #pragma unroll
   for (int v = 0; v < V; ++v) {
     const int c = lane + G * v;
@@ -246,11 +361,11 @@ inline bool pick_geometry(int64_t D, Geometry* g) {
 template <int G, int V, int MODE>
 int launch_fwd_one(size_t lds, dim3 grid, hipStream_t st, const float* x, int64_t N, int D, const int32_t* rowptr,
                    const int32_t* src, const int32_t* aux, const float* ea, const float* etab, int64_t T,
-                   float* agg, int relu) {
+                   float* agg, int relu, SplitArgs sp) {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   {
     std::lock_guard<std::mutex> lock(g_k1_profile.mu);
-    if (g_k1_profile.enabled) {
+    if (g_k1_profile.enabled && !sp.items) {
       STEMGNN_HIP_TRY(hipEventCreate(&ev0));
       STEMGNN_HIP_TRY(hipEventCreate(&ev1));
       g_k1_profile.events.emplace_back(ev0, ev1);
@@ -258,9 +373,9 @@ int launch_fwd_one(size_t lds, dim3 grid, hipStream_t st, const float* x, int64_
   }
   if (ev0) {
     hipExtLaunchKernelGGL((k_sage_agg_fwd<G, V, MODE>), grid, dim3(kBlock), lds, st, ev0, ev1, 0, x, N, D, rowptr, src,
-                          aux, ea, etab, T, agg, relu);
+                          aux, ea, etab, T, agg, relu, sp);
   } else {
-    k_sage_agg_fwd<G, V, MODE><<<grid, kBlock, lds, st>>>(x, N, D, rowptr, src, aux, ea, etab, T, agg, relu);
+    k_sage_agg_fwd<G, V, MODE><<<grid, kBlock, lds, st>>>(x, N, D, rowptr, src, aux, ea, etab, T, agg, relu, sp);
   }
   STEMGNN_LAUNCH_CHECK();
   return STEMGNN_OK;
@@ -269,24 +384,24 @@ int launch_fwd_one(size_t lds, dim3 grid, hipStream_t st, const float* x, int64_
 template <int G, int V>
 int launch_fwd_mode(int mode, size_t lds, dim3 grid, hipStream_t st, const float* x, int64_t N, int D,
                     const int32_t* rowptr, const int32_t* src, const int32_t* aux, const float* ea,
-                    const float* etab, int64_t T, float* agg, int relu) {
+                    const float* etab, int64_t T, float* agg, int relu, SplitArgs sp) {
   switch (mode) {
-    case kNoEdge: return launch_fwd_one<G, V, kNoEdge>(0, grid, st, x, N, D, rowptr, src, aux, ea, etab, T, agg, relu);
-    case kDenseEdge: return launch_fwd_one<G, V, kDenseEdge>(0, grid, st, x, N, D, rowptr, src, aux, ea, etab, T, agg, relu);
-    case kTableLds: return launch_fwd_one<G, V, kTableLds>(lds, grid, st, x, N, D, rowptr, src, aux, ea, etab, T, agg, relu);
-    default: return launch_fwd_one<G, V, kTableGlobal>(0, grid, st, x, N, D, rowptr, src, aux, ea, etab, T, agg, relu);
+    case kNoEdge: return launch_fwd_one<G, V, kNoEdge>(0, grid, st, x, N, D, rowptr, src, aux, ea, etab, T, agg, relu, sp);
+    case kDenseEdge: return launch_fwd_one<G, V, kDenseEdge>(0, grid, st, x, N, D, rowptr, src, aux, ea, etab, T, agg, relu, sp);
+    case kTableLds: return launch_fwd_one<G, V, kTableLds>(lds, grid, st, x, N, D, rowptr, src, aux, ea, etab, T, agg, relu, sp);
+    default: return launch_fwd_one<G, V, kTableGlobal>(0, grid, st, x, N, D, rowptr, src, aux, ea, etab, T, agg, relu, sp);
   }
 }
 
 template <int G, int V>
 int launch_bwd_mode(int mode, size_t lds, dim3 grid, hipStream_t st, const float* g_agg, const float* x, int64_t N,
                     int D, const int32_t* rowptr_t, const int32_t* dst_t, const int32_t* aux, const float* inv_deg,
-                    const float* ea, const float* etab, int64_t T, float* g_x, int relu) {
+                    const float* ea, const float* etab, int64_t T, float* g_x, int relu, SplitArgs sp) {
   switch (mode) {
-    case kNoEdge: k_sage_agg_bwd<G, V, kNoEdge><<<grid, kBlock, 0, st>>>(g_agg, x, N, D, rowptr_t, dst_t, aux, inv_deg, ea, etab, T, g_x, relu); break;
-    case kDenseEdge: k_sage_agg_bwd<G, V, kDenseEdge><<<grid, kBlock, 0, st>>>(g_agg, x, N, D, rowptr_t, dst_t, aux, inv_deg, ea, etab, T, g_x, relu); break;
-    case kTableLds: k_sage_agg_bwd<G, V, kTableLds><<<grid, kBlock, lds, st>>>(g_agg, x, N, D, rowptr_t, dst_t, aux, inv_deg, ea, etab, T, g_x, relu); break;
-    default: k_sage_agg_bwd<G, V, kTableGlobal><<<grid, kBlock, 0, st>>>(g_agg, x, N, D, rowptr_t, dst_t, aux, inv_deg, ea, etab, T, g_x, relu); break;
+    case kNoEdge: k_sage_agg_bwd<G, V, kNoEdge><<<grid, kBlock, 0, st>>>(g_agg, x, N, D, rowptr_t, dst_t, aux, inv_deg, ea, etab, T, g_x, relu, sp); break;
+    case kDenseEdge: k_sage_agg_bwd<G, V, kDenseEdge><<<grid, kBlock, 0, st>>>(g_agg, x, N, D, rowptr_t, dst_t, aux, inv_deg, ea, etab, T, g_x, relu, sp); break;
+    case kTableLds: k_sage_agg_bwd<G, V, kTableLds><<<grid, kBlock, lds, st>>>(g_agg, x, N, D, rowptr_t, dst_t, aux, inv_deg, ea, etab, T, g_x, relu, sp); break;
+    default: k_sage_agg_bwd<G, V, kTableGlobal><<<grid, kBlock, 0, st>>>(g_agg, x, N, D, rowptr_t, dst_t, aux, inv_deg, ea, etab, T, g_x, relu, sp); break;
   }
   STEMGNN_LAUNCH_CHECK();
   return STEMGNN_OK;
@@ -328,11 +443,57 @@ inline int resolve_mode(const float* edge_attr, const float* etab, const int32_t
 
 using namespace stemgnn;
 
+namespace {
+struct SplitPlan {  // host view of the caller's split-plan buffers (see stemgnn_sage_agg_fwd_split)
+  int chunk, heavy_above, build;
+  int64_t cap_items, cap_heavy;
+  int32_t *item_row, *item_beg, *heavy_row, *heavy_span, *counts;
+  float* partial;
+};
+
+// Capacities that can never overflow: a heavy row has more than heavy_above >= chunk edges, so there
+// are fewer than E/chunk of them and their chunk count is below E/chunk + (number of heavy rows).
+inline bool plan_ok(const SplitPlan* p, int64_t E) {
+  if (p->chunk <= 0 || p->heavy_above < p->chunk || E < 0) return false;
+  if (p->cap_heavy < E / p->chunk + 1 || p->cap_items < 2 * (E / p->chunk) + 2) return false;
+  if (!fits_i32(p->cap_items)) return false;
+  return p->item_row && p->item_beg && p->heavy_row && p->heavy_span && p->counts && p->partial;
+}
+
+inline SplitArgs split_args(const SplitPlan* plan, int pass) {
+  SplitArgs sp = no_split();
+  if (!plan) return sp;
+  sp.item_row = plan->item_row; sp.item_beg = plan->item_beg; sp.heavy_row = plan->heavy_row;
+  sp.heavy_span = plan->heavy_span; sp.counts = plan->counts; sp.partial = plan->partial;
+  sp.chunk = plan->chunk;
+  if (pass == 0) { sp.skip_above = plan->heavy_above; sp.fill = plan->build; }
+  else sp.items = 1;
+  return sp;
+}
+
+int launch_combine(const SplitPlan* p, const int32_t* rowptr, int D, int mean, float* out, hipStream_t st) {
+  const unsigned grid = static_cast<unsigned>(p->cap_heavy);
+  if (D / 4 <= 32) {
+    const size_t lds = static_cast<size_t>(kBlock / 32) * D * sizeof(float);
+    k_split_combine<32><<<grid, kBlock, lds, st>>>(p->partial, p->heavy_row, p->heavy_span, p->counts, rowptr, D,
+                                                     mean, out);
+  } else {
+    const size_t lds = static_cast<size_t>(kBlock / 64) * D * sizeof(float);
+    k_split_combine<64><<<grid, kBlock, lds, st>>>(p->partial, p->heavy_row, p->heavy_span, p->counts, rowptr, D,
+                                                     mean, out);
+  }
+  STEMGNN_LAUNCH_CHECK();
+  return STEMGNN_OK;
+}
+}  // namespace
+
 extern "C" {
 
 static int sage_agg_fwd_impl(const float* x, int64_t N, int64_t D, const int32_t* rowptr, const int32_t* src,
                              const int32_t* eid, const float* edge_attr, const float* etab,
-                             const int32_t* etype_slot, int64_t T, float* agg, int relu, void* stream_) {
+                             const int32_t* etype_slot, int64_t T, float* agg, int relu, const SplitPlan* plan,
+                             int pass, void* stream_) {
+  // pass 0: rows (heavy ones skipped when a plan is given); pass 1: chunk items of the heavy rows
   hipStream_t st = static_cast<hipStream_t>(stream_);
   Geometry geo;
   if (N < 0 || !pick_geometry(D, &geo)) return STEMGNN_ERR_INVALID_ARG;
@@ -342,22 +503,24 @@ static int sage_agg_fwd_impl(const float* x, int64_t N, int64_t D, const int32_t
   int mode; const int32_t* aux; size_t lds;
   int rc = resolve_mode(edge_attr, etab, etype_slot, eid, T, D, &mode, &aux, &lds);
   if (rc != STEMGNN_OK) return rc;
-  const int rows_per_block = (kBlock / geo.G) * kRowsPerGroup;
-  dim3 grid(static_cast<unsigned>((N + rows_per_block - 1) / rows_per_block));
+  const int groups = kBlock / geo.G;
+  const SplitArgs sp = split_args(plan, pass);
+  const int64_t units = (plan && pass == 1) ? plan->cap_items : N;
+  dim3 grid(static_cast<unsigned>((units + groups - 1) / groups));
   const int Di = static_cast<int>(D);
   STEMGNN_GEOM_DISPATCH(launch_fwd_mode, mode, lds, grid, st, x, N, Di, rowptr, src, aux, edge_attr, etab, T, agg,
-                        relu);
+                        relu, sp);
 }
 
 int stemgnn_sage_agg_fwd(const float* x, int64_t N, int64_t D, const int32_t* rowptr, const int32_t* src,
                          const int32_t* eid, const float* edge_attr, const float* etab, const int32_t* etype_slot,
                          int64_t T, float* agg, void* stream_) {
-  return sage_agg_fwd_impl(x, N, D, rowptr, src, eid, edge_attr, etab, etype_slot, T, agg, 1, stream_);
+  return sage_agg_fwd_impl(x, N, D, rowptr, src, eid, edge_attr, etab, etype_slot, T, agg, 1, nullptr, 0, stream_);
 }
 
 int stemgnn_mean_agg_fwd(const float* x, int64_t N, int64_t D, const int32_t* rowptr, const int32_t* src, float* agg,
                          void* stream_) {
-  return sage_agg_fwd_impl(x, N, D, rowptr, src, nullptr, nullptr, nullptr, nullptr, 0, agg, 0, stream_);
+  return sage_agg_fwd_impl(x, N, D, rowptr, src, nullptr, nullptr, nullptr, nullptr, 0, agg, 0, nullptr, 0, stream_);
 }
 
 int stemgnn_profile_k1(int enable) {
@@ -389,7 +552,7 @@ int stemgnn_profile_k1_collect(double* total_ms_host, int64_t* launches_host) {
 static int sage_agg_bwd_impl(const float* g_agg, const float* x, int64_t N, int64_t D, const int32_t* rowptr_t,
                              const int32_t* dst_t, const int32_t* eid_t, const float* inv_deg,
                              const float* edge_attr, const float* etab, const int32_t* etype_slot_t, int64_t T,
-                             float* g_x, int relu, void* stream_) {
+                             float* g_x, int relu, const SplitPlan* plan, int pass, void* stream_) {
   hipStream_t st = static_cast<hipStream_t>(stream_);
   Geometry geo;
   if (N < 0 || !pick_geometry(D, &geo)) return STEMGNN_ERR_INVALID_ARG;
@@ -400,24 +563,73 @@ static int sage_agg_bwd_impl(const float* g_agg, const float* x, int64_t N, int6
   int rc = resolve_mode(edge_attr, etab, etype_slot_t, eid_t, T, D, &mode, &aux, &lds);
   if (rc != STEMGNN_OK) return rc;
   const int groups = kBlock / geo.G;
-  dim3 grid(static_cast<unsigned>((N + groups - 1) / groups));
+  const SplitArgs sp = split_args(plan, pass);
+  const int64_t units = (plan && pass == 1) ? plan->cap_items : N;
+  dim3 grid(static_cast<unsigned>((units + groups - 1) / groups));
   const int Di = static_cast<int>(D);
   STEMGNN_GEOM_DISPATCH(launch_bwd_mode, mode, lds, grid, st, g_agg, x, N, Di, rowptr_t, dst_t, aux, inv_deg,
-                        edge_attr, etab, T, g_x, relu);
+                        edge_attr, etab, T, g_x, relu, sp);
 }
 
 int stemgnn_sage_agg_bwd(const float* g_agg, const float* x, int64_t N, int64_t D, const int32_t* rowptr_t,
                          const int32_t* dst_t, const int32_t* eid_t, const float* inv_deg, const float* edge_attr,
                          const float* etab, const int32_t* etype_slot_t, int64_t T, float* g_x, void* stream_) {
   return sage_agg_bwd_impl(g_agg, x, N, D, rowptr_t, dst_t, eid_t, inv_deg, edge_attr, etab, etype_slot_t, T, g_x, 1,
-                           stream_);
+                           nullptr, 0, stream_);
 }
 
 int stemgnn_mean_agg_bwd(const float* g_agg, int64_t N, int64_t D, const int32_t* rowptr_t, const int32_t* dst_t,
                          const float* inv_deg, float* g_x, void* stream_) {
   // the relu mask is not evaluated: x is only dereferenced for rows with out-edges, any valid [N, D] buffer serves
   return sage_agg_bwd_impl(g_agg, g_agg, N, D, rowptr_t, dst_t, nullptr, inv_deg, nullptr, nullptr, nullptr, 0, g_x, 0,
-                           stream_);
+                           nullptr, 0, stream_);
+}
+
+// ---- heavy-row splitting ---------------------------------------------------------------------
+static int plan_begin(const SplitPlan* plan, int64_t E, hipStream_t st) {
+  if (!plan_ok(plan, E)) return STEMGNN_ERR_INVALID_ARG;
+  if (plan->build) STEMGNN_HIP_TRY(hipMemsetAsync(plan->counts, 0, 2 * sizeof(int32_t), st));
+  return STEMGNN_OK;
+}
+
+int stemgnn_sage_agg_fwd_split(const float* x, int64_t N, int64_t D, int64_t E, const int32_t* rowptr,
+                               const int32_t* src, const int32_t* eid, const float* edge_attr, const float* etab,
+                               const int32_t* etype_slot, int64_t T, float* agg, int32_t relu, int32_t chunk,
+                               int32_t heavy_above, int32_t build_plan, int64_t cap_items, int64_t cap_heavy,
+                               int32_t* item_row, int32_t* item_beg, int32_t* heavy_row, int32_t* heavy_span,
+                               int32_t* counts, float* partial, void* stream_) {
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  SplitPlan plan{chunk, heavy_above, build_plan, cap_items, cap_heavy, item_row, item_beg, heavy_row, heavy_span,
+                 counts, partial};
+  int rc = plan_begin(&plan, E, st);
+  if (rc != STEMGNN_OK) return rc;
+  rc = sage_agg_fwd_impl(x, N, D, rowptr, src, eid, edge_attr, etab, etype_slot, T, agg, relu, &plan, 0, stream_);
+  if (rc != STEMGNN_OK || N == 0) return rc;
+  rc = sage_agg_fwd_impl(x, N, D, rowptr, src, eid, edge_attr, etab, etype_slot, T, agg, relu, &plan, 1, stream_);
+  if (rc != STEMGNN_OK) return rc;
+  return launch_combine(&plan, rowptr, static_cast<int>(D), 1, agg, st);
+}
+
+int stemgnn_sage_agg_bwd_split(const float* g_agg, const float* x, int64_t N, int64_t D, int64_t E,
+                               const int32_t* rowptr_t, const int32_t* dst_t, const int32_t* eid_t,
+                               const float* inv_deg, const float* edge_attr, const float* etab,
+                               const int32_t* etype_slot_t, int64_t T, float* g_x, int32_t relu, int32_t chunk,
+                               int32_t heavy_above, int32_t build_plan, int64_t cap_items, int64_t cap_heavy,
+                               int32_t* item_row, int32_t* item_beg, int32_t* heavy_row, int32_t* heavy_span,
+                               int32_t* counts, float* partial, void* stream_) {
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  SplitPlan plan{chunk, heavy_above, build_plan, cap_items, cap_heavy, item_row, item_beg, heavy_row, heavy_span,
+                 counts, partial};
+  int rc = plan_begin(&plan, E, st);
+  if (rc != STEMGNN_OK) return rc;
+  const float* xx = relu ? x : g_agg;  // plain mean: the kernel never reads x (see stemgnn_mean_agg_bwd)
+  rc = sage_agg_bwd_impl(g_agg, xx, N, D, rowptr_t, dst_t, eid_t, inv_deg, edge_attr, etab, etype_slot_t, T, g_x,
+                         relu, &plan, 0, stream_);
+  if (rc != STEMGNN_OK || N == 0) return rc;
+  rc = sage_agg_bwd_impl(g_agg, xx, N, D, rowptr_t, dst_t, eid_t, inv_deg, edge_attr, etab, etype_slot_t, T, g_x,
+                         relu, &plan, 1, stream_);
+  if (rc != STEMGNN_OK) return rc;
+  return launch_combine(&plan, rowptr_t, static_cast<int>(D), 0, g_x, st);
 }
 
 }  // extern "C"

@@ -112,6 +112,15 @@ class HipNeighborSampler:
         self.x, self.ntf, self.etf = x, node_text_feat, edge_text_feat
         self.local_of = ops.sampler_init_map(num_nodes, edge_index.device)
         self.seed, self.calls = int(seed), 0
+        # degree bounds of every batch, known on the host once (one sync here, none per batch): a
+        # batch node is expanded at most once, and keeps at most its full-graph out-edges
+        if num_nodes and edge_index.size(1):
+            d_in, d_out = torch.stack([(rowptr[1:] - rowptr[:-1]).max().long(),
+                                       torch.bincount(edge_index[0], minlength=1).max()]).tolist()
+        else:
+            d_in = d_out = 0
+        cap = max((f if f >= 0 else d_in) for f in self.fanouts) if self.fanouts else 0
+        self.batch_max_in_degree, self.batch_max_out_degree = int(min(cap, d_in)), int(d_out)
 
     def sample(self, seeds: Tensor) -> Batch:
         from ..graph import GraphStructure
@@ -122,7 +131,9 @@ class HipNeighborSampler:
         n_id64 = n_id.long()
         b = Batch(batch_size=seeds.numel(), n_id=n_id64, x=self.x[n_id64], edge_index=coo, xe=etype.long(),
                   node_text_feat=self.ntf, edge_text_feat=self.etf)
-        b.graph = GraphStructure.from_csr(rowptr, src, coo, nb, etype_slot=etype)
+        b.graph = GraphStructure.from_csr(rowptr, src, coo, nb, etype_slot=etype,
+                                          max_in_degree=self.batch_max_in_degree,
+                                          max_out_degree=self.batch_max_out_degree)
         return b
 
 

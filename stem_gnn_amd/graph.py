@@ -66,6 +66,11 @@ class GraphStructure:
         self.etype_slot = self.etype_slot_t = None
         self._edge_type = None
         self._edge_index = None
+        # Host-side upper bounds of the largest in/out degree (None = unknown).  Known-small bounds
+        # let the aggregation skip the heavy-row split passes (ops.SplitPlan) without a device sync.
+        self.max_in_degree: Optional[int] = None
+        self.max_out_degree: Optional[int] = None
+        self._plan_in = self._plan_out = None
         if edge_index is None:  # filled in by a factory (dropout_undirected)
             self.num_edges = 0
             self.rowptr = self.src = self.eid = self._bad = None
@@ -78,15 +83,22 @@ class GraphStructure:
         if edge_type is not None:
             self.set_edge_type(edge_type)
         if _VALIDATE if validate is None else validate:
-            bad = int(self._bad.item())
+            # one sync: the bad-entry count and, while at it, the degree bounds
+            deg_in = (self.rowptr[1:] - self.rowptr[:-1]).max().reshape(1) if self.num_nodes else self._bad.reshape(1) * 0
+            deg_out = (torch.bincount(self._edge_index[0].clamp(0, max(self.num_nodes - 1, 0)),
+                                      minlength=1).max().reshape(1) if self.num_edges else deg_in * 0)
+            bad, d_in, d_out = torch.cat([self._bad.reshape(1).long(), deg_in.long(), deg_out.long()]).tolist()
             if bad:
                 raise IndexError(f"edge_index has {bad} entries outside [0, {self.num_nodes})")
+            self.max_in_degree, self.max_out_degree = int(d_in), int(d_out)
 
     @classmethod
     def from_csr(cls, rowptr: Tensor, src: Tensor, edge_index: Tensor, num_nodes: int,
-                 etype_slot: Optional[Tensor] = None) -> "GraphStructure":
+                 etype_slot: Optional[Tensor] = None, max_in_degree: Optional[int] = None,
+                 max_out_degree: Optional[int] = None) -> "GraphStructure":
         """Adopt a by-target CSR whose slot j IS edge j of `edge_index` (what the HIP sampler emits)."""
         g = cls(None, num_nodes)
+        g.max_in_degree, g.max_out_degree = max_in_degree, max_out_degree
         g.num_edges = int(src.numel())
         g._edge_index = edge_index
         g.rowptr, g.src = rowptr, src
@@ -135,6 +147,19 @@ class GraphStructure:
             self.etype_slot_t = (ops.gather_i32(self._edge_type, self.eid_t) if self.num_edges else self._edge_type)
         return self
 
+    def split_plan(self, side: str):
+        """The heavy-row split plan for the by-target ("in") or by-source ("out") CSR, or None when
+        the host-side degree bound says no row is heavy."""
+        bound = self.max_in_degree if side == "in" else self.max_out_degree
+        if self.num_edges == 0 or (bound is not None and bound <= max(ops.SPLIT_HEAVY, ops.SPLIT_CHUNK)):
+            return None
+        if side == "out" and self.rowptr_t is self.rowptr:  # symmetric graph: one degree sequence, one plan
+            side = "in"
+        attr = "_plan_in" if side == "in" else "_plan_out"
+        if getattr(self, attr) is None:
+            setattr(self, attr, ops.SplitPlan(self.num_edges, self.rowptr.device))
+        return getattr(self, attr)
+
     def in_degree(self) -> Tensor:
         return (self.rowptr[1:] - self.rowptr[:-1]).long()
 
@@ -151,6 +176,9 @@ class GraphStructure:
         (out.rowptr, out.src, out.eid, out.etype_slot, out.dst_t, out.eid_t, out.etype_slot_t,
          out.inv_deg) = ops.graph_dropout_undirected(self, p, seed, offset, keep)
         out.rowptr_t = out.rowptr  # the augmented graph is symmetric: identical degree sequence
+        if self.max_in_degree is not None and self.max_out_degree is not None:
+            # a node keeps at most all of its in- and out-edges, each mirrored once
+            out.max_in_degree = out.max_out_degree = self.max_in_degree + self.max_out_degree
         out._edge_type = self._edge_type
         return out
 

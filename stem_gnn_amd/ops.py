@@ -5,6 +5,7 @@ is no eager/CPU fallback.
 """
 from __future__ import annotations
 
+import os
 import threading
 from ctypes import c_void_p
 from typing import Optional, Tuple
@@ -258,8 +259,14 @@ def sage_agg_fwd(x: Tensor, graph, edge_attr: Optional[Tensor], etab: Optional[T
         if etype_slot is None:
             raise RuntimeError("graph structure has no edge types; build it with edge_type=...")
     agg = torch.empty_like(x)
-    check(lib.stemgnn_sage_agg_fwd(_p(x), N, D, _p(graph.rowptr), _p(graph.src), _p(graph.eid), _p(edge_attr),
-                                   _p(etab), _p(etype_slot), T, _p(agg), _stream()), "sage_agg_fwd")
+    plan = graph.split_plan("in")
+    if plan is None:
+        check(lib.stemgnn_sage_agg_fwd(_p(x), N, D, _p(graph.rowptr), _p(graph.src), _p(graph.eid), _p(edge_attr),
+                                       _p(etab), _p(etype_slot), T, _p(agg), _stream()), "sage_agg_fwd")
+    else:
+        check(lib.stemgnn_sage_agg_fwd_split(_p(x), N, D, graph.num_edges, _p(graph.rowptr), _p(graph.src),
+                                             _p(graph.eid), _p(edge_attr), _p(etab), _p(etype_slot), T, _p(agg), 1,
+                                             *plan.args(D, x.device), _stream()), "sage_agg_fwd_split")
     if k1_timer.enabled:
         mode = "dense" if edge_attr is not None else ("table" if etab is not None else "none")
         k1_timer.bytes.append((N, graph, D, mode, T))  # edge counts are resolved after the timed region
@@ -274,11 +281,46 @@ def sage_agg_bwd(g_agg: Tensor, x: Tensor, graph, edge_attr: Optional[Tensor], e
         edge_attr = etab = None
     T = 0 if etab is None else etab.size(0)
     g_x = torch.empty_like(x)
-    check(lib.stemgnn_sage_agg_bwd(_p(g_agg), _p(x), N, D, _p(graph.rowptr_t), _p(graph.dst_t), _p(graph.eid_t),
-                                   _p(graph.inv_deg), _p(edge_attr), _p(etab),
-                                   _p(graph.etype_slot_t if etab is not None else None), T, _p(g_x), _stream()),
-          "sage_agg_bwd")
+    ets = graph.etype_slot_t if etab is not None else None
+    plan = graph.split_plan("out")
+    if plan is None:
+        check(lib.stemgnn_sage_agg_bwd(_p(g_agg), _p(x), N, D, _p(graph.rowptr_t), _p(graph.dst_t), _p(graph.eid_t),
+                                       _p(graph.inv_deg), _p(edge_attr), _p(etab), _p(ets), T, _p(g_x), _stream()),
+              "sage_agg_bwd")
+    else:
+        check(lib.stemgnn_sage_agg_bwd_split(_p(g_agg), _p(x), N, D, graph.num_edges, _p(graph.rowptr_t),
+                                             _p(graph.dst_t), _p(graph.eid_t), _p(graph.inv_deg), _p(edge_attr),
+                                             _p(etab), _p(ets), T, _p(g_x), 1, *plan.args(D, x.device), _stream()),
+              "sage_agg_bwd_split")
     return g_x
+
+
+SPLIT_CHUNK = int(os.environ.get("STEMGNN_SPLIT_CHUNK", "64"))    # edges per work item of a heavy row
+SPLIT_HEAVY = int(os.environ.get("STEMGNN_SPLIT_HEAVY", "128"))   # rows with more edges than this are split
+
+
+class SplitPlan:
+    """Device buffers of the heavy-row split plan of one CSR (include/stemgnn.h: stemgnn_sage_agg_fwd_split).
+    The first aggregation call over the CSR fills it on the device; later calls reuse it."""
+
+    def __init__(self, num_edges: int, device):
+        self.chunk, self.heavy = SPLIT_CHUNK, max(SPLIT_HEAVY, SPLIT_CHUNK)
+        self.cap_items = 2 * (num_edges // self.chunk) + 2
+        self.cap_heavy = num_edges // self.chunk + 1
+        i32 = dict(dtype=torch.int32, device=device)
+        self.item_row = torch.empty(self.cap_items, **i32)
+        self.item_beg = torch.empty(self.cap_items, **i32)
+        self.heavy_row = torch.empty(self.cap_heavy, **i32)
+        self.heavy_span = torch.empty(self.cap_heavy, 2, **i32)
+        self.counts = torch.zeros(2, **i32)
+        self.built = False
+
+    def args(self, D: int, device):
+        partial = torch.empty(self.cap_items, D, dtype=torch.float32, device=device)
+        build = 0 if self.built else 1
+        self.built = True
+        return (self.chunk, self.heavy, build, self.cap_items, self.cap_heavy, _p(self.item_row), _p(self.item_beg),
+                _p(self.heavy_row), _p(self.heavy_span), _p(self.counts), _p(partial))
 
 
 class SageAggFn(torch.autograd.Function):
@@ -313,7 +355,14 @@ class MeanAggFn(torch.autograd.Function):
         if N != graph.num_nodes:
             raise RuntimeError("x / graph size mismatch")
         agg = torch.empty_like(x)
-        check(lib.stemgnn_mean_agg_fwd(_p(x), N, D, _p(graph.rowptr), _p(graph.src), _p(agg), _stream()), "mean_agg_fwd")
+        plan = graph.split_plan("in")
+        if plan is None:
+            check(lib.stemgnn_mean_agg_fwd(_p(x), N, D, _p(graph.rowptr), _p(graph.src), _p(agg), _stream()),
+                  "mean_agg_fwd")
+        else:
+            check(lib.stemgnn_sage_agg_fwd_split(_p(x), N, D, graph.num_edges, _p(graph.rowptr), _p(graph.src), None,
+                                                 None, None, None, 0, _p(agg), 0, *plan.args(D, x.device), _stream()),
+                  "mean_agg_fwd_split")
         ctx.graph = graph
         return agg
 
@@ -324,8 +373,14 @@ class MeanAggFn(torch.autograd.Function):
         g_agg = g_agg.contiguous()
         N, D = g_agg.shape
         g_x = torch.empty_like(g_agg)
-        check(lib.stemgnn_mean_agg_bwd(_p(g_agg), N, D, _p(g.rowptr_t), _p(g.dst_t), _p(g.inv_deg), _p(g_x), _stream()),
-              "mean_agg_bwd")
+        plan = g.split_plan("out")
+        if plan is None:
+            check(lib.stemgnn_mean_agg_bwd(_p(g_agg), N, D, _p(g.rowptr_t), _p(g.dst_t), _p(g.inv_deg), _p(g_x),
+                                           _stream()), "mean_agg_bwd")
+        else:
+            check(lib.stemgnn_sage_agg_bwd_split(_p(g_agg), None, N, D, g.num_edges, _p(g.rowptr_t), _p(g.dst_t), None,
+                                                 _p(g.inv_deg), None, None, None, 0, _p(g_x), 0,
+                                                 *plan.args(D, g_agg.device), _stream()), "mean_agg_bwd_split")
         return g_x, None
 
 

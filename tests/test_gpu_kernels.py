@@ -125,6 +125,116 @@ def test_sage_agg_hub_node(dev):
     torch.testing.assert_close(out, ref, rtol=1e-4, atol=1e-5)  # 7001-term fp32 sums, different association
 
 
+def skewed_graph(n, e, seed):
+    """Power-law targets AND sources: a handful of hubs with thousands of in-/out-edges."""
+    g = torch.Generator().manual_seed(seed)
+    dst = (torch.rand(e, generator=g) ** 6 * n).long().clamp(max=n - 1)
+    src = (torch.rand(e, generator=g) ** 6 * n).long().clamp(max=n - 1)
+    return torch.stack([src, dst])
+
+
+@pytest.mark.parametrize("n,e,d", [(400, 30000, 32), (400, 30000, 48), (1500, 60000, 128), (300, 20000, 768),
+                                   (200, 9000, 1024)])
+@pytest.mark.parametrize("mode", ["none", "dense", "table"])
+def test_sage_agg_heavy_row_split(dev, n, e, d, mode):
+    """Hubs are cut into chunk items + a combine pass (stemgnn_sage_agg_fwd/bwd_split): against the
+    oracle, against the unsplit kernels (light rows: same bits), and plan reuse gives the same bits."""
+    from stem_gnn_amd import ops
+    from stem_gnn_amd.graph import EdgeTypeAttr, GraphStructure
+    from stem_gnn_amd.model.encoder import aggregate
+    torch.manual_seed(e + d)
+    ei = skewed_graph(n, e, seed=d)
+    indeg, outdeg = torch.bincount(ei[1], minlength=n), torch.bincount(ei[0], minlength=n)
+    assert int(indeg.max()) > 8 * ops.SPLIT_HEAVY and int(outdeg.max()) > 8 * ops.SPLIT_HEAVY
+    x, w = torch.randn(n, d), torch.randn(n, d)
+    table, et = torch.randn(5, d), torch.randint(0, 5, (e,))
+    ea_cpu = None if mode == "none" else table[et]
+    x_ref = x.clone().requires_grad_(True)
+    ref = O.sage_mean_aggregate(x_ref, ei, ea_cpu)
+    (ref * w).sum().backward()
+    # thousands of signed fp32 terms per hub row cancel: the yardstick is the same oracle in fp64, and the HIP
+    # result must be as close to it as the fp32 oracle is (chunked sums are in fact closer than sequential ones)
+    x64 = x.double().requires_grad_(True)
+    ref64 = O.sage_mean_aggregate(x64, ei, None if ea_cpu is None else ea_cpu.double())
+    (ref64 * w.double()).sum().backward()
+
+    def check(got, want32, want64):
+        err = (got.double().cpu() - want64).abs().max().item()
+        err32 = (want32.double() - want64).abs().max().item()
+        assert err <= max(1.5 * err32, 1e-6 * want64.abs().max().item()), (err, err32)
+        torch.testing.assert_close(got.cpu(), want32, rtol=1e-4, atol=1e-4 * want64.abs().max().item())
+
+    ea = {"none": None, "dense": None if ea_cpu is None else ea_cpu.to(dev),
+          "table": EdgeTypeAttr(table.to(dev), et.to(dev))}[mode]
+
+    def run(gs):
+        xg = x.to(dev).requires_grad_(True)
+        out = aggregate(xg, gs, ea)
+        (out * w.to(dev)).sum().backward()
+        return out.detach(), xg.grad
+
+    et_dev = et.to(dev) if mode == "table" else None
+    gs = GraphStructure(ei.to(dev), n, et_dev)            # validation on -> degree bounds known -> split
+    assert gs.max_in_degree == int(indeg.max()) and gs.max_out_degree == int(outdeg.max())
+    out, gx = run(gs)
+    assert gs._plan_in is not None and gs._plan_out is not None
+    items, heavy = gs._plan_in.counts.tolist()
+    assert heavy == int((indeg > ops.SPLIT_HEAVY).sum())
+    assert items == int(((indeg[indeg > ops.SPLIT_HEAVY] + ops.SPLIT_CHUNK - 1) // ops.SPLIT_CHUNK).sum())
+    check(out, ref.detach(), ref64.detach())
+    check(gx, x_ref.grad, x64.grad)
+    out2, gx2 = run(gs)                                                         # plan reused (build_plan = 0)
+    assert torch.equal(out2, out) and torch.equal(gx2, gx)
+    plain = GraphStructure(ei.to(dev), n, et_dev, validate=False)
+    plain.max_in_degree = plain.max_out_degree = 0                              # bound says "no hubs": one pass
+    out3, gx3 = run(plain)
+    assert plain._plan_in is None and plain._plan_out is None
+    light_in, light_out = (indeg <= ops.SPLIT_HEAVY).to(dev), (outdeg <= ops.SPLIT_HEAVY).to(dev)
+    assert torch.equal(out3[light_in], out[light_in]) and torch.equal(gx3[light_out], gx[light_out])
+    check(out3, ref.detach(), ref64.detach())
+    check(gx3, x_ref.grad, x64.grad)
+    unknown = GraphStructure(ei.to(dev), n, et_dev, validate=False)             # no bound -> split, same bits
+    out4, gx4 = run(unknown)
+    assert unknown.max_in_degree is None and torch.equal(out4, out) and torch.equal(gx4, gx)
+
+
+def test_heavy_row_split_on_augmented_graph_and_plain_mean(dev):
+    """dropout_undirected output (symmetric: one plan for both directions) and MixtureSageLayer's
+    plain mean go through the split entry points too."""
+    from stem_gnn_amd import ops
+    from stem_gnn_amd.graph import GraphStructure
+    from stem_gnn_amd.model.encoder import aggregate
+    n, e, d = 600, 40000, 128
+    torch.manual_seed(5)
+    ei = skewed_graph(n, e, seed=1)
+    x, w = torch.randn(n, d), torch.randn(n, d)
+    ea = torch.randn(e, d)
+    gs = GraphStructure(ei.to(dev), n)
+    keep = torch.rand(e) < 0.7
+    aug = gs.dropout_undirected(0.3, keep=keep.to(dev))
+    ei_o, ea_o, _ = O.dropout_adj_undirected(ei, ea, keep)
+    x_ref = x.clone().requires_grad_(True)
+    ref = O.sage_mean_aggregate(x_ref, ei_o, ea_o)
+    (ref * w).sum().backward()
+    xg = x.to(dev).requires_grad_(True)
+    out = aggregate(xg, aug, ea.to(dev))
+    (out * w.to(dev)).sum().backward()
+    assert aug._plan_in is not None and aug._plan_out is None and int(aug._plan_in.counts[1]) > 0
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(xg.grad.cpu(), x_ref.grad, rtol=1e-4, atol=1e-4 * x_ref.grad.abs().max().item())
+    # plain mean (no edge term, no relu)
+    xm = x.to(dev).requires_grad_(True)
+    m = ops.MeanAggFn.apply(xm, gs)
+    (m * w.to(dev)).sum().backward()
+    xr = x.clone().requires_grad_(True)
+    deg = torch.bincount(ei[1], minlength=n).clamp(min=1).unsqueeze(1)
+    mr = torch.zeros(n, d).index_add_(0, ei[1], xr[ei[0]]) / deg
+    (mr * w).sum().backward()
+    assert gs._plan_in is not None and int(gs._plan_in.counts[1]) > 0
+    torch.testing.assert_close(m.detach().cpu(), mr.detach(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(xm.grad.cpu(), xr.grad, rtol=1e-4, atol=1e-4 * xr.grad.abs().max().item())
+
+
 # ---------------------------------------------------------------------------- K4
 @pytest.mark.parametrize("n,d", [(2, 4), (37, 32), (1000, 128), (513, 768), (4096, 48)])
 @pytest.mark.parametrize("use_bn,act,p,slope", [(True, 1, 0.15, 0.0), (True, 0, 0.0, 0.0), (False, 1, 0.3, 0.01),
