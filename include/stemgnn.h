@@ -247,6 +247,13 @@ int stemgnn_dropout_keep_mask(int64_t n, float p, uint64_t seed, uint64_t offset
  * All matrices dense row-major fp32; K1, K2, N multiples of 4.
  * ------------------------------------------------------------------------------------ */
 
+/* The three dense products below run on the bf16 matrix cores by default: every fp32 operand is cut exactly
+ * into three bf16 pieces and the six significant piece products are accumulated in fp32 -- no further from the
+ * fp64 result than the fp32-MFMA kernels (csrc/linear.hip).  mode 0 selects the fp32-MFMA kernels, 1 the
+ * default; any other value only queries.  Returns the previous mode.  The tile plan
+ * (stemgnn_linear_stats_blocks) depends on the mode: set it before sizing buffers. */
+int stemgnn_linear_set_mode(int mode);
+
 /* y [M, N] = x1 [M, K1] w1[N, K1]^T (+ x2 [M, K2] w2 [N, K2]^T when K2 > 0) + bias [N] (NULL: none).
  * stats_partial (may be NULL): receives per-row-block column sums / sums of squares of y,
  * [stemgnn_linear_stats_blocks(M, N)][2][N]; *stats_blocks_host (host pointer, may be NULL)

@@ -21,6 +21,7 @@
 // 2*M*N*K flop at 157 TFLOP/s vs (M*K + M*N)*4 bytes of HBM traffic.
 #include "common.h"
 
+#include <atomic>
 #include <cstdlib>
 
 namespace stemgnn {
@@ -32,6 +33,48 @@ constexpr int kLd = kKC + 4;  // 36-dword row stride: conflict-free ds_read_b128
 constexpr int kMaxSplits = 512;
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// ---- fp32 products on the bf16 matrix cores (the default path) --------------------------------
+// An fp32 value is cut EXACTLY into three bf16 pieces a = h + m + l: three 8-bit slices of the 24-bit
+// significand, by truncation, so every piece carries the sign of a and each remainder is exact; a bf16
+// is the upper half of the fp32 pattern.  a*b is accumulated (in the fp32 MFMA accumulator) from the
+// six piece products of relative size >= 2^-16 (hh, hm, mh, mm, hl, lh); the dropped ml, lm, ll sum to
+// < 2^-23 |a*b|, the size of ONE fp32 rounding of the product.  Measured against fp64 the result is no
+// further from the truth than the v_mfma_f32_32x32x2_f32 kernel (tools/micro/gemm_bf16x3.hip: max error
+// 1.5e-6 vs 2.0e-6 at K = 128, 6.6e-6 vs 7.2e-6 at K = 512), and six v_mfma_f32_32x32x16_bf16 take 192
+// cycles per 16 k where eight v_mfma_f32_32x32x2_f32 take 512.  Non-finite inputs give NaN where plain
+// fp32 would give Inf (Inf - Inf in the first remainder).
+constexpr int kLdP = 2 * kKC + 16;  // bytes per LDS row of one bf16 plane: 32 k + 16 B pad (conflict-free b128 reads)
+
+__device__ inline uint32_t hi16(float f) { return __float_as_uint(f) & 0xffff0000u; }
+__device__ inline uint32_t pack_hi(uint32_t lo_elem, uint32_t hi_elem) {  // bf16 pair from two fp32 patterns
+  return __builtin_amdgcn_perm(hi_elem, lo_elem, 0x07060302u);
+}
+__device__ inline void split3(float4 a, uint2& h, uint2& m, uint2& l) {
+  const float v[4] = {a.x, a.y, a.z, a.w};
+  uint32_t hb[4], mb[4], lb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    hb[i] = hi16(v[i]);
+    const float r1 = v[i] - __uint_as_float(hb[i]);
+    mb[i] = hi16(r1);
+    lb[i] = __float_as_uint(r1 - __uint_as_float(mb[i]));  // at most 8 significant bits left: a bf16 value
+  }
+  h = make_uint2(pack_hi(hb[0], hb[1]), pack_hi(hb[2], hb[3]));
+  m = make_uint2(pack_hi(mb[0], mb[1]), pack_hi(mb[2], mb[3]));
+  l = make_uint2(pack_hi(lb[0], lb[1]), pack_hi(lb[2], lb[3]));
+}
+// c += a * b over a 16-wide k step, pieces indexed [0] = h, [1] = m, [2] = l; small terms first
+__device__ inline floatx16 mfma_x3(const bf16x8 (&a)[3], const bf16x8 (&b)[3], floatx16 c) {
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
+  return c;
+}
 
 __device__ inline float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ inline void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
@@ -177,6 +220,152 @@ k_linear_fwd(const float* __restrict__ x1, const float* __restrict__ w1, int K1,
   }
 }
 
+// The same tile on the bf16 matrix cores (split3 / mfma_x3 above): chunks are split while they are staged.
+template <int BM, bool STATS>
+__global__ void __launch_bounds__(kBlock, 2)
+k_linear_fwd_x3(const float* __restrict__ x1, const float* __restrict__ w1, int K1, const float* __restrict__ x2,
+             const float* __restrict__ w2, int K2, const float* __restrict__ bias, int64_t M, int N,
+             float* __restrict__ y, float* __restrict__ stats_partial /*[blocks][2][N]*/, int64_t row_base,
+             int64_t stats_block0) {
+  // BM = 128: waves 2(m) x 2(n), 64x64 per wave.  BM = 32 (tail tiles): waves 1 x 4, 32x32 per wave.
+  constexpr int WM = BM == 128 ? 2 : 1;
+  constexpr int WN = 4 / WM;
+  constexpr int TM = BM / (32 * WM);
+  constexpr int TN = kBN / (32 * WN);
+  constexpr int FA = BM * 8 / kBlock;  // float4 of an activation chunk per thread
+  constexpr int PA = BM * kLdP, PB = kBN * kLdP;  // bytes of one bf16 plane
+  __shared__ __attribute__((aligned(16))) unsigned char sA[3 * PA];  // planes h, m, l of the activation chunk
+  __shared__ __attribute__((aligned(16))) unsigned char sB[3 * PB];  // planes h, m, l of the weight chunk
+  __shared__ float s_stats[WM][2][kBN];  // [wave_m][sum|sumsq][n]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN, hi = lane >> 5, lj = lane & 31;
+  const int64_t m0 = row_base + static_cast<int64_t>(blockIdx.x) * BM;
+  const int n0 = blockIdx.y * kBN;
+  const int c1 = (K1 + kKC - 1) / kKC, c2 = (K2 + kKC - 1) / kKC;
+  const int steps = c1 + c2;
+
+  float4 ra[FA], rb[4];
+  auto fetch = [&](int step) {
+    const bool second = step >= c1;
+    const float* xs = second ? x2 : x1;
+    const float* ws = second ? w2 : w1;
+    const int K = second ? K2 : K1;
+    const int k0 = (second ? step - c1 : step) * kKC;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int idx = t * kBlock + tid;  // 16-byte column = idx % 8, row = idx / 8
+      const int r = idx >> 3, k = k0 + 4 * (idx & 7);
+      const int n = n0 + r;
+      rb[t] = (n < N && k < K) ? ld4(ws + static_cast<int64_t>(n) * K + k) : zero4();
+      if (t < FA) {
+        const int64_t m = m0 + r;
+        ra[t] = (m < M && k < K) ? ld4(xs + m * K + k) : zero4();
+      }
+    }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int idx = t * kBlock + tid;
+      const int off = (idx >> 3) * kLdP + 8 * (idx & 7);
+      uint2 h, m, l;
+      split3(rb[t], h, m, l);
+      *reinterpret_cast<uint2*>(sB + off) = h;
+      *reinterpret_cast<uint2*>(sB + PB + off) = m;
+      *reinterpret_cast<uint2*>(sB + 2 * PB + off) = l;
+      if (t < FA) {
+        split3(ra[t], h, m, l);
+        *reinterpret_cast<uint2*>(sA + off) = h;
+        *reinterpret_cast<uint2*>(sA + PA + off) = m;
+        *reinterpret_cast<uint2*>(sA + 2 * PA + off) = l;
+      }
+    }
+  };
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  float bias_v[TN];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int n = n0 + wn * 32 * TN + tn * 32 + lj;
+    bias_v[tn] = (bias != nullptr && n < N) ? bias[n] : 0.f;
+  }
+
+  fetch(0);
+  for (int step = 0; step < steps; ++step) {
+    stash();
+    __syncthreads();
+    if (step + 1 < steps) fetch(step + 1);
+#pragma unroll
+    for (int ks = 0; ks < kKC / 16; ++ks) {
+      const int ko = ks * 32 + hi * 16;  // bytes: lane half 0 takes k 0..7, half 1 k 8..15 of the 16-wide step
+      bf16x8 a[TM][3], b[TN][3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+#pragma unroll
+        for (int t = 0; t < TM; ++t)
+          a[t][p] = *reinterpret_cast<const bf16x8*>(sA + p * PA + (wm * 32 * TM + t * 32 + lj) * kLdP + ko);
+#pragma unroll
+        for (int t = 0; t < TN; ++t)
+          b[t][p] = *reinterpret_cast<const bf16x8*>(sB + p * PB + (wn * 32 * TN + t * 32 + lj) * kLdP + ko);
+      }
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma_x3(a[tm], b[tn], acc[tm][tn]);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias, store (two 128-byte row segments per store instruction), column stats.
+  // The bias was loaded before the main loop: the epilogue issues stores only, so no
+  // s_waitcnt vmcnt(0) ever serialises them (vmcnt counts stores too).
+  const bool interior = (m0 + BM <= M) && (n0 + kBN <= N);
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int nl = wn * 32 * TN + tn * 32 + lj;
+    const int n = n0 + nl;
+    const float bv = bias_v[tn];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const int64_t mrow0 = m0 + wm * 32 * TM + tm * 32 + 4 * hi;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t m = mrow0 + (r & 3) + 8 * (r >> 2);
+        const float v = acc[tm][tn][r] + bv;
+        if (interior || (m < M && n < N)) {
+          y[m * N + n] = v;
+          if (STATS) { s1 += v; s2 += v * v; }
+        }
+      }
+    }
+    if (STATS) {
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (hi == 0) { s_stats[wm][0][nl] = s1; s_stats[wm][1][nl] = s2; }
+    }
+  }
+  if (STATS) {
+    __syncthreads();
+    if (tid < kBN && n0 + tid < N) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) { t1 += s_stats[w][0][tid]; t2 += s_stats[w][1][tid]; }
+      float* p = stats_partial + (stats_block0 + blockIdx.x) * 2 * N;
+      p[n0 + tid] = t1;
+      p[N + n0 + tid] = t2;
+    }
+  }
+}
+
 // (A weight-resident persistent variant -- 128-column weight tile kept in LDS, one 512-thread block
 // per CU streaming activation chunks through a ring with one barrier per step -- was built and
 // measured slower than the kernel above: 55 vs 46 us at K = 128, 92 vs 81 us at K = 256, M = 102400,
@@ -275,6 +464,121 @@ k_linear_bwd_weight(const float* __restrict__ dy, const float* __restrict__ x, i
     partial_db[static_cast<int64_t>(split) * N + n0 + tid] = colsum;
 }
 
+// The same product on the bf16 matrix cores.  Both operands are contracted over their SLOW dimension (rows m),
+// and a v_mfma_f32_32x32x16_bf16 lane wants 8 consecutive m: each thread stages a 4 (m) x 4 (n or k) micro-tile,
+// splits it and stores it transposed, so the LDS planes are [n][32 m] / [k][32 m] and the fragment reads are the
+// forward kernel's.  db comes from the staged registers (shuffle over the 8 lanes that share a column group).
+__global__ void __launch_bounds__(kBlock, 2)
+k_linear_bwd_weight_x3(const float* __restrict__ dy, const float* __restrict__ x, int64_t M, int N, int K,
+                       int64_t rows_per_split, float* __restrict__ partial_dw /*[S][N][K]*/,
+                       float* __restrict__ partial_db /*[S][N]*/) {
+  constexpr int PL = kBN * kLdP;
+  __shared__ __attribute__((aligned(16))) unsigned char sA[3 * PL];  // dY^T planes [128 n][32 m]
+  __shared__ __attribute__((aligned(16))) unsigned char sB[3 * PL];  // X^T  planes [128 k][32 m]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wi = wave >> 1, wj = wave & 1, hi = lane >> 5, lj = lane & 31;
+  const int split = blockIdx.x;
+  const int n0 = blockIdx.y * kBN, k0 = blockIdx.z * kBN;
+  const int64_t mbeg = split * rows_per_split;
+  const int64_t mend = min(M, mbeg + rows_per_split);
+  const int steps = static_cast<int>((mend - mbeg + kKC - 1) / kKC);
+  const int mq = tid & 7, cq = tid >> 3;  // rows 4 mq .. 4 mq + 3 of the chunk, columns 4 cq .. 4 cq + 3 of the tile
+  const bool do_db = blockIdx.z == 0 && partial_db != nullptr;
+
+  float4 ra[4], rb[4];
+  auto fetch = [&](int step) {
+    const int64_t mm = mbeg + static_cast<int64_t>(step) * kKC + 4 * mq;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t m = mm + i;
+      ra[i] = (m < mend && n0 + 4 * cq < N) ? ld4(dy + m * N + n0 + 4 * cq) : zero4();
+      rb[i] = (m < mend && k0 + 4 * cq < K) ? ld4(x + m * K + k0 + 4 * cq) : zero4();
+    }
+  };
+  // q[i] holds columns c .. c+3 of row i: split every element, store column j as the 4 consecutive m of plane row j
+  auto stash_t = [&](const float4 (&q)[4], unsigned char* planes) {
+    uint32_t hb[4][4], mb[4][4], lb[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float v[4] = {q[i].x, q[i].y, q[i].z, q[i].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        hb[i][j] = hi16(v[j]);
+        const float r1 = v[j] - __uint_as_float(hb[i][j]);
+        mb[i][j] = hi16(r1);
+        lb[i][j] = __float_as_uint(r1 - __uint_as_float(mb[i][j]));
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int off = (4 * cq + j) * kLdP + 8 * mq;
+      *reinterpret_cast<uint2*>(planes + off) = make_uint2(pack_hi(hb[0][j], hb[1][j]), pack_hi(hb[2][j], hb[3][j]));
+      *reinterpret_cast<uint2*>(planes + PL + off) = make_uint2(pack_hi(mb[0][j], mb[1][j]), pack_hi(mb[2][j], mb[3][j]));
+      *reinterpret_cast<uint2*>(planes + 2 * PL + off) = make_uint2(pack_hi(lb[0][j], lb[1][j]), pack_hi(lb[2][j], lb[3][j]));
+    }
+  };
+
+  floatx16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  float4 colsum = zero4();  // columns 4 cq .. 4 cq + 3 (lanes with mq == 0 hold the total)
+
+  if (steps > 0) fetch(0);
+  for (int step = 0; step < steps; ++step) {
+    stash_t(ra, sA);
+    stash_t(rb, sB);
+    if (do_db) {
+      float4 c = make_float4(ra[0].x + ra[1].x + ra[2].x + ra[3].x, ra[0].y + ra[1].y + ra[2].y + ra[3].y,
+                             ra[0].z + ra[1].z + ra[2].z + ra[3].z, ra[0].w + ra[1].w + ra[2].w + ra[3].w);
+#pragma unroll
+      for (int o = 1; o < 8; o <<= 1) {
+        c.x += __shfl_xor(c.x, o, 64); c.y += __shfl_xor(c.y, o, 64);
+        c.z += __shfl_xor(c.z, o, 64); c.w += __shfl_xor(c.w, o, 64);
+      }
+      colsum.x += c.x; colsum.y += c.y; colsum.z += c.z; colsum.w += c.w;
+    }
+    __syncthreads();
+    if (step + 1 < steps) fetch(step + 1);
+#pragma unroll
+    for (int ks = 0; ks < kKC / 16; ++ks) {
+      const int ko = ks * 32 + hi * 16;
+      bf16x8 a[2][3], b[2][3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          a[t][p] = *reinterpret_cast<const bf16x8*>(sA + p * PL + (wi * 64 + t * 32 + lj) * kLdP + ko);
+          b[t][p] = *reinterpret_cast<const bf16x8*>(sB + p * PL + (wj * 64 + t * 32 + lj) * kLdP + ko);
+        }
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = mfma_x3(a[ti], b[tj], acc[ti][tj]);
+    }
+    __syncthreads();
+  }
+
+  float* pw = partial_dw + static_cast<int64_t>(split) * N * K;
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj) {
+      const int k = k0 + wj * 64 + tj * 32 + lj;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wi * 64 + ti * 32 + acc_row(r, hi);
+        if (n < N && k < K) pw[static_cast<int64_t>(n) * K + k] = acc[ti][tj][r];
+      }
+    }
+  if (do_db && mq == 0 && n0 + 4 * cq < N)  // N % 4 == 0: the four columns are in range together
+    st4(partial_db + static_cast<int64_t>(split) * N + n0 + 4 * cq, colsum);
+}
+
 // out[i] = sum_s partial[s][i]: 16 float4 columns x 16 split-slices per block, fixed-order LDS
 // tree over the slices (deterministic).
 __global__ void __launch_bounds__(kBlock)
@@ -324,21 +628,39 @@ inline bool lin_dims_ok(int64_t M, int64_t N, int64_t K) {
   return M >= 0 && N > 0 && K > 0 && K % 4 == 0 && N <= 65536 && K <= 65536;
 }
 
+// Which matrix-core path the three products take: 1 (default) = bf16 pieces, 0 = v_mfma_f32_32x32x2_f32 (kept as
+// the cross-check of the split product).  STEMGNN_GEMM=f32 in the environment starts the process in mode 0;
+// stemgnn_linear_set_mode switches at run time.
+std::atomic<int> g_gemm_mode{-1};
+inline bool gemm_x3() {
+  int m = g_gemm_mode.load(std::memory_order_relaxed);
+  if (m < 0) {
+    const char* e = getenv("STEMGNN_GEMM");
+    m = (e && e[0] == 'f') ? 0 : 1;
+    g_gemm_mode.store(m, std::memory_order_relaxed);
+  }
+  return m == 1;
+}
+
 // Resident-block slots of the 128-row forward tile kernel on this device (blocks per CU x CUs).
-inline int64_t fwd_slots() {
+template <bool X3>
+inline int64_t fwd_slots_of() {
   static const int64_t slots = [] {
     int per_cu = 0, cus = 0, dev = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_linear_fwd<128, false>, kBlock, 0) != hipSuccess ||
+        (X3 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_linear_fwd_x3<128, false>, kBlock, 0)
+            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_linear_fwd<128, false>, kBlock, 0)) !=
+            hipSuccess ||
         per_cu <= 0 || cus <= 0) {
       (void)hipGetLastError();
-      return static_cast<int64_t>(3 * 256);
+      return static_cast<int64_t>((X3 ? 2 : 3) * 256);
     }
     return static_cast<int64_t>(per_cu) * cus;
   }();
   return slots;
 }
+inline int64_t fwd_slots() { return gemm_x3() ? fwd_slots_of<true>() : fwd_slots_of<false>(); }
 
 // Tile plan of the forward product: whole rounds of 128-row tiles, and (when the last round
 // would be mostly empty) its rows as 32-row tiles.  Measured at N = 128 on MI355X: 768 tiles (one
@@ -387,6 +709,12 @@ using namespace stemgnn;
 
 extern "C" {
 
+int stemgnn_linear_set_mode(int mode) {
+  const int prev = gemm_x3() ? 1 : 0;
+  if (mode == 0 || mode == 1) g_gemm_mode.store(mode, std::memory_order_relaxed);
+  return prev;
+}
+
 size_t stemgnn_linear_stats_partial_bytes(int64_t M, int64_t N) {
   if (M < 0 || N <= 0) return 0;
   return static_cast<size_t>((M + 31) / 32) * 2 * N * sizeof(float) + 256;  // upper bound over every tile plan
@@ -411,12 +739,16 @@ int stemgnn_linear_fwd(const float* x1, const float* w1, int64_t K1, const float
   const int gy = static_cast<int>((N + kBN - 1) / kBN);
   const FwdPlan plan = plan_fwd(M, N);
   const int k1 = static_cast<int>(K1), k2 = static_cast<int>(K2), n = static_cast<int>(N);
+  const bool x3 = gemm_x3();
   if (plan.main_tiles > 0) {
     dim3 grid(static_cast<unsigned>(plan.main_tiles), static_cast<unsigned>(gy));
-    if (stats_partial)
-      k_linear_fwd<128, true><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, stats_partial, 0, 0);
-    else
-      k_linear_fwd<128, false><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, nullptr, 0, 0);
+    if (stats_partial) {
+      if (x3) k_linear_fwd_x3<128, true><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, stats_partial, 0, 0);
+      else k_linear_fwd<128, true><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, stats_partial, 0, 0);
+    } else {
+      if (x3) k_linear_fwd_x3<128, false><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, nullptr, 0, 0);
+      else k_linear_fwd<128, false><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, nullptr, 0, 0);
+    }
     STEMGNN_LAUNCH_CHECK();
   }
   if (plan.tail_tiles > 0) {
@@ -424,12 +756,17 @@ int stemgnn_linear_fwd(const float* x1, const float* w1, int64_t K1, const float
     // a quarter of the latency each, instead of a handful of full-size stragglers
     dim3 grid(static_cast<unsigned>(plan.tail_tiles), static_cast<unsigned>(gy));
     const int64_t row_base = plan.main_tiles * kBM;
-    if (stats_partial)
-      k_linear_fwd<32, true><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, stats_partial, row_base,
-                                                      plan.main_tiles);
-    else
-      k_linear_fwd<32, false><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, nullptr, row_base,
-                                                       plan.main_tiles);
+    if (stats_partial) {
+      if (x3) k_linear_fwd_x3<32, true><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, stats_partial,
+                                                                 row_base, plan.main_tiles);
+      else k_linear_fwd<32, true><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, stats_partial,
+                                                           row_base, plan.main_tiles);
+    } else {
+      if (x3) k_linear_fwd_x3<32, false><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, nullptr,
+                                                                  row_base, plan.main_tiles);
+      else k_linear_fwd<32, false><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, nullptr,
+                                                            row_base, plan.main_tiles);
+    }
     STEMGNN_LAUNCH_CHECK();
   }
   return STEMGNN_OK;
@@ -458,8 +795,12 @@ int stemgnn_linear_bwd_weight(const float* dy, const float* x, int64_t M, int64_
   float* pw = reinterpret_cast<float*>(align_up(reinterpret_cast<uintptr_t>(workspace), 256));
   float* pb = pw + static_cast<size_t>(S) * N * K;
   dim3 grid(static_cast<unsigned>(S), static_cast<unsigned>((N + kBN - 1) / kBN), static_cast<unsigned>((K + kBN - 1) / kBN));
-  k_linear_bwd_weight<<<grid, kBlock, 0, st>>>(dy, x, M, static_cast<int>(N), static_cast<int>(K), rows, pw,
-                                               db ? pb : nullptr);
+  if (gemm_x3())
+    k_linear_bwd_weight_x3<<<grid, kBlock, 0, st>>>(dy, x, M, static_cast<int>(N), static_cast<int>(K), rows, pw,
+                                                    db ? pb : nullptr);
+  else
+    k_linear_bwd_weight<<<grid, kBlock, 0, st>>>(dy, x, M, static_cast<int>(N), static_cast<int>(K), rows, pw,
+                                                 db ? pb : nullptr);
   STEMGNN_LAUNCH_CHECK();
   const int64_t nk = N * K;
   k_reduce_splits<<<static_cast<unsigned>((nk / 4 + 15) / 16), kBlock, 0, st>>>(pw, S, nk, dw);

@@ -460,6 +460,12 @@ class BnActDropFn(torch.autograd.Function):
 # ----------------------------------------------------------------------------------------
 # K3 / K5: dense projections on the fp32 matrix cores
 # ----------------------------------------------------------------------------------------
+def linear_set_mode(mode: int) -> int:
+    """1 (default): fp32 products from exact bf16 pieces on the bf16 matrix cores; 0: fp32-MFMA kernels.
+    Returns the previous mode (any other argument only queries)."""
+    return int(lib.stemgnn_linear_set_mode(int(mode)))
+
+
 def linear_fwd(x1: Tensor, w1: Tensor, x2: Optional[Tensor], w2: Optional[Tensor], bias: Optional[Tensor],
                want_stats: bool = False):
     """y = x1 w1^T (+ x2 w2^T) + bias; optionally the per-row-block column partials of y."""

@@ -316,6 +316,36 @@ def test_gather_rows_and_ema_lerp(dev):
 
 
 # ---------------------------------------------------------------------------- K3 / K5
+@pytest.mark.parametrize("m,k,n", [(4096, 128, 128), (3000, 512, 128), (2500, 128, 512), (1111, 768, 96), (257, 36, 40)])
+def test_linear_split_bf16_product_is_as_exact_as_fp32_mfma(dev, m, k, n):
+    """The default dense products cut every fp32 operand exactly into three bf16 pieces (csrc/linear.hip).  Against
+    an fp64 product of the same fp32 inputs -- mixed magnitudes and signs, so cancellation is real -- they must be no
+    further from the truth than the fp32-MFMA kernels (mode 0), for Y = X W^T + b, dW = dY^T X and db."""
+    from stem_gnn_amd import ops
+    torch.manual_seed(m + k)
+    x = torch.randn(m, k) * torch.exp(2.0 * torch.randn(m, k))
+    w = torch.randn(n, k) * torch.exp(2.0 * torch.randn(n, k)) / k ** 0.5
+    b = torch.randn(n)
+    g = torch.randn(m, n) * torch.exp(2.0 * torch.randn(m, n))
+    y64 = x.double() @ w.double().t() + b.double()
+    dw64, db64 = g.double().t() @ x.double(), g.double().sum(0)
+    xg, wg, bg, gg = x.to(dev), w.to(dev), b.to(dev), g.to(dev)
+    prev = ops.linear_set_mode(-1)
+    errs = {}
+    try:
+        for mode in (0, 1):
+            ops.linear_set_mode(mode)
+            y = ops.linear_fwd(xg, wg, None, None, bg, False)[0]
+            dw, db = ops.linear_bwd_weight(gg, xg, True)
+            errs[mode] = [((a.double().cpu() - r).abs().max() / r.abs().max()).item()
+                          for a, r in ((y, y64), (dw, dw64), (db, db64))]
+    finally:
+        ops.linear_set_mode(prev)
+    for e0, e1 in zip(errs[0], errs[1]):
+        assert e1 <= max(1.5 * e0, 2e-7), (errs)
+        assert e1 < 1e-5
+
+
 @pytest.mark.parametrize("m,k1,k2,n,bias", [(1, 32, 0, 32, True), (130, 32, 32, 64, True), (1000, 128, 128, 128, True),
                                             (777, 128, 0, 512, True), (513, 512, 0, 128, False),
                                             (4100, 768, 768, 768, True), (300, 48, 0, 36, True)])
