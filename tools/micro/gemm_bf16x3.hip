@@ -343,149 +343,6 @@ static void launch_v3(const float* x, const float* w, int K, int64_t M, int N, f
   k_gemm_v3<KC, OCC, SCHED><<<grid, kBlock, lds>>>(x, g_planes, K, M, N, y);
 }
 
-// v5: the v1 structure (one LDS buffer, two barriers per 32-wide K chunk, 4 waves of 64x64) with the global loads
-// issued PF chunks ahead into rotating register sets.  The loads and their s_waitcnt are inline asm: the
-// compiler's own vmcnt bookkeeping waits for ALL outstanding loads at the loop head, which collapses any
-// prefetch distance > 1.
-__device__ inline void gload4(floatx4& d, const float* p) {
-  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory");
-}
-template <int N>
-__device__ inline void wait_loads(floatx4 (&a)[4], floatx4 (&b)[4]) {
-  asm volatile("s_waitcnt vmcnt(%8)"
-               : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])
-               : "n"(N) : "memory");
-}
-__device__ inline void split3v(floatx4 a, uint2& h, uint2& m, uint2& l) {
-  split3(make_float4(a[0], a[1], a[2], a[3]), h, m, l);
-}
-
-template <int OCC, int PF>
-__global__ void __launch_bounds__(kBlock, OCC)
-k_gemm_v5(const float* __restrict__ x, const float* __restrict__ w, int K, int64_t M, int N, float* __restrict__ y) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* sA = smem;
-  unsigned char* sB = smem + 3 * kPlane;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1, hi = lane >> 5, lj = lane & 31;
-  const int64_t m0 = static_cast<int64_t>(blockIdx.x) * kBM;
-  const int n0 = blockIdx.y * kBN;
-  const int steps = K / kKC;
-
-  const float *pa[4], *pb[4];
-  int off[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int idx = t * kBlock + tid;
-    int64_t m = m0 + (idx >> 3);
-    if (m >= M) m = M - 1;  // clamped rows are computed and never stored
-    int n = n0 + (idx >> 3);
-    if (n >= N) n = N - 1;
-    pa[t] = x + m * K + 4 * (idx & 7);
-    pb[t] = w + static_cast<int64_t>(n) * K + 4 * (idx & 7);
-    off[t] = (idx >> 3) * kLdB + 8 * (idx & 7);
-  }
-  floatx4 ra[PF][4], rb[PF][4];
-  auto issue = [&](int step, floatx4 (&qa)[4], floatx4 (&qb)[4]) {
-    const int k0 = (step < steps ? step : steps - 1) * kKC;  // past the end: a harmless re-read keeps vmcnt uniform
-#pragma unroll
-    for (int t = 0; t < 4; ++t) gload4(qa[t], pa[t] + k0);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) gload4(qb[t], pb[t] + k0);
-  };
-  auto stash = [&](floatx4 (&qa)[4], floatx4 (&qb)[4]) {
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      uint2 h, m, l;
-      split3v(qa[t], h, m, l);
-      *reinterpret_cast<uint2*>(sA + off[t]) = h;
-      *reinterpret_cast<uint2*>(sA + kPlane + off[t]) = m;
-      *reinterpret_cast<uint2*>(sA + 2 * kPlane + off[t]) = l;
-      split3v(qb[t], h, m, l);
-      *reinterpret_cast<uint2*>(sB + off[t]) = h;
-      *reinterpret_cast<uint2*>(sB + kPlane + off[t]) = m;
-      *reinterpret_cast<uint2*>(sB + 2 * kPlane + off[t]) = l;
-    }
-  };
-  floatx16 acc[2][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-  auto mma = [&]() {
-#pragma unroll
-    for (int ks = 0; ks < kKC / 16; ++ks) {
-      const int ko = ks * 32 + hi * 16;
-      bf16x8 a[2][3], b[2][3];
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-          a[t][p] = *reinterpret_cast<const bf16x8*>(sA + p * kPlane + (wm * 64 + t * 32 + lj) * kLdB + ko);
-          b[t][p] = *reinterpret_cast<const bf16x8*>(sB + p * kPlane + (wn * 64 + t * 32 + lj) * kLdB + ko);
-        }
-#pragma unroll
-      for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-          floatx16 c = acc[tm][tn];
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][2], b[tn][0], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][2], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][1], b[tn][1], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][1], b[tn][0], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][1], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][0], c, 0, 0, 0);
-          acc[tm][tn] = c;
-        }
-    }
-  };
-
-#pragma unroll
-  for (int p = 0; p < PF; ++p) issue(p, ra[p], rb[p]);
-  for (int s0 = 0; s0 < steps; s0 += PF) {
-#pragma unroll
-    for (int j = 0; j < PF; ++j) {
-      const int st = s0 + j;
-      if (st < steps) {
-        wait_loads<8 * (PF - 1)>(ra[j], rb[j]);
-        stash(ra[j], rb[j]);
-        __syncthreads();
-        issue(st + PF, ra[j], rb[j]);
-        mma();
-        __syncthreads();
-      }
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-  for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
-      const int n = n0 + wn * 64 + tn * 32 + lj;
-      float* yr = y + (m0 + wm * 64 + tm * 32 + 4 * hi) * N + n;
-      const int64_t mrem = M - (m0 + wm * 64 + tm * 32 + 4 * hi);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int dr = (r & 3) + 8 * (r >> 2);
-        if (dr < mrem && n < N) yr[static_cast<int64_t>(dr) * N] = acc[tm][tn][r];
-      }
-    }
-}
-
-template <int OCC, int PF>
-static void launch_v5(const float* x, const float* w, int K, int64_t M, int N, float* y) {
-  dim3 grid(static_cast<unsigned>((M + kBM - 1) / kBM), (N + kBN - 1) / kBN);
-  static bool once = [] {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_v5<OCC, PF>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        6 * kPlane);
-    return true;
-  }();
-  (void)once;
-  k_gemm_v5<OCC, PF><<<grid, kBlock, 6 * kPlane>>>(x, w, K, M, N, y);
-}
-
 // the fp32-MFMA tile of csrc/linear.hip, for the side-by-side number
 constexpr int kLd = kKC + 4;
 template <int OCC>
@@ -599,20 +456,9 @@ int main() {
   std::vector<float> hy(M * NMAX), hy2(M * NMAX);
   for (auto kn : {std::pair<int, int>{128, 128}, {256, 128}, {512, 128}, {128, 512}}) {
     const int K = kn.first, N = kn.second;
-    printf("  v5 (occ2): pf1 %.1f  pf2 %.1f  pf3 %.1f us\n", time_us(launch_v5<2, 1>, x, w, K, M, N, y2),
-           time_us(launch_v5<2, 2>, x, w, K, M, N, y2), time_us(launch_v5<2, 3>, x, w, K, M, N, y2));
-    {
-      std::vector<float> h3(M * N);
-      hipMemcpy(h3.data(), y2, M * N * 4, hipMemcpyDeviceToHost);
-      double e3 = 0;
-      for (int64_t m = 0; m < M; m += 499)
-        for (int n = 0; n < N; ++n) {
-          double r = 0;
-          for (int k = 0; k < K; ++k) r += static_cast<double>(hx[m * K + k]) * hw[static_cast<int64_t>(n) * K + k];
-          e3 = fmax(e3, fabs(h3[m * N + n] - r));
-        }
-      printf("  v5 pf3 max|err| vs fp64: %.3g\n", e3);
-    }
+    printf("  double-buffered variants: kc16/occ2 %.1f  kc16/occ2/sched2 %.1f  kc32/occ1 %.1f us\n",
+           time_us(launch_v3<16, 2, 0>, x, w, K, M, N, y2), time_us(launch_v3<16, 2, 2>, x, w, K, M, N, y2),
+           time_us(launch_v3<32, 1, 0>, x, w, K, M, N, y2));
     const double us_s1 = time_us(launch_split<1>, x, w, K, M, N, y);
     const double us_s = time_us(launch_split<2>, x, w, K, M, N, y);
     const double us_f = time_us(launch_f32, x, w, K, M, N, y2);
