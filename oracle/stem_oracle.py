@@ -452,3 +452,99 @@ def build_oracle_model(D: int, L: int, H: int, K: int, Dc: int, *, dropout=0.15,
                               orthogonal_reg_weight=ortho_w, orthogonal_reg_max_codes=ortho_max,
                               ema_update=ema_update)
     return OraclePretrainModel(enc, vq, nn.Linear(D, D), OracleInnerProductDecoder(D, D), nn.Linear(2 * D, D))
+
+
+# --------------------------------------------------------------------------------------
+# Finetune consumer of the path (model/ft_model.py, task/node.py).  PARITY UNPINNED (no
+# reference fixtures; restated from the source).
+# --------------------------------------------------------------------------------------
+def compute_multitask_loss(pred: Tensor, y: Tensor) -> Tensor:
+    """ft_model.py:7-20: masked BCE-with-logits over the label matrix (0 -> -1 encodes 'negative',
+    the in-place edit of ``y`` included)."""
+    y[y == 0] = -1
+    is_valid = y ** 2 > 0
+    loss = 0.0
+    for idx in range(y.shape[1]):
+        exist_y = y[is_valid[:, idx], idx]
+        exist_pred = pred[is_valid[:, idx], idx]
+        loss = loss + F.binary_cross_entropy_with_logits(exist_pred.double(), (exist_y + 1) / 2, reduction="none").sum()
+    return loss / torch.sum(is_valid)
+
+
+class OracleTaskModel(nn.Module):
+    """TaskModel (ft_model.py:23-107): linear decoder on top of encoder + VQ."""
+
+    def __init__(self, encoder: OracleEncoder, vq: OracleVectorQuantize, num_classes: int, params: Dict):
+        super().__init__()
+        self.encoder, self.vq = encoder, vq
+        num_heads, _, code_dim = vq.codebook.shape  # ft_model.py:32
+        self.num_classes = num_classes
+        self.num_heads = num_heads
+        self.separate_decoder_for_each_head = params["separate_decoder_for_each_head"]
+        self.decoder_jac_coeff = params.get("decoder_jac_coeff", 0.0)
+        self.use_vq = params.get("use_vq", 1)
+        if self.separate_decoder_for_each_head:
+            self.decoder = nn.Linear(code_dim * num_heads, num_classes * num_heads)  # ft_model.py:41
+        else:
+            self.decoder = nn.Linear(code_dim, num_classes)
+
+    def decoder_jacobian_penalty(self) -> Tensor:  # ft_model.py:45-50
+        if self.decoder_jac_coeff <= 0:
+            return torch.zeros(())
+        return self.decoder_jac_coeff * self.decoder.weight.pow(2).sum()
+
+    def encode(self, x, edge_index, edge_attr=None, dropout_masks=None):
+        return self.encoder(x, edge_index, edge_attr, dropout_masks=dropout_masks)
+
+    def get_lin_logits(self, z: Tensor, ortho_ids: Optional[Tensor] = None) -> Tensor:  # ft_model.py:90-103
+        if self.use_vq:
+            quantize, _, _, codes = self.vq(z, ortho_ids)
+            if self.separate_decoder_for_each_head:
+                return self.decoder(codes).reshape(-1, self.num_heads, self.num_classes)
+            return self.decoder(quantize).reshape(-1, 1, self.num_classes)
+        if self.separate_decoder_for_each_head:
+            return self.decoder(self.vq.project_in(z)).reshape(-1, self.num_heads, self.num_classes)
+        return self.decoder(z).reshape(-1, 1, self.num_classes)
+
+    def compute_activation_loss(self, z, y, task="single", ortho_ids=None):  # ft_model.py:82-88
+        logits = self.get_lin_logits(z, ortho_ids).mean(1)
+        if task == "single":
+            return F.cross_entropy(logits, y)
+        if task == "multi":
+            return compute_multitask_loss(logits, y)
+        raise ValueError('task must be either "single" or "multi"')
+
+    def forward(self, x, edge_index, edge_attr=None, dropout_masks=None):
+        return self.get_lin_logits(self.encode(x, edge_index, edge_attr, dropout_masks))
+
+
+def ft_node_full_batch_step(model: OracleTaskModel, optimizer, x, edge_index, edge_attr, y, train_mask, params,
+                            dropout_masks=None, ortho_ids=None, scheduler=None) -> Dict[str, Tensor]:
+    """ft_node with loader=None (task/node.py:38-63): encode the whole graph, cross-entropy on the train nodes,
+    decoder penalty, env regulariser, one optimizer step."""
+    model.train()
+    z = model.encode(x, edge_index, edge_attr, dropout_masks)
+    act_loss = model.compute_activation_loss(z[train_mask], y[train_mask], ortho_ids=ortho_ids) * 1.0
+    jac_loss = model.decoder_jacobian_penalty()
+    env_loss = params.get("lamda_env", 0.0) * model.encoder.get_env_reg()
+    loss = act_loss + jac_loss + env_loss
+    optimizer.zero_grad()
+    loss.backward()
+    optimizer.step()
+    if scheduler:
+        scheduler.step()
+    return {"act_loss": act_loss.detach(), "jac_loss": jac_loss.detach(), "env_loss": env_loss.detach(),
+            "loss": loss.detach()}
+
+
+def eval_node_full_batch(model: OracleTaskModel, x, edge_index, edge_attr, y, split: Dict[str, Tensor]):
+    """eval_node with loader=None (task/node.py:106-135): softmax of the head-mean logits, accuracy * 100 per mask
+    (utils/eval.py:11-29; torchmetrics multiclass Accuracy == fraction of arg-max hits)."""
+    model.eval()
+    with torch.no_grad():
+        z = model.encode(x, edge_index, edge_attr)
+        pred = model.get_lin_logits(z).mean(1).softmax(dim=-1)
+        hit = (pred.argmax(dim=-1) == y).float()
+        out = {k: hit[m].mean().item() * 100 for k, m in (("train", split["train"]), ("val", split["valid"]),
+                                                           ("test", split["test"]))}
+    return out, pred

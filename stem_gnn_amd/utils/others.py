@@ -29,3 +29,35 @@ def get_scheduler(optimizer, use_scheduler=True, epochs=1000):
 
 def get_device_from_model(model):
     return next(model.parameters()).device
+
+
+def active_code(encoder, vq, data):
+    """utils/others.py:152-157: the codes a graph activates and their share of the codebook."""
+    z = encoder(data.x, data.edge_index, data.edge_attr)
+    _, indices, _, _ = vq(z)
+    return indices.unique(), indices.unique().numel() / (vq.codebook_size * vq.heads)
+
+
+def load_params(model, path):
+    """utils/others.py:160-171: load an ``encoder_{e}.pt`` / ``vq_{e}.pt`` state dict.  The reference runs one
+    forward of the quantiser first so its k-means initialiser has fired before ``initted`` is overwritten; the
+    module here takes the flag from the state dict directly.  Tensors only are unpickled."""
+    state = torch.load(path, map_location=get_device_from_model(model), weights_only=True)
+    model.load_state_dict(state)
+    return model
+
+
+def freeze_params(model):
+    for param in model.parameters():
+        param.requires_grad = False
+    return model
+
+
+def mask2idx(mask):
+    return torch.where(mask == True)[0]  # noqa: E712  (reference spelling)
+
+
+def idx2mask(idx, num_nodes):
+    mask = torch.zeros(num_nodes, dtype=torch.bool)
+    mask[idx] = 1
+    return mask

@@ -1,0 +1,157 @@
+"""GPU parity tests of the finetune / evaluation consumer (BASELINE config 1: Cora-sized node classification,
+full batch): TaskModel + ft_node / eval_node on the HIP path against the CPU oracle replaying the HIP run's dropout
+draws.  No Cora data can be materialised here: a synthetic graph with Cora's node / edge / feature /
+class counts and unit-norm features stands in."""
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+
+from oracle import stem_oracle as O  # noqa: E402  (checker only)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+class Data:
+    pass
+
+
+def cora_like(seed=0, n=2708, e=10556, d=768, c=7, t=1):
+    g = torch.Generator().manual_seed(seed)
+    half = torch.randint(0, n, (2, e // 2), generator=g)
+    ei = torch.cat([half, half.flip(0)], dim=1)
+    data = Data()
+    data.node_text_feat = torch.nn.functional.normalize(torch.randn(n, d, generator=g), dim=-1)
+    data.edge_text_feat = torch.nn.functional.normalize(torch.randn(t, d, generator=g), dim=-1)
+    data.xe = torch.randint(0, t, (ei.size(1),), generator=g)
+    data.edge_index = ei
+    labels = torch.randint(0, c, (n,), generator=g)
+    perm = torch.randperm(n, generator=g)
+    split = {}
+    for name, lo, hi in (("train", 0, 140), ("valid", 140, 640), ("test", 640, 1640)):
+        m = torch.zeros(n, dtype=torch.bool)
+        m[perm[lo:hi]] = True
+        split[name] = m
+    return data, labels, split
+
+
+def build_pair(D, L, H, K, C, dev, params, dropout=0.15, normalize="none", seed=0):
+    from stem_gnn_amd.model.encoder import Encoder
+    from stem_gnn_amd.model.ft_model import TaskModel
+    from stem_gnn_amd.model.vq import VectorQuantize
+    torch.manual_seed(seed)
+    oenc = O.OracleEncoder(D, D, L, normalize=normalize, dropout=dropout)
+    ovq = O.OracleVectorQuantize(D, K, D, H, decay=0.8, commitment_weight=10, orthogonal_reg_weight=1,
+                                 orthogonal_reg_max_codes=32, ema_update=False)
+    om = O.OracleTaskModel(oenc, ovq, C, params)
+    enc = Encoder(D, D, nn.ReLU, L, backbone="sage", normalize=normalize, dropout=dropout)
+    vq = VectorQuantize(dim=D, codebook_size=K, codebook_dim=D, heads=H, separate_codebook_per_head=True, decay=0.8,
+                        commitment_weight=10, use_cosine_sim=True, orthogonal_reg_weight=1,
+                        orthogonal_reg_max_codes=32, kmeans_init=False, ema_update=False)
+    gm = TaskModel(enc, vq, C, params)
+    gm.load_state_dict(om.state_dict())  # the reference's key names on both sides
+    return om, gm.to(dev)
+
+
+@pytest.mark.parametrize("separate,use_vq,freeze", [(True, 1, 1), (False, 1, 0), (True, 0, 1)])
+def test_cora_sized_finetune_steps_and_eval(dev, separate, use_vq, freeze):
+    from stem_gnn_amd import ops
+    from stem_gnn_amd.task.node import ft_node, eval_node
+    from stem_gnn_amd.utils.others import freeze_params
+    D, L, H, K, C = 768, 2, 4, 128, 7
+    params = {"separate_decoder_for_each_head": separate, "decoder_jac_coeff": 1e-3, "use_vq": use_vq,
+              "setting": "standard", "task": "node", "lamda_env": 0.0}
+    data, labels, split = cora_like()
+    om, gm = build_pair(D, L, H, K, C, dev, params)
+    if freeze:  # finetune.py:178-180
+        freeze_params(om.vq); freeze_params(gm.vq)
+    opt_o = torch.optim.AdamW([p for p in om.parameters()], lr=5e-4)   # config/finetune.yaml node.cora
+    opt_g = torch.optim.AdamW([p for p in gm.parameters()], lr=5e-4)
+    ops.manual_seed(3)
+    N = data.node_text_feat.size(0)
+    ea_cpu = data.edge_text_feat[data.xe]
+    for step in range(3):
+        # the quantiser's orthogonal-loss draw is unused downstream (its loss output is discarded by TaskModel)
+        ids = torch.arange(32)
+        gm.vq._rand_code_ids = lambda n, k, device: ids.to(device)
+        out_g = ft_node(gm, data, None, opt_g, split, labels, params)
+        masks = [ops.dropout_keep_mask(N * D, 0.15, s, o, dev).view(N, D).cpu() for (s, o) in gm.encoder.last_dropout_keys]
+        out_o = O.ft_node_full_batch_step(om, opt_o, data.node_text_feat, data.edge_index, ea_cpu, labels,
+                                          split["train"], params, dropout_masks=masks, ortho_ids=ids)
+        for k in ("act_loss", "jac_loss", "env_loss", "loss"):
+            assert abs(out_g[k] - float(out_o[k])) <= 1e-4 * max(1.0, abs(float(out_o[k]))), (step, k, out_g, out_o)
+    # parameters after three AdamW steps (lr 5e-4: Adam normalises the gradient, so this bounds its direction too)
+    for (n1, p1), (n2, p2) in zip(om.named_parameters(), gm.named_parameters()):
+        assert n1 == n2
+        if p1.requires_grad:
+            torch.testing.assert_close(p2.detach().cpu(), p1.detach(), rtol=1e-3, atol=2e-4, msg=lambda m: f"{n1}: {m}")
+    res_g = eval_node(gm, data, None, split, labels, params)
+    res_o, pred_o = O.eval_node_full_batch(om, data.node_text_feat, data.edge_index, ea_cpu, labels, split)
+    assert res_g["metric"] == "acc"
+    for k in ("train", "val", "test"):
+        # accuracy moves in steps of 100/|mask|: allow one near-tie arg-max flip per mask
+        assert abs(res_g[k] - res_o[k]) <= 100.0 / int(split["valid" if k == "val" else k].sum()) + 1e-6
+    gm.eval()
+    with torch.no_grad():
+        logits = gm(data.node_text_feat.to(dev), data.edge_index.to(dev), ea_cpu.to(dev)).mean(1).softmax(-1)
+    torch.testing.assert_close(logits.cpu(), pred_o, rtol=1e-4, atol=1e-5)
+
+
+def test_minibatch_finetune_and_eval_run_on_the_hip_loader(dev):
+    """ft_node / eval_node with a loader (finetune.py:198-200: NeighborLoader batches), on the HIP sampler: every
+    labelled seed is predicted exactly once and the loss goes down."""
+    from stem_gnn_amd.data.sampler import HipNeighborSampler, NeighborLoader
+    from stem_gnn_amd.task.node import ft_node, eval_node
+    D, L, H, K, C = 128, 2, 4, 64, 7
+    params = {"separate_decoder_for_each_head": True, "decoder_jac_coeff": 0.0, "use_vq": 1, "setting": "standard",
+              "task": "node"}
+    data, labels, split = cora_like(seed=1, d=D, t=3)
+    _, gm = build_pair(D, L, H, K, C, dev, params, dropout=0.0)
+    n = data.node_text_feat.size(0)
+    ei, xe = data.edge_index.to(dev), data.xe.to(dev)
+    sampler = HipNeighborSampler(ei, xe, n, torch.arange(n, device=dev), data.node_text_feat.to(dev),
+                                 data.edge_text_feat.to(dev), [30, 30], seed=0)
+    y_dev = labels.to(dev)
+
+    class Loader:
+        def __init__(self, nodes, shuffle):
+            self.inner = NeighborLoader(sampler, nodes, 512, shuffle=shuffle)
+
+        def __iter__(self):
+            for b in self.inner:
+                b.y = y_dev[b.n_id]
+                yield b
+
+        def __len__(self):
+            return len(self.inner)
+
+    train_nodes = torch.where(split["train"])[0].to(dev)
+    opt = torch.optim.AdamW(gm.parameters(), lr=5e-3)
+    losses = [ft_node(gm, data, Loader(train_nodes, True), opt, split, labels, params)["loss"] for _ in range(8)]
+    assert losses[-1] < losses[0]
+    res = eval_node(gm, data, Loader(torch.arange(n, device=dev), False), split, labels, params)
+    assert 0.0 <= res["test"] <= 100.0 and res["train"] > 100.0 / C  # better than chance on the nodes it trained on
+
+
+def test_eval_metrics_match_their_definitions(dev):
+    from stem_gnn_amd.utils.eval import eval_acc, eval_auc
+    torch.manual_seed(0)
+    pred = torch.rand(1000, 5, device=dev)
+    y = torch.randint(0, 5, (1000,), device=dev)
+    mask = torch.rand(1000, device=dev) < 0.3
+    assert abs(eval_acc(pred, y, mask) - (pred[mask].argmax(1) == y[mask]).float().mean().item()) < 1e-7
+    # AUC against the O(n^2) definition, ties included
+    s = torch.randint(0, 50, (400, 2), device=dev).float()
+    t = (torch.rand(400, 2, device=dev) < 0.4).float()
+    t[::7, 1] = float("nan")
+    exp = []
+    for i in range(2):
+        v = t[:, i] == t[:, i]
+        p, q = s[v, i][t[v, i] == 1], s[v, i][t[v, i] == 0]
+        exp.append(((p[:, None] > q[None, :]).double().mean() + 0.5 * (p[:, None] == q[None, :]).double().mean()).item())
+    assert abs(eval_auc(s, t) - sum(exp) / 2) < 1e-9
