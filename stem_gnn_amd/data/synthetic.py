@@ -16,12 +16,14 @@ class SyntheticGraph:
     edge_index: Tensor        # int64 [2, E], unsorted COO, row 0 = source, row 1 = target
     xe: Tensor                # int64 [E] edge-type id per edge
     x: Tensor                 # int64 [N] node -> row of node_text_feat (identity here)
-    node_text_feat: Tensor    # fp32 [N, D], unit-norm rows
+    node_text_feat: Tensor    # fp32 [N or feat_rows, D], unit-norm rows
     edge_text_feat: Tensor    # fp32 [T, D], unit-norm rows
 
 
 def make_graph(num_nodes: int, num_edges: int, dim: int, num_edge_types: int = 4, kind: str = "U",
-               device="cpu", graph_seed: int = 1234, feat_seed: int = 0) -> SyntheticGraph:
+               device="cpu", graph_seed: int = 1234, feat_seed: int = 0, feat_rows: int = 0) -> SyntheticGraph:
+    """``feat_rows`` > 0: a text table of that many unique rows with ``x`` drawn uniformly into it (the
+    multi-dataset mixes, where many nodes share a text, e.g. atoms); 0: one row per node, ``x`` the identity."""
     if num_edges % 2:
         raise ValueError("num_edges must be even (mirrored undirected pairs)")
     dev = torch.device(device)
@@ -47,6 +49,9 @@ def make_graph(num_nodes: int, num_edges: int, dim: int, num_edge_types: int = 4
     xe_half = torch.randint(0, num_edge_types, (half,), generator=g, device=dev)
     xe = torch.cat([xe_half, xe_half])[shuffle].contiguous()  # both directions of a pair share the type
     gf = torch.Generator(device=dev).manual_seed(feat_seed)
-    ntf = F.normalize(torch.randn(num_nodes, dim, generator=gf, device=dev), dim=-1)
+    rows = feat_rows if feat_rows > 0 else num_nodes
+    ntf = F.normalize(torch.randn(rows, dim, generator=gf, device=dev), dim=-1)
     etf = F.normalize(torch.randn(num_edge_types, dim, generator=gf, device=dev), dim=-1)
-    return SyntheticGraph(num_nodes, ei, xe, torch.arange(num_nodes, device=dev), ntf, etf)
+    x = (torch.randint(0, rows, (num_nodes,), generator=gf, device=dev) if feat_rows > 0
+         else torch.arange(num_nodes, device=dev))
+    return SyntheticGraph(num_nodes, ei, xe, x, ntf, etf)

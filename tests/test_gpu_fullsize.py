@@ -107,3 +107,41 @@ def test_sampler_contract_on_the_20m_edge_graph(dev, c4_graph):
     pos = torch.searchsorted(key_full, key_b).clamp(max=key_full.numel() - 1)
     assert bool((key_full[pos] == key_b).all())
     assert int((s.local_of != -2 ** 31).sum()) == 0
+
+
+def test_c3_sized_full_batch_step_runs_and_learns(dev):
+    """BASELINE config 3 stand-in (169,343 nodes, 2,315,598 directed entries, D = 768, K = 512, full batch): too big
+    for the CPU oracle, so the step is checked through properties: finite decreasing loss, in-range codes, a used
+    codebook, gradients on every trainable parameter, the teacher moved by the EMA and nothing else."""
+    from stem_gnn_amd import ops
+    from stem_gnn_amd.data.synthetic import make_graph
+    from stem_gnn_amd.graph import EdgeTypeAttr, GraphStructure
+    from stem_gnn_amd.pretrain import build_model, build_optimizer, default_params, pretrain_step
+    N, E, D, K = 169_343, 2_315_598, 768, 512
+    g = make_graph(N, E, D, 1, kind="U", device=dev)
+    params = default_params()
+    params.update(input_dim=D, hidden_dim=D, code_dim=D, codebook_size=K, pretrain_batch_size=N)
+    torch.manual_seed(0)
+    model = build_model(params, dev).train()
+    opt, sched = build_optimizer(model, params)
+    gs = GraphStructure(g.edge_index, N, g.xe, validate=True).ensure_transpose()
+    ea = EdgeTypeAttr(g.edge_text_feat, g.xe)
+    teacher0 = [p.detach().clone() for p in model.sem_encoder.parameters()]
+    ops.manual_seed(1)
+    losses = []
+    for _ in range(4):
+        loss, parts, _ = pretrain_step(model, opt, sched, params, g.node_text_feat, gs, ea, N, record_draws=False)
+        losses.append(float(loss))
+        assert all(bool(torch.isfinite(v).all()) for v in parts.values())
+    assert losses[-1] < losses[0]
+    for n_, p in model.named_parameters():
+        if p.requires_grad and not n_.startswith("sem_encoder"):
+            assert p.grad is not None and bool(torch.isfinite(p.grad).all()), n_
+    moved = [float((a - b).abs().max()) for a, b in zip(teacher0, model.sem_encoder.parameters())]
+    assert max(moved) > 0 and max(moved) < 1e-2            # EMA with decay 0.99 of parameters moving by ~lr per step
+    model.eval()
+    with torch.no_grad():
+        z = model.encoder(g.node_text_feat, gs, ea)
+        _, ind, _, _ = model.vq(z)
+    assert tuple(ind.shape) == (N, params["codebook_head"]) and int(ind.min()) >= 0 and int(ind.max()) < K
+    assert ind.unique().numel() > 8

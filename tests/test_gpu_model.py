@@ -186,10 +186,12 @@ def test_encoder_fwd_bwd_vs_oracle(dev, attr):
         torch.testing.assert_close(ge(x.to(dev), ei.to(dev), ea_gpu).cpu(), oe(x, ei, ea_cpu), rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("D,H,K,attr", [(768, 4, 128, "table"), (96, 2, 40, "dense")])
+@pytest.mark.parametrize("D,H,K,attr", [(768, 4, 128, "table"), (96, 2, 40, "dense"), (128, 4, 512, "table"),
+                                        (256, 4, 2048, "table")])
 def test_pretrain_step_other_widths(dev, D, H, K, attr):
     """One full step at the reference's default width (config/pretrain.yaml: D = Dc = 768, H = 4,
-    K = 128; Cora-like size) and at a non-power-of-two width with the dense edge_attr API."""
+    K = 128; Cora-like size), at a non-power-of-two width with the dense edge_attr API, and at the codebook
+    sizes of BASELINE configs 3 and 5 (K = 512, K = 2048)."""
     from stem_gnn_amd import ops
     from stem_gnn_amd.graph import EdgeTypeAttr
     from stem_gnn_amd.pretrain import pretrain_step, default_params
