@@ -137,7 +137,7 @@ def test_c3_sized_full_batch_step_runs_and_learns(dev):
     for n_, p in model.named_parameters():
         if p.requires_grad and not n_.startswith("sem_encoder"):
             assert p.grad is not None and bool(torch.isfinite(p.grad).all()), n_
-    moved = [float((a - b).abs().max()) for a, b in zip(teacher0, model.sem_encoder.parameters())]
+    moved = [float((a - b.detach()).abs().max()) for a, b in zip(teacher0, model.sem_encoder.parameters())]
     assert max(moved) > 0 and max(moved) < 1e-2            # EMA with decay 0.99 of parameters moving by ~lr per step
     model.eval()
     with torch.no_grad():
