@@ -264,6 +264,12 @@ int stemgnn_linear_fwd(const float* x1, const float* w1, int64_t k1, const float
                        const float* bias, int64_t num_rows, int64_t out_dim, float* y, float* stats_partial,
                        int64_t* stats_blocks_host, void* stream);
 
+/* Backward w.r.t. the input of y = x w^T: dx[M, K] = dy[M, N] w[N, K] (autograd of nn.Linear, reference
+ * model/encoder.py:83-87, model/vq.py:881,1041).  The weight is read as stored; no transposed copy is made.
+ * N, K multiples of 4. */
+int stemgnn_linear_bwd_data(const float* dy, const float* w, int64_t num_rows, int64_t out_features,
+                            int64_t in_features, float* dx, void* stream);
+
 /* dw [N, K] = dy [M, N]^T x [M, K];  db [N] = column sums of dy (NULL: skip).  Deterministic
  * two-stage reduction over row splits (no atomics). */
 size_t stemgnn_linear_bwd_weight_workspace_bytes(int64_t num_rows, int64_t out_dim, int64_t in_dim);

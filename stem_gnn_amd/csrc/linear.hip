@@ -65,6 +65,34 @@ __device__ inline void split3(float4 a, uint2& h, uint2& m, uint2& l) {
   m = make_uint2(pack_hi(mb[0], mb[1]), pack_hi(mb[2], mb[3]));
   l = make_uint2(pack_hi(lb[0], lb[1]), pack_hi(lb[2], lb[3]));
 }
+// q[i] = columns c .. c+3 of contraction row 4 (tid & 7) + i (c = 4 (tid >> 3)): split every element and store column j
+// as the 4 consecutive contraction steps of plane row c + j, i.e. the transposed image [column][32 k] the fragment
+// reads want, for an operand whose contraction index is its SLOW dimension.
+__device__ inline void stash_transposed(const float4 (&q)[4], unsigned char* planes, int plane_bytes, int tid) {
+  const int kq = tid & 7, cq = tid >> 3;
+  uint32_t hb[4][4], mb[4][4], lb[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float v[4] = {q[i].x, q[i].y, q[i].z, q[i].w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      hb[i][j] = hi16(v[j]);
+      const float r1 = v[j] - __uint_as_float(hb[i][j]);
+      mb[i][j] = hi16(r1);
+      lb[i][j] = __float_as_uint(r1 - __uint_as_float(mb[i][j]));
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int off = (4 * cq + j) * kLdP + 8 * kq;
+    *reinterpret_cast<uint2*>(planes + off) = make_uint2(pack_hi(hb[0][j], hb[1][j]), pack_hi(hb[2][j], hb[3][j]));
+    *reinterpret_cast<uint2*>(planes + plane_bytes + off) =
+        make_uint2(pack_hi(mb[0][j], mb[1][j]), pack_hi(mb[2][j], mb[3][j]));
+    *reinterpret_cast<uint2*>(planes + 2 * plane_bytes + off) =
+        make_uint2(pack_hi(lb[0][j], lb[1][j]), pack_hi(lb[2][j], lb[3][j]));
+  }
+}
+
 // c += a * b over a 16-wide k step, pieces indexed [0] = h, [1] = m, [2] = l; small terms first
 __device__ inline floatx16 mfma_x3(const bf16x8 (&a)[3], const bf16x8 (&b)[3], floatx16 c) {
   c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);
@@ -86,7 +114,7 @@ __device__ inline int acc_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4
 // ---------------------------------------------------------------------------------------
 // forward: Y = X1 W1^T (+ X2 W2^T) + b
 // ---------------------------------------------------------------------------------------
-template <int BM, bool STATS>
+template <int BM, bool STATS, bool BT = false>
 __global__ void __launch_bounds__(kBlock, 2)
 k_linear_fwd(const float* __restrict__ x1, const float* __restrict__ w1, int K1, const float* __restrict__ x2,
              const float* __restrict__ w2, int K2, const float* __restrict__ bias, int64_t M, int N,
@@ -121,7 +149,13 @@ k_linear_fwd(const float* __restrict__ x1, const float* __restrict__ w1, int K1,
       const int idx = t * kBlock + tid;  // 16-byte column = idx % 8, row = idx / 8
       const int r = idx >> 3, k = k0 + 4 * (idx & 7);
       const int n = n0 + r;
-      rb[t] = (n < N && k < K) ? ld4(ws + static_cast<int64_t>(n) * K + k) : zero4();
+      if (BT) {
+        // weight given as [K][N] (backward-data: dX = dY W): rows k0 + 4 (tid & 7) + t, columns n0 + 4 (tid >> 3) ..+3
+        const int kk = k0 + 4 * (tid & 7) + t, nn = n0 + 4 * (tid >> 3);
+        rb[t] = (kk < K && nn < N) ? ld4(ws + static_cast<int64_t>(kk) * N + nn) : zero4();
+      } else {
+        rb[t] = (n < N && k < K) ? ld4(ws + static_cast<int64_t>(n) * K + k) : zero4();
+      }
       if (t < FA) {
         const int64_t m = m0 + r;
         ra[t] = (m < M && k < K) ? ld4(xs + m * K + k) : zero4();
@@ -132,7 +166,15 @@ k_linear_fwd(const float* __restrict__ x1, const float* __restrict__ w1, int K1,
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int idx = t * kBlock + tid;
-      st4(sB + (idx >> 3) * kLd + 4 * (idx & 7), rb[t]);
+      if (BT) {  // rb[t] = W[k0 + 4 kq + t][n0 + 4 cq .. +3]  ->  sB[n][k]
+        const int kq = tid & 7, cq = tid >> 3;
+        sB[(4 * cq + 0) * kLd + 4 * kq + t] = rb[t].x;
+        sB[(4 * cq + 1) * kLd + 4 * kq + t] = rb[t].y;
+        sB[(4 * cq + 2) * kLd + 4 * kq + t] = rb[t].z;
+        sB[(4 * cq + 3) * kLd + 4 * kq + t] = rb[t].w;
+      } else {
+        st4(sB + (idx >> 3) * kLd + 4 * (idx & 7), rb[t]);
+      }
       if (t < FA) st4(sA + (idx >> 3) * kLd + 4 * (idx & 7), ra[t]);
     }
   };
@@ -221,7 +263,7 @@ k_linear_fwd(const float* __restrict__ x1, const float* __restrict__ w1, int K1,
 }
 
 // The same tile on the bf16 matrix cores (split3 / mfma_x3 above): chunks are split while they are staged.
-template <int BM, bool STATS>
+template <int BM, bool STATS, bool BT = false>
 __global__ void __launch_bounds__(kBlock, 2)
 k_linear_fwd_x3(const float* __restrict__ x1, const float* __restrict__ w1, int K1, const float* __restrict__ x2,
              const float* __restrict__ w2, int K2, const float* __restrict__ bias, int64_t M, int N,
@@ -257,7 +299,13 @@ k_linear_fwd_x3(const float* __restrict__ x1, const float* __restrict__ w1, int 
       const int idx = t * kBlock + tid;  // 16-byte column = idx % 8, row = idx / 8
       const int r = idx >> 3, k = k0 + 4 * (idx & 7);
       const int n = n0 + r;
-      rb[t] = (n < N && k < K) ? ld4(ws + static_cast<int64_t>(n) * K + k) : zero4();
+      if (BT) {
+        // weight given as [K][N] (backward-data: dX = dY W): rows k0 + 4 (tid & 7) + t, columns n0 + 4 (tid >> 3) ..+3
+        const int kk = k0 + 4 * (tid & 7) + t, nn = n0 + 4 * (tid >> 3);
+        rb[t] = (kk < K && nn < N) ? ld4(ws + static_cast<int64_t>(kk) * N + nn) : zero4();
+      } else {
+        rb[t] = (n < N && k < K) ? ld4(ws + static_cast<int64_t>(n) * K + k) : zero4();
+      }
       if (t < FA) {
         const int64_t m = m0 + r;
         ra[t] = (m < M && k < K) ? ld4(xs + m * K + k) : zero4();
@@ -265,15 +313,18 @@ k_linear_fwd_x3(const float* __restrict__ x1, const float* __restrict__ w1, int 
     }
   };
   auto stash = [&]() {
+    if (BT) stash_transposed(rb, sB, PB, tid);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int idx = t * kBlock + tid;
       const int off = (idx >> 3) * kLdP + 8 * (idx & 7);
       uint2 h, m, l;
-      split3(rb[t], h, m, l);
-      *reinterpret_cast<uint2*>(sB + off) = h;
-      *reinterpret_cast<uint2*>(sB + PB + off) = m;
-      *reinterpret_cast<uint2*>(sB + 2 * PB + off) = l;
+      if (!BT) {
+        split3(rb[t], h, m, l);
+        *reinterpret_cast<uint2*>(sB + off) = h;
+        *reinterpret_cast<uint2*>(sB + PB + off) = m;
+        *reinterpret_cast<uint2*>(sB + 2 * PB + off) = l;
+      }
       if (t < FA) {
         split3(ra[t], h, m, l);
         *reinterpret_cast<uint2*>(sA + off) = h;
@@ -496,28 +547,7 @@ k_linear_bwd_weight_x3(const float* __restrict__ dy, const float* __restrict__ x
       rb[i] = (m < mend && k0 + 4 * cq < K) ? ld4(x + m * K + k0 + 4 * cq) : zero4();
     }
   };
-  // q[i] holds columns c .. c+3 of row i: split every element, store column j as the 4 consecutive m of plane row j
-  auto stash_t = [&](const float4 (&q)[4], unsigned char* planes) {
-    uint32_t hb[4][4], mb[4][4], lb[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float v[4] = {q[i].x, q[i].y, q[i].z, q[i].w};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        hb[i][j] = hi16(v[j]);
-        const float r1 = v[j] - __uint_as_float(hb[i][j]);
-        mb[i][j] = hi16(r1);
-        lb[i][j] = __float_as_uint(r1 - __uint_as_float(mb[i][j]));
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int off = (4 * cq + j) * kLdP + 8 * mq;
-      *reinterpret_cast<uint2*>(planes + off) = make_uint2(pack_hi(hb[0][j], hb[1][j]), pack_hi(hb[2][j], hb[3][j]));
-      *reinterpret_cast<uint2*>(planes + PL + off) = make_uint2(pack_hi(mb[0][j], mb[1][j]), pack_hi(mb[2][j], mb[3][j]));
-      *reinterpret_cast<uint2*>(planes + 2 * PL + off) = make_uint2(pack_hi(lb[0][j], lb[1][j]), pack_hi(lb[2][j], lb[3][j]));
-    }
-  };
+  auto stash_t = [&](const float4 (&q)[4], unsigned char* planes) { stash_transposed(q, planes, PL, tid); };
 
   floatx16 acc[2][2];
 #pragma unroll
@@ -582,10 +612,14 @@ k_linear_bwd_weight_x3(const float* __restrict__ dy, const float* __restrict__ x
 // out[i] = sum_s partial[s][i]: 16 float4 columns x 16 split-slices per block, fixed-order LDS
 // tree over the slices (deterministic).
 __global__ void __launch_bounds__(kBlock)
-k_reduce_splits(const float* __restrict__ partial, int splits, int64_t n, float* __restrict__ out) {
+k_reduce_splits(const float* __restrict__ partial, int splits, int64_t n, float* __restrict__ out,
+                const float* __restrict__ partial2, int64_t n2, float* __restrict__ out2, int blocks1) {
+  // blocks [0, blocks1) reduce the first slab family (dW), the rest the second (db), in one launch
   __shared__ float4 red[kBlock];
   const int col = threadIdx.x & 15, slice = threadIdx.x >> 4;
-  const int64_t i = (static_cast<int64_t>(blockIdx.x) * 16 + col) * 4;
+  int bx = blockIdx.x;
+  if (bx >= blocks1) { bx -= blocks1; partial = partial2; n = n2; out = out2; }
+  const int64_t i = (static_cast<int64_t>(bx) * 16 + col) * 4;
   float4 a = zero4();
   if (i < n) {
     for (int s = slice; s < splits; s += 16) {
@@ -772,6 +806,35 @@ int stemgnn_linear_fwd(const float* x1, const float* w1, int64_t K1, const float
   return STEMGNN_OK;
 }
 
+int stemgnn_linear_bwd_data(const float* dy, const float* w, int64_t M, int64_t N, int64_t K, float* dx,
+                            void* stream_) {
+  // dx[M, K] = dy[M, N] w[N, K]: the forward tile with the weight read as stored (contraction index slow) and
+  // transposed while it is staged, instead of a separate transpose kernel and a W^T buffer per call
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  if (!lin_dims_ok(M, K, N) || K % 4 != 0) return STEMGNN_ERR_INVALID_ARG;
+  if (!fits_i32(M)) return STEMGNN_ERR_TOO_LARGE;
+  if (M == 0) return STEMGNN_OK;
+  if (!dy || !w || !dx) return STEMGNN_ERR_INVALID_ARG;
+  const int gy = static_cast<int>((K + kBN - 1) / kBN);
+  const FwdPlan plan = plan_fwd(M, K);
+  const int kc = static_cast<int>(N), n = static_cast<int>(K);
+  const bool x3 = gemm_x3();
+  if (plan.main_tiles > 0) {
+    dim3 grid(static_cast<unsigned>(plan.main_tiles), static_cast<unsigned>(gy));
+    if (x3) k_linear_fwd_x3<128, false, true><<<grid, kBlock, 0, st>>>(dy, w, kc, nullptr, nullptr, 0, nullptr, M, n, dx, nullptr, 0, 0);
+    else k_linear_fwd<128, false, true><<<grid, kBlock, 0, st>>>(dy, w, kc, nullptr, nullptr, 0, nullptr, M, n, dx, nullptr, 0, 0);
+    STEMGNN_LAUNCH_CHECK();
+  }
+  if (plan.tail_tiles > 0) {
+    dim3 grid(static_cast<unsigned>(plan.tail_tiles), static_cast<unsigned>(gy));
+    const int64_t row_base = plan.main_tiles * kBM;
+    if (x3) k_linear_fwd_x3<32, false, true><<<grid, kBlock, 0, st>>>(dy, w, kc, nullptr, nullptr, 0, nullptr, M, n, dx, nullptr, row_base, 0);
+    else k_linear_fwd<32, false, true><<<grid, kBlock, 0, st>>>(dy, w, kc, nullptr, nullptr, 0, nullptr, M, n, dx, nullptr, row_base, 0);
+    STEMGNN_LAUNCH_CHECK();
+  }
+  return STEMGNN_OK;
+}
+
 size_t stemgnn_linear_bwd_weight_workspace_bytes(int64_t M, int64_t N, int64_t K) {
   if (!lin_dims_ok(M, N, K)) return 0;
   return static_cast<size_t>(pick_splits(M, out_tiles(N, K))) * (N * K + N) * sizeof(float) + 512;
@@ -803,12 +866,10 @@ int stemgnn_linear_bwd_weight(const float* dy, const float* x, int64_t M, int64_
                                                  db ? pb : nullptr);
   STEMGNN_LAUNCH_CHECK();
   const int64_t nk = N * K;
-  k_reduce_splits<<<static_cast<unsigned>((nk / 4 + 15) / 16), kBlock, 0, st>>>(pw, S, nk, dw);
+  const int blocks1 = static_cast<int>((nk / 4 + 15) / 16);
+  const int blocks2 = db ? static_cast<int>((N / 4 + 15) / 16) : 0;
+  k_reduce_splits<<<static_cast<unsigned>(blocks1 + blocks2), kBlock, 0, st>>>(pw, S, nk, dw, pb, N, db, blocks1);
   STEMGNN_LAUNCH_CHECK();
-  if (db) {
-    k_reduce_splits<<<static_cast<unsigned>((N / 4 + 15) / 16), kBlock, 0, st>>>(pb, S, N, db);
-    STEMGNN_LAUNCH_CHECK();
-  }
   return STEMGNN_OK;
 }
 

@@ -16,12 +16,16 @@ from torch import Tensor
 from ._lib import check, lib
 
 
-def _stream() -> c_void_p:
-    return c_void_p(torch.cuda.current_stream().cuda_stream)
+_raw_stream = torch._C._cuda_getCurrentRawStream  # the hipStream_t of torch's current stream, without the Stream object
+_cur_device = torch._C._cuda_getDevice
 
 
-def _p(t: Optional[Tensor]) -> Optional[c_void_p]:
-    return None if t is None else c_void_p(t.data_ptr())
+def _stream() -> int:
+    return _raw_stream(_cur_device())
+
+
+def _p(t: Optional[Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()  # ctypes turns the int into the void* argument
 
 
 def _req(t: Tensor, dtype, name: str, ndim: Optional[int] = None) -> Tensor:
@@ -506,6 +510,18 @@ def linear_bwd_weight(dy: Tensor, x: Tensor, want_bias: bool):
     return dw, db
 
 
+def linear_bwd_data(dy: Tensor, w: Tensor) -> Tensor:
+    """dx = dy w for y = x w^T (w [N, K] as stored)."""
+    _req(dy, torch.float32, "dy", 2)
+    _req(w, torch.float32, "w", 2)
+    M, N = dy.shape
+    if w.size(0) != N:
+        raise RuntimeError(f"linear_bwd_data: dy has {N} columns, w has {w.size(0)} rows")
+    dx = torch.empty(M, w.size(1), dtype=torch.float32, device=dy.device)
+    check(lib.stemgnn_linear_bwd_data(_p(dy), _p(w), M, N, w.size(1), _p(dx), _stream()), "linear_bwd_data")
+    return dx
+
+
 def transpose(w: Tensor) -> Tensor:
     _req(w, torch.float32, "w", 2)
     out = torch.empty(w.size(1), w.size(0), dtype=torch.float32, device=w.device)
@@ -537,12 +553,12 @@ class LinearFn(torch.autograd.Function):
         need = ctx.needs_input_grad
         gx1 = gw1 = gx2 = gw2 = gb = None
         if need[0]:
-            gx1, _, _ = linear_fwd(gy, transpose(w1), None, None, None)
+            gx1 = linear_bwd_data(gy, w1)
         if need[1]:
             gw1, gb = linear_bwd_weight(gy, x1, ctx.has_bias and need[4])
         if x2 is not None:
             if need[2]:
-                gx2, _, _ = linear_fwd(gy, transpose(w2), None, None, None)
+                gx2 = linear_bwd_data(gy, w2)
             if need[3]:
                 gw2, gb2 = linear_bwd_weight(gy, x2, ctx.has_bias and need[4] and gb is None)
                 gb = gb if gb is not None else gb2
