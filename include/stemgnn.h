@@ -377,6 +377,17 @@ int stemgnn_gather_rows(const float* table, int64_t num_table_rows, int64_t dim,
  *   teacher = teacher * decay + student * (1 - decay). */
 int stemgnn_ema_lerp(float* teacher, const float* student, int64_t n, float decay, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * torch.nn.utils.clip_grad_norm_(params, max_norm) (reference pretrain.py:62), L2 norm.
+ * grads / sizes are HOST arrays of `count` (<= stemgnn_clip_grad_max_tensors()) device pointers
+ * and element counts.  out[0] = total norm, out[1] = the factor applied (<= 1), both on the
+ * device; the gradients are scaled in place.  fp64 accumulation in a fixed order.
+ * ------------------------------------------------------------------------------------ */
+int32_t stemgnn_clip_grad_max_tensors(void);
+size_t stemgnn_clip_grad_workspace_bytes(int64_t total_elements, int32_t count);
+int stemgnn_clip_grad_norm(float* const* grads, const int64_t* sizes, int32_t count, float max_norm, float* out,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,128 @@
+// Gradient clipping by global L2 norm (reference pretrain.py:62: torch.nn.utils.clip_grad_norm_(params, 1.0)) as
+// three launches over a by-value table of the gradient tensors, instead of ATen's per-call chain (_foreach_norm,
+// stack, vector_norm, add, div, clamp, _foreach_mul: 8-9 launches and as many host round trips through Python).
+//   total = sqrt(sum_i sum(g_i^2))  (fp64 accumulation in a fixed order: reproducible)
+//   coef  = min(1, max_norm / (total + 1e-6));  g_i *= coef  (skipped when coef == 1: x * 1.0f is exact)
+#include "common.h"
+
+namespace stemgnn {
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kMaxTensors = 64;
+constexpr int kChunk = 16384;  // elements per block
+
+struct TensorTable {
+  float* p[kMaxTensors];
+  int64_t n[kMaxTensors];
+  int32_t first_block[kMaxTensors + 1];
+  int32_t count;
+};
+
+__device__ inline int find_tensor(const TensorTable& t, int b) {
+  int i = 0;
+  while (i + 1 < t.count && b >= t.first_block[i + 1]) ++i;
+  return i;
+}
+
+__global__ void __launch_bounds__(kBlock) k_sumsq_partial(TensorTable t, double* __restrict__ partial) {
+  __shared__ double red[kBlock];
+  const int b = blockIdx.x, i = find_tensor(t, b);
+  const int64_t beg = static_cast<int64_t>(b - t.first_block[i]) * kChunk;
+  const int64_t end = beg + kChunk < t.n[i] ? beg + kChunk : t.n[i];
+  const float* g = t.p[i];
+  double s = 0.0;
+  for (int64_t j = beg + threadIdx.x; j < end; j += kBlock) {
+    const double v = g[j];
+    s += v * v;
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = kBlock / 2; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[b] = red[0];
+}
+
+__global__ void __launch_bounds__(kBlock) k_norm_finish(const double* __restrict__ partial, int n, float max_norm,
+                                                        float* __restrict__ out /*[2]: total norm, coef*/) {
+  __shared__ double red[kBlock];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += kBlock) s += partial[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = kBlock / 2; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float total = static_cast<float>(sqrt(red[0]));
+    float coef = max_norm / (total + 1e-6f);  // clip_grad.py: clip_coef = max_norm / (total_norm + 1e-6), clamped to 1
+    if (!(coef < 1.0f)) coef = 1.0f;
+    out[0] = total;
+    out[1] = coef;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) k_scale_tensors(TensorTable t, const float* __restrict__ out) {
+  const float coef = out[1];
+  if (coef >= 1.0f) return;
+  const int b = blockIdx.x, i = find_tensor(t, b);
+  const int64_t beg = static_cast<int64_t>(b - t.first_block[i]) * kChunk;
+  const int64_t end = beg + kChunk < t.n[i] ? beg + kChunk : t.n[i];
+  float* g = t.p[i];
+  for (int64_t j = beg + threadIdx.x; j < end; j += kBlock) g[j] *= coef;
+}
+
+inline int64_t blocks_of(int64_t n) { return (n + kChunk - 1) / kChunk; }
+
+}  // namespace
+}  // namespace stemgnn
+
+using namespace stemgnn;
+
+extern "C" {
+
+int32_t stemgnn_clip_grad_max_tensors(void) { return kMaxTensors; }
+
+size_t stemgnn_clip_grad_workspace_bytes(int64_t total_elements, int32_t count) {
+  if (total_elements < 0 || count < 0) return 0;
+  return static_cast<size_t>(total_elements / kChunk + count + 1) * sizeof(double) + 256;
+}
+
+int stemgnn_clip_grad_norm(float* const* grads, const int64_t* sizes, int32_t count, float max_norm, float* out,
+                           void* workspace, size_t workspace_bytes, void* stream_) {
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  if (count < 0 || count > kMaxTensors || !out || !(max_norm > 0.f)) return STEMGNN_ERR_INVALID_ARG;
+  TensorTable t;
+  int64_t blocks = 0, total = 0;
+  t.count = 0;
+  for (int i = 0; i < count; ++i) {
+    if (sizes[i] < 0 || (sizes[i] > 0 && !grads[i])) return STEMGNN_ERR_INVALID_ARG;
+    if (sizes[i] == 0) continue;
+    t.p[t.count] = grads[i];
+    t.n[t.count] = sizes[i];
+    t.first_block[t.count] = static_cast<int32_t>(blocks);
+    blocks += blocks_of(sizes[i]);
+    total += sizes[i];
+    ++t.count;
+    if (!fits_i32(blocks)) return STEMGNN_ERR_TOO_LARGE;
+  }
+  t.first_block[t.count] = static_cast<int32_t>(blocks);
+  if (!workspace || workspace_bytes < stemgnn_clip_grad_workspace_bytes(total, count)) return STEMGNN_ERR_WORKSPACE;
+  double* partial = reinterpret_cast<double*>(align_up(reinterpret_cast<uintptr_t>(workspace), 256));
+  if (blocks > 0) {
+    k_sumsq_partial<<<static_cast<unsigned>(blocks), kBlock, 0, st>>>(t, partial);
+    STEMGNN_LAUNCH_CHECK();
+  }
+  k_norm_finish<<<1, kBlock, 0, st>>>(partial, static_cast<int>(blocks), max_norm, out);
+  STEMGNN_LAUNCH_CHECK();
+  if (blocks > 0) {
+    k_scale_tensors<<<static_cast<unsigned>(blocks), kBlock, 0, st>>>(t, out);
+    STEMGNN_LAUNCH_CHECK();
+  }
+  return STEMGNN_OK;
+}
+
+}  // extern "C"

@@ -848,6 +848,32 @@ class QueryFanOutFn(torch.autograd.Function):
         return g, None, None
 
 
+_CLIP_MAX = int(lib.stemgnn_clip_grad_max_tensors())
+
+
+def clip_grad_norm_(parameters, max_norm: float) -> Tensor:
+    """torch.nn.utils.clip_grad_norm_(parameters, max_norm) (L2; reference pretrain.py:62) in three launches.
+    Returns the total norm (0-dim tensor).  Gradients that are not dense fp32 on one device, or more than the
+    table holds, go through torch's own implementation."""
+    import ctypes
+    grads = [p.grad for p in parameters if p.grad is not None]
+    if not grads:
+        return torch.zeros(())
+    dev = grads[0].device
+    if (len(grads) > _CLIP_MAX or not grads[0].is_cuda
+            or any(g.dtype != torch.float32 or g.device != dev or not g.is_contiguous() for g in grads)):
+        return torch.nn.utils.clip_grad_norm_([p for p in parameters if p.grad is not None], max_norm)
+    n = len(grads)
+    ptrs = (ctypes.c_void_p * n)(*[g.data_ptr() for g in grads])
+    sizes = (ctypes.c_int64 * n)(*[g.numel() for g in grads])
+    total = sum(sizes)
+    out = torch.empty(2, dtype=torch.float32, device=dev)
+    ws = _workspace(lib.stemgnn_clip_grad_workspace_bytes(total, n), dev)
+    check(lib.stemgnn_clip_grad_norm(ptrs, sizes, n, float(max_norm), _p(out), _p(ws), ws.numel(), _stream()),
+          "clip_grad_norm")
+    return out[0]
+
+
 def gather_rows(table: Tensor, index: Tensor) -> Tensor:
     """out[i] = table[index[i]] (device-side node_text_feat[x] of reference pretrain.py:33-38)."""
     _req(table, torch.float32, "table", 2)

@@ -69,6 +69,17 @@ def build_optimizer(model: nn.Module, params: Dict):
     return opt, sched
 
 
+def _trainable(model):
+    """The parameters that can receive gradients, listed once per module (walking the module tree every step costs
+    more host time than the clip itself).  Set ``model._stemgnn_trainable = None`` after adding or freezing
+    parameters."""
+    plist = getattr(model, "_stemgnn_trainable", None)
+    if plist is None:
+        plist = [p for p in model.parameters() if p.requires_grad]
+        object.__setattr__(model, "_stemgnn_trainable", plist)
+    return plist
+
+
 _LOSS_KEYS = ("feat_recon_loss", "topo_recon_loss", "topo_sem_recon_loss", "sem_recon_loss", "commit_loss",
               "env_reg_loss")
 
@@ -127,7 +138,7 @@ def pretrain_step(model: PretrainModel, optimizer, scheduler, params: Dict, x, e
     loss.backward()
     if grad_sync is not None:
         grad_sync()
-    nn.utils.clip_grad_norm_(model.parameters(), 1.0)  # pretrain.py:62
+    ops.clip_grad_norm_(_trainable(model), 1.0)  # pretrain.py:62
     optimizer.step()
     if scheduler:
         scheduler.step()

@@ -591,3 +591,27 @@ def test_ortho_loss_fn(dev, H, K, Dc, M):
     (out * 2.0).backward()
     torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-4, atol=1e-6)
     torch.testing.assert_close(eg.grad.cpu(), er.grad, rtol=1e-3, atol=1e-6)
+
+
+@pytest.mark.parametrize("scale", [3.0, 1e-3])
+def test_clip_grad_norm_matches_torch(dev, scale):
+    """stemgnn_clip_grad_norm against torch.nn.utils.clip_grad_norm_ (reference pretrain.py:62): clipping case and
+    the no-op case (total norm below max_norm leaves every bit alone), mixed tensor sizes incl. empty and 1-element."""
+    from stem_gnn_amd import ops
+    torch.manual_seed(0)
+    shapes = [(128, 256), (128,), (1,), (0,), (512, 128), (4, 128, 128), (100003,)]
+    ps = [torch.nn.Parameter(torch.zeros(s, device=dev)) for s in shapes]
+    qs = [torch.nn.Parameter(torch.zeros(s, device=dev)) for s in shapes]
+    for p, q in zip(ps, qs):
+        g = torch.randn(p.shape, device=dev) * scale
+        p.grad, q.grad = g.clone(), g.clone()
+    ps.append(torch.nn.Parameter(torch.zeros(3, device=dev)))      # no grad: skipped by both
+    qs.append(torch.nn.Parameter(torch.zeros(3, device=dev)))
+    t_ref = torch.nn.utils.clip_grad_norm_(qs, 1.0)
+    t = ops.clip_grad_norm_(ps, 1.0)
+    torch.testing.assert_close(t, t_ref, rtol=1e-5, atol=0)
+    for p, q in zip(ps[:-1], qs[:-1]):
+        if scale < 1:
+            assert torch.equal(p.grad, q.grad)
+        else:
+            torch.testing.assert_close(p.grad, q.grad, rtol=1e-5, atol=1e-9)
