@@ -90,6 +90,16 @@ int stemgnn_graph_dropout_undirected(const int32_t* rowptr, const int32_t* src, 
  * network + cycle walking); no sort.  out int64 [k]. */
 int stemgnn_sample_subset(int64_t n, int64_t k, uint64_t seed, uint64_t offset, int64_t* out, void* stream);
 
+/* The k-subset of stemgnn_sample_subset (same picks for the same n = num_edges, seed, offset) applied to an edge
+ * list in the launch that draws it (reference model/pt_model.py:55-57,75-80): perm[i] = the pick,
+ * sel_index[0 or sel_stride + i] = edge_index[:, perm[i]] (sel_stride >= k lets the caller place the picks in the
+ * first k columns of a wider [2, *] buffer), sel_type[i] = edge_type[perm[i]], selected[perm[i]] = 1 after the call
+ * has zeroed selected[0, num_edges).  sel_index, sel_type (+ edge_type) and selected may be NULL.
+ * edge_index int64 [2, num_edges] contiguous. */
+int stemgnn_sample_edges(const int64_t* edge_index, const int64_t* edge_type, int64_t num_edges, int64_t k,
+                         uint64_t seed, uint64_t offset, int64_t* perm, int64_t* sel_index, int64_t sel_stride,
+                         int64_t* sel_type, uint8_t* selected, void* stream);
+
 /* mask_feature(x, p, mode='col') (reference pretrain.py:41): zero the feature columns whose
  * Philox draw is < p (keep mask = stemgnn_dropout_keep_mask(D, p, seed, offset)). */
 int stemgnn_mask_columns(const float* x, int64_t num_rows, int64_t dim, float p, uint64_t seed, uint64_t offset,
@@ -101,6 +111,10 @@ int stemgnn_mask_columns(const float* x, int64_t num_rows, int64_t dim, float p,
  * the by-target CSR).  out int64 [2, k]. */
 int stemgnn_negative_sample(const int32_t* rowptr, const int32_t* src, const int32_t* eid, const uint8_t* selected,
                             int64_t num_nodes, int64_t k, uint64_t seed, uint64_t offset, int64_t* out, void* stream);
+/* The same with the two output rows out_stride (>= k) elements apart (writes into a slice of a wider buffer). */
+int stemgnn_negative_sample_into(const int32_t* rowptr, const int32_t* src, const int32_t* eid,
+                                 const uint8_t* selected, int64_t num_nodes, int64_t k, uint64_t seed,
+                                 uint64_t offset, int64_t* out, int64_t out_stride, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Mini-batch neighbour sampler (replaces NeighborLoader(num_neighbors=[f]*L) on the host,

@@ -44,6 +44,8 @@ _SIGNATURES = {
     "stemgnn_sample_subset": (c_int, [I64, I64, c_uint64, c_uint64, P, P]),
     "stemgnn_mask_columns": (c_int, [P, I64, I64, c_float, c_uint64, c_uint64, P, P]),
     "stemgnn_negative_sample": (c_int, [P, P, P, P, I64, I64, c_uint64, c_uint64, P, P]),
+    "stemgnn_negative_sample_into": (c_int, [P, P, P, P, I64, I64, c_uint64, c_uint64, P, I64, P]),
+    "stemgnn_sample_edges": (c_int, [P, P, I64, I64, c_uint64, c_uint64, P, P, I64, P, P, P]),
     "stemgnn_edge_bce_loss": (c_int, [P, I64, I64, P, P, P]),
     "stemgnn_edge_dot_bwd_scaled": (c_int, [P, P, P, I64, I64, P, I64, P, P]),
     "stemgnn_sampler_init_map": (c_int, [P, I64, P]),

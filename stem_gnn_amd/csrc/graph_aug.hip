@@ -103,7 +103,8 @@ k_aug_fill(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src, 
 __global__ void __launch_bounds__(kThreads)
 k_negative_sample(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src,
                   const int32_t* __restrict__ eid, const uint8_t* __restrict__ selected, int64_t N, int64_t k,
-                  uint64_t seed, uint64_t offset, int64_t* __restrict__ out /*[2][k]*/) {
+                  uint64_t seed, uint64_t offset, int64_t* __restrict__ out /*[2][k], rows out_stride apart*/,
+                  int64_t out_stride) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
   if (i >= k) return;
   const uint64_t population = static_cast<uint64_t>(N) * static_cast<uint64_t>(N - 1);
@@ -120,7 +121,7 @@ k_negative_sample(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
     if (!hit) break;
   }
   out[i] = r;
-  out[k + i] = c;
+  out[out_stride + i] = c;
 }
 
 // Uniform k-subset of [0, n) without replacement = the first k outputs of a keyed pseudo-random
@@ -135,10 +136,7 @@ __device__ inline uint32_t feistel_round_fn(uint32_t v, uint32_t key) {
   return x;
 }
 
-__global__ void __launch_bounds__(kThreads)
-k_sample_subset(int64_t n, int64_t k, int half_bits, uint64_t seed, uint64_t offset, int64_t* __restrict__ out) {
-  const int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
-  if (i >= k) return;
+__device__ inline int64_t feistel_pick(int64_t i, int64_t n, int half_bits, uint64_t seed, uint64_t offset) {
   uint32_t keys[8];
   Philox::gen(seed, offset, 0, *reinterpret_cast<uint32_t(*)[4]>(&keys[0]));
   Philox::gen(seed, offset, 1, *reinterpret_cast<uint32_t(*)[4]>(&keys[4]));
@@ -154,7 +152,33 @@ k_sample_subset(int64_t n, int64_t k, int half_bits, uint64_t seed, uint64_t off
     }
     x = (l << half_bits) | r;
   } while (x >= static_cast<uint64_t>(n));
-  out[i] = static_cast<int64_t>(x);
+  return static_cast<int64_t>(x);
+}
+
+__global__ void __launch_bounds__(kThreads)
+k_sample_subset(int64_t n, int64_t k, int half_bits, uint64_t seed, uint64_t offset, int64_t* __restrict__ out) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+  if (i >= k) return;
+  out[i] = feistel_pick(i, n, half_bits, seed, offset);
+}
+
+// The same k picks applied to an edge list in the launch that draws them: the picked columns of edge_index, the
+// picked edge types and the membership mask the negative sampler needs -- instead of four indexing launches.
+__global__ void __launch_bounds__(kThreads)
+k_sample_edges(const int64_t* __restrict__ edge_index, const int64_t* __restrict__ edge_type, int64_t E, int64_t k,
+               int half_bits, uint64_t seed, uint64_t offset, int64_t* __restrict__ perm,
+               int64_t* __restrict__ sel_index, int64_t sel_stride, int64_t* __restrict__ sel_type,
+               uint8_t* __restrict__ selected) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+  if (i >= k) return;
+  const int64_t e = feistel_pick(i, E, half_bits, seed, offset);
+  perm[i] = e;
+  if (sel_index) {
+    sel_index[i] = edge_index[e];
+    sel_index[sel_stride + i] = edge_index[E + e];
+  }
+  if (sel_type) sel_type[i] = edge_type[e];
+  if (selected) selected[e] = 1;
 }
 
 // mask_feature(x, p, mode='col') (reference pretrain.py:41): out = x with column c zeroed when
@@ -266,14 +290,38 @@ int stemgnn_mask_columns(const float* x, int64_t N, int64_t D, float p, uint64_t
   return STEMGNN_OK;
 }
 
+int stemgnn_sample_edges(const int64_t* edge_index, const int64_t* edge_type, int64_t E, int64_t k, uint64_t seed,
+                         uint64_t offset, int64_t* perm, int64_t* sel_index, int64_t sel_stride, int64_t* sel_type,
+                         uint8_t* selected, void* stream_) {
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  if (E < 0 || k < 0 || k > E || (sel_index && sel_stride < k) || (sel_type && !edge_type)) return STEMGNN_ERR_INVALID_ARG;
+  if (selected && E > 0) STEMGNN_HIP_TRY(hipMemsetAsync(selected, 0, static_cast<size_t>(E), st));
+  if (k == 0) return STEMGNN_OK;
+  if (!edge_index || !perm || E >= (1ll << 60)) return STEMGNN_ERR_INVALID_ARG;
+  int bits = 2;
+  while ((1ll << bits) < E) ++bits;
+  if (bits & 1) ++bits;
+  k_sample_edges<<<static_cast<unsigned>((k + kThreads - 1) / kThreads), kThreads, 0, st>>>(
+      edge_index, edge_type, E, k, bits / 2, seed, offset, perm, sel_index, sel_stride, sel_type, selected);
+  STEMGNN_LAUNCH_CHECK();
+  return STEMGNN_OK;
+}
+
 int stemgnn_negative_sample(const int32_t* rowptr, const int32_t* src, const int32_t* eid, const uint8_t* selected,
                             int64_t N, int64_t k, uint64_t seed, uint64_t offset, int64_t* out, void* stream_) {
-  if (N < 0 || k < 0) return STEMGNN_ERR_INVALID_ARG;
+  return stemgnn_negative_sample_into(rowptr, src, eid, selected, N, k, seed, offset, out, k, stream_);
+}
+
+int stemgnn_negative_sample_into(const int32_t* rowptr, const int32_t* src, const int32_t* eid,
+                                 const uint8_t* selected, int64_t N, int64_t k, uint64_t seed, uint64_t offset,
+                                 int64_t* out, int64_t out_stride, void* stream_) {
+  if (N < 0 || k < 0 || out_stride < k) return STEMGNN_ERR_INVALID_ARG;
   if (k == 0) return STEMGNN_OK;
   if (N < 2 || !rowptr || !src || !eid || !selected || !out) return STEMGNN_ERR_INVALID_ARG;
   if (!fits_i32(N)) return STEMGNN_ERR_TOO_LARGE;
   k_negative_sample<<<static_cast<unsigned>((k + kThreads - 1) / kThreads), kThreads, 0,
-                      static_cast<hipStream_t>(stream_)>>>(rowptr, src, eid, selected, N, k, seed, offset, out);
+                      static_cast<hipStream_t>(stream_)>>>(rowptr, src, eid, selected, N, k, seed, offset, out,
+                                                                           out_stride);
   STEMGNN_LAUNCH_CHECK();
   return STEMGNN_OK;
 }

@@ -107,6 +107,23 @@ class PretrainModel(nn.Module):
         full_edge_index = _edge_index_of(pos_edge_index)
         pos_edge_index = full_edge_index
         num_edges = pos_edge_index.size(1)
+        dec = self.topo_recon_decoder
+        replay = draws is not None and ("topo_perm" in draws or "neg_edge_index" in draws)
+        if (ratio != 1.0 and neg_edge_index is None and not replay and z.is_cuda and num_edges > 0
+                and isinstance(dec, InnerProductDecoder)):
+            # one launch draws the positives, gathers their endpoints into the left half of the [2, 2k] index
+            # buffer and flags them; the negative sampler fills the right half (pt_model.py:53-60, no indexing ops)
+            if graph is None:
+                graph = as_graph(full_edge_index, z.size(0))
+            k = max(int(num_edges * ratio), 1)
+            perm, both, _, selected = ops.sample_edges(full_edge_index.contiguous(), None, k, want_selected=True,
+                                                       pad_columns=k)
+            seed, offset = ops.next_dropout_key()
+            ops.negative_sample_into(graph, selected, k, seed, offset, both, k)
+            self.last_draws["topo_perm"] = perm
+            self.last_draws["neg_edge_index"] = both[:, k:]
+            zl = ops.linear(z, dec.lin) if dec.proj_z else z
+            return ops.EdgeBceLossFn.apply(zl, both, k)
         perm = self._sample_edges(num_edges, ratio, z.device, "topo_perm", draws)
         if perm is not None:
             pos_edge_index = pos_edge_index[:, perm]
@@ -218,13 +235,23 @@ class PretrainModel(nn.Module):
         if topo_recon_ratio not in (0.0, 1.0) and query.is_cuda:
             # fused fan-out of the query: one dense gradient buffer for its three consumers
             full_ei = _edge_index_of(orig_edge_index)
-            perm = self._sample_edges(full_ei.size(1), topo_recon_ratio, z.device, "topo_sem_perm", draws)
-            sem_ei = full_ei[:, perm]
+            typed = isinstance(orig_edge_attr, EdgeTypeAttr)
+            fused = (typed and orig_edge_attr.etype is not None and orig_edge_attr.etype.dtype == torch.int64
+                     and not (draws is not None and "topo_sem_perm" in draws) and full_ei.size(1) > 0)
+            if fused:
+                # picks, their endpoints and their edge types in one launch; the target rows in one gather
+                k = max(int(full_ei.size(1) * topo_recon_ratio), 1)
+                perm, sem_ei, sel_type, _ = ops.sample_edges(full_ei.contiguous(), orig_edge_attr.etype, k)
+                self.last_draws["topo_sem_perm"] = perm
+                target = ops.gather_rows(orig_edge_attr.table, sel_type)
+            else:
+                perm = self._sample_edges(full_ei.size(1), topo_recon_ratio, z.device, "topo_sem_perm", draws)
+                sem_ei = full_ei[:, perm]
+                attr = orig_edge_attr[perm]
+                target = attr.dense() if typed else attr
             q_all, q_head, zz = ops.QueryFanOutFn.apply(query, query.size(0) if bs is None else bs, sem_ei)
             feat_recon_loss = ops.MseLossFn.apply(self.feat_recon(q_head), orig_x[:bs])  # pt_model.py:42-43
             topo_recon_loss = self.topo_recon_loss(q_all, orig_edge_index, ratio=topo_recon_ratio, draws=draws)
-            attr = orig_edge_attr[perm]
-            target = attr.dense() if isinstance(attr, EdgeTypeAttr) else attr
             topo_sem_recon_loss = ops.MseLossFn.apply(self._lin(self.topo_sem_recon_decoder, zz), target)  # :80-81
             sem_recon_loss = self.sem_recon_loss(g, q_head, eta=1.0, bs=bs, teacher=teacher)
         else:

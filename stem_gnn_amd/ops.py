@@ -143,6 +143,37 @@ def sample_subset(n: int, k: int, device, key=None) -> Tensor:
     return out
 
 
+def sample_edges(edge_index: Tensor, edge_type: Optional[Tensor], k: int, want_selected: bool = False,
+                 pad_columns: int = 0, key=None):
+    """The picks of ``sample_subset(E, k)`` applied in the same launch: -> (perm [k], picked columns as a
+    [2, k + pad_columns] buffer whose first k columns are filled, picked edge types or None, uint8 membership mask
+    over the E edges or None)."""
+    _req(edge_index, torch.int64, "edge_index", 2)
+    E, dev = edge_index.size(1), edge_index.device
+    seed, offset = key if key is not None else next_dropout_key()
+    perm = torch.empty(k, dtype=torch.int64, device=dev)
+    width = k + pad_columns
+    sel = torch.empty(2, width, dtype=torch.int64, device=dev)
+    sel_type = None
+    if edge_type is not None:
+        _req(edge_type, torch.int64, "edge_type", 1)
+        sel_type = torch.empty(k, dtype=torch.int64, device=dev)
+    selected = torch.empty(E, dtype=torch.uint8, device=dev) if want_selected else None
+    check(lib.stemgnn_sample_edges(_p(edge_index), _p(edge_type), E, k, seed, offset, _p(perm), _p(sel), width,
+                                   _p(sel_type), _p(selected), _stream()), "sample_edges")
+    return perm, sel, sel_type, selected
+
+
+def negative_sample_into(g, selected: Tensor, k: int, seed: int, offset: int, out: Tensor, column: int) -> None:
+    """negative_sample written into columns [column, column + k) of the int64 [2, W] buffer `out`."""
+    _req(selected, torch.uint8, "selected", 1)
+    _req(out, torch.int64, "out", 2)
+    if column < 0 or column + k > out.size(1):
+        raise RuntimeError("negative_sample_into: column range outside the buffer")
+    check(lib.stemgnn_negative_sample_into(_p(g.rowptr), _p(g.src), _p(g.eid), _p(selected), g.num_nodes, k, seed, offset,
+                                           out.data_ptr() + 8 * column, out.size(1), _stream()), "negative_sample_into")
+
+
 def mask_columns(x: Tensor, p: float, key=None):
     """mask_feature(x, p, mode='col'): -> (masked copy, (seed, offset)); keep mask =
     dropout_keep_mask(D, p, seed, offset)."""

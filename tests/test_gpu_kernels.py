@@ -615,3 +615,28 @@ def test_clip_grad_norm_matches_torch(dev, scale):
             assert torch.equal(p.grad, q.grad)
         else:
             torch.testing.assert_close(p.grad, q.grad, rtol=1e-5, atol=1e-9)
+
+
+def test_sample_edges_matches_subset_and_indexing(dev):
+    """stemgnn_sample_edges == sample_subset picks + edge_index[:, perm] + type[perm] + membership mask; the strided
+    negative sampler writes the same pairs as the plain one."""
+    from stem_gnn_amd import ops
+    from stem_gnn_amd.graph import GraphStructure
+    torch.manual_seed(0)
+    n, E, k = 500, 7001, 700
+    ei = torch.randint(0, n, (2, E), device=dev)
+    et = torch.randint(0, 9, (E,), device=dev)
+    key = (77, 1234)
+    perm, sel, sel_type, selected = ops.sample_edges(ei, et, k, want_selected=True, pad_columns=k, key=key)
+    ref = ops.sample_subset(E, k, dev, key=key)
+    assert torch.equal(perm, ref) and perm.unique().numel() == k
+    assert torch.equal(sel[:, :k], ei[:, perm]) and torch.equal(sel_type, et[perm])
+    exp = torch.zeros(E, dtype=torch.uint8, device=dev)
+    exp[perm] = 1
+    assert torch.equal(selected, exp)
+    g = GraphStructure(ei, n)
+    neg = ops.negative_sample(g, selected, k, 5, 6)
+    ops.negative_sample_into(g, selected, k, 5, 6, sel, k)
+    assert torch.equal(sel[:, k:], neg) and torch.equal(sel[:, :k], ei[:, perm])
+    perm2, sel2, t2, m2 = ops.sample_edges(ei, None, 1, key=key)     # k = 1, no types, no mask
+    assert t2 is None and m2 is None and torch.equal(sel2[:, 0], ei[:, perm2[0]])
