@@ -32,82 +32,6 @@ constexpr int kBM = 128, kBN = 128, kKC = 32;
 constexpr int kLd = kKC + 4;  // 36-dword row stride: conflict-free ds_read_b128 of 32 rows x 16 B
 constexpr int kMaxSplits = 512;
 
-typedef float floatx16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-// ---- fp32 products on the bf16 matrix cores (the default path) --------------------------------
-// An fp32 value is cut EXACTLY into three bf16 pieces a = h + m + l: three 8-bit slices of the 24-bit
-// significand, by truncation, so every piece carries the sign of a and each remainder is exact; a bf16
-// is the upper half of the fp32 pattern.  a*b is accumulated (in the fp32 MFMA accumulator) from the
-// six piece products of relative size >= 2^-16 (hh, hm, mh, mm, hl, lh); the dropped ml, lm, ll sum to
-// < 2^-23 |a*b|, the size of ONE fp32 rounding of the product.  Measured against fp64 the result is no
-// further from the truth than the v_mfma_f32_32x32x2_f32 kernel (tools/micro/gemm_bf16x3.hip: max error
-// 1.5e-6 vs 2.0e-6 at K = 128, 6.6e-6 vs 7.2e-6 at K = 512), and six v_mfma_f32_32x32x16_bf16 take 192
-// cycles per 16 k where eight v_mfma_f32_32x32x2_f32 take 512.  Non-finite inputs give NaN where plain
-// fp32 would give Inf (Inf - Inf in the first remainder).
-constexpr int kLdP = 2 * kKC + 16;  // bytes per LDS row of one bf16 plane: 32 k + 16 B pad (conflict-free b128 reads)
-
-__device__ inline uint32_t hi16(float f) { return __float_as_uint(f) & 0xffff0000u; }
-__device__ inline uint32_t pack_hi(uint32_t lo_elem, uint32_t hi_elem) {  // bf16 pair from two fp32 patterns
-  return __builtin_amdgcn_perm(hi_elem, lo_elem, 0x07060302u);
-}
-__device__ inline void split3(float4 a, uint2& h, uint2& m, uint2& l) {
-  const float v[4] = {a.x, a.y, a.z, a.w};
-  uint32_t hb[4], mb[4], lb[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    hb[i] = hi16(v[i]);
-    const float r1 = v[i] - __uint_as_float(hb[i]);
-    mb[i] = hi16(r1);
-    lb[i] = __float_as_uint(r1 - __uint_as_float(mb[i]));  // at most 8 significant bits left: a bf16 value
-  }
-  h = make_uint2(pack_hi(hb[0], hb[1]), pack_hi(hb[2], hb[3]));
-  m = make_uint2(pack_hi(mb[0], mb[1]), pack_hi(mb[2], mb[3]));
-  l = make_uint2(pack_hi(lb[0], lb[1]), pack_hi(lb[2], lb[3]));
-}
-// q[i] = columns c .. c+3 of contraction row 4 (tid & 7) + i (c = 4 (tid >> 3)): split every element and store column j
-// as the 4 consecutive contraction steps of plane row c + j, i.e. the transposed image [column][32 k] the fragment
-// reads want, for an operand whose contraction index is its SLOW dimension.
-__device__ inline void stash_transposed(const float4 (&q)[4], unsigned char* planes, int plane_bytes, int tid) {
-  const int kq = tid & 7, cq = tid >> 3;
-  uint32_t hb[4][4], mb[4][4], lb[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float v[4] = {q[i].x, q[i].y, q[i].z, q[i].w};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      hb[i][j] = hi16(v[j]);
-      const float r1 = v[j] - __uint_as_float(hb[i][j]);
-      mb[i][j] = hi16(r1);
-      lb[i][j] = __float_as_uint(r1 - __uint_as_float(mb[i][j]));
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int off = (4 * cq + j) * kLdP + 8 * kq;
-    *reinterpret_cast<uint2*>(planes + off) = make_uint2(pack_hi(hb[0][j], hb[1][j]), pack_hi(hb[2][j], hb[3][j]));
-    *reinterpret_cast<uint2*>(planes + plane_bytes + off) =
-        make_uint2(pack_hi(mb[0][j], mb[1][j]), pack_hi(mb[2][j], mb[3][j]));
-    *reinterpret_cast<uint2*>(planes + 2 * plane_bytes + off) =
-        make_uint2(pack_hi(lb[0][j], lb[1][j]), pack_hi(lb[2][j], lb[3][j]));
-  }
-}
-
-// c += a * b over a 16-wide k step, pieces indexed [0] = h, [1] = m, [2] = l; small terms first
-__device__ inline floatx16 mfma_x3(const bf16x8 (&a)[3], const bf16x8 (&b)[3], floatx16 c) {
-  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
-  return c;
-}
-
-__device__ inline float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-__device__ inline void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
-__device__ inline float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
-
 // C-tile register r of lane (lj, hi) is row (r&3) + 8*(r>>2) + 4*hi, column lj.
 __device__ inline int acc_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 

@@ -10,7 +10,7 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kMaxTensors = 64;
-constexpr int kChunk = 16384;  // elements per block
+constexpr int kChunk = 2048;  // elements per block (8 per thread: the reduction is latency-bound, not bandwidth-bound)
 
 struct TensorTable {
   float* p[kMaxTensors];

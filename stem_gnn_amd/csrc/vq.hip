@@ -31,18 +31,25 @@ constexpr int kPad = 4;              // row padding (floats): 36-dword stride ->
 constexpr int kLd = kKC + kPad;
 constexpr float kNormEps = 1e-12f;   // F.normalize eps (vq.py:28-29)
 
-typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 __device__ inline float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ inline void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
-template <int CG>
+// X3: the similarity product on the bf16 matrix cores from exact three-way operand pieces (common.h), else
+// v_mfma_f32_32x32x2_f32.  Both are fp32-accurate; they round differently, so an index may differ between the
+// two only where the top-2 similarity gap is at rounding level (the same band the parity tests allow against ATen).
+template <int CG, bool X3>
 __global__ void __launch_bounds__(kBlock, 2)
 k_vq_assign(const float* __restrict__ xp, int64_t N, int H, int Dc, const float* __restrict__ embed, int K,
             int training, float* __restrict__ xn_out, float* __restrict__ norm_out, int64_t* __restrict__ ind_out,
             float* __restrict__ quant, float* __restrict__ sq_partial) {
-  __shared__ __attribute__((aligned(16))) float sA[32 * CG * kLd];
-  __shared__ __attribute__((aligned(16))) float sB[kRowsPerBlock * kLd];
+  constexpr int PA = 32 * CG * kLdP, PB = kRowsPerBlock * kLdP;  // bytes of one bf16 plane (X3)
+  constexpr int kBytesA = X3 ? 3 * PA : 32 * CG * kLd * 4;
+  constexpr int kBytesB = X3 ? 3 * PB : kRowsPerBlock * kLd * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char sA_raw[kBytesA];
+  __shared__ __attribute__((aligned(16))) unsigned char sB_raw[kBytesB];
+  float* sA = reinterpret_cast<float*>(sA_raw);
+  float* sB = reinterpret_cast<float*>(sB_raw);
   __shared__ float s_inv[kRowsPerBlock];
   __shared__ float s_red[kBlock / kWave];
 
@@ -96,12 +103,30 @@ k_vq_assign(const float* __restrict__ xp, int64_t N, int H, int Dc, const float*
 #pragma unroll
     for (int t = 0; t < CG; ++t) {
       const int idx = t * kBlock + tid;
-      st4(sA + (idx >> 3) * kLd + 4 * (idx & 7), ra[t]);
+      if (X3) {
+        const int off = (idx >> 3) * kLdP + 8 * (idx & 7);
+        uint2 h, m, l;
+        split3(ra[t], h, m, l);
+        *reinterpret_cast<uint2*>(sA_raw + off) = h;
+        *reinterpret_cast<uint2*>(sA_raw + PA + off) = m;
+        *reinterpret_cast<uint2*>(sA_raw + 2 * PA + off) = l;
+      } else {
+        st4(sA + (idx >> 3) * kLd + 4 * (idx & 7), ra[t]);
+      }
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int idx = t * kBlock + tid;
-      st4(sB + (idx >> 3) * kLd + 4 * (idx & 7), rb[t]);
+      if (X3) {
+        const int off = (idx >> 3) * kLdP + 8 * (idx & 7);
+        uint2 h, m, l;
+        split3(rb[t], h, m, l);
+        *reinterpret_cast<uint2*>(sB_raw + off) = h;
+        *reinterpret_cast<uint2*>(sB_raw + PB + off) = m;
+        *reinterpret_cast<uint2*>(sB_raw + 2 * PB + off) = l;
+      } else {
+        st4(sB + (idx >> 3) * kLd + 4 * (idx & 7), rb[t]);
+      }
     }
   };
 
@@ -122,9 +147,25 @@ k_vq_assign(const float* __restrict__ xp, int64_t N, int H, int Dc, const float*
     stash();
     __syncthreads();
     if (step + 1 < steps) fetch(step + 1);
+    if (X3) {
+#pragma unroll
+      for (int ks = 0; ks < kKC / 16; ++ks) {
+        const int ko = ks * 32 + hi * 16;  // bytes: lane half 0 takes k 0..7, half 1 k 8..15 of the 16-wide step
+        bf16x8 b[3], a[CG][3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          b[p] = *reinterpret_cast<const bf16x8*>(sB_raw + p * PB + (wave * 32 + lj) * kLdP + ko);
+#pragma unroll
+          for (int t = 0; t < CG; ++t)
+            a[t][p] = *reinterpret_cast<const bf16x8*>(sA_raw + p * PA + (t * 32 + lj) * kLdP + ko);
+        }
+#pragma unroll
+        for (int t = 0; t < CG; ++t) acc[t] = mfma_x3(a[t], b, acc[t]);
+      }
+    }
     // 4 micro-steps of 8 k each: half 0 takes k 0..3, half 1 takes k 4..7 of the micro-step
 #pragma unroll
-    for (int ms = 0; ms < kKC / 8; ++ms) {
+    for (int ms = 0; ms < (X3 ? 0 : kKC / 8); ++ms) {
       const int ko = ms * 8 + hi * 4;
       const float4 b = ld4(sB + (wave * 32 + lj) * kLd + ko);
       float4 a[CG];
@@ -356,12 +397,18 @@ int stemgnn_vq_assign_fwd(const float* xp, int64_t N, int64_t H, int64_t Dc, con
   const int64_t rb = row_blocks(N);
   dim3 grid(static_cast<unsigned>(rb), static_cast<unsigned>(H));
   const int Hi = static_cast<int>(H), Dci = static_cast<int>(Dc), Ki = static_cast<int>(K);
-  if (K <= 32)
-    k_vq_assign<1><<<grid, kBlock, 0, st>>>(xp, N, Hi, Dci, embed, Ki, training, xn, norm, ind, quant, partial);
-  else if (K <= 64)
-    k_vq_assign<2><<<grid, kBlock, 0, st>>>(xp, N, Hi, Dci, embed, Ki, training, xn, norm, ind, quant, partial);
-  else
-    k_vq_assign<4><<<grid, kBlock, 0, st>>>(xp, N, Hi, Dci, embed, Ki, training, xn, norm, ind, quant, partial);
+  const bool x3 = stemgnn_linear_set_mode(-1) == 1;  // the mode of the dense products (csrc/linear.hip)
+#define STEMGNN_VQ_LAUNCH(CG)                                                                                         \
+  do {                                                                                                                \
+    if (x3) k_vq_assign<CG, true><<<grid, kBlock, 0, st>>>(xp, N, Hi, Dci, embed, Ki, training, xn, norm, ind, quant, \
+                                                            partial);                                                 \
+    else k_vq_assign<CG, false><<<grid, kBlock, 0, st>>>(xp, N, Hi, Dci, embed, Ki, training, xn, norm, ind, quant,   \
+                                                          partial);                                                   \
+  } while (0)
+  if (K <= 32) STEMGNN_VQ_LAUNCH(1);
+  else if (K <= 64) STEMGNN_VQ_LAUNCH(2);
+  else STEMGNN_VQ_LAUNCH(4);
+#undef STEMGNN_VQ_LAUNCH
   STEMGNN_LAUNCH_CHECK();
   k_sum_partials<<<1, kBlock, 0, st>>>(partial, rb * H, sqerr);
   STEMGNN_LAUNCH_CHECK();
