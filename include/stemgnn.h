@@ -229,10 +229,11 @@ int stemgnn_bn_stats(const float* y, int64_t num_rows, int64_t dim, float eps,
                      void* workspace, size_t workspace_bytes, void* stream);
 
 /* Same finalisation from per-block column partials [blocks][2][D] (sum, sum of squares) that a
- * producer kernel already wrote (stemgnn_linear_fwd's fused statistics). */
+ * producer kernel already wrote (stemgnn_linear_fwd's fused statistics).  num_batches_tracked != NULL:
+ * BatchNorm1d's int64 call counter, incremented by one in the same launch. */
 int stemgnn_bn_stats_from_partials(const float* partial, int64_t blocks, int64_t num_rows, int64_t dim, float eps,
                                    float* mean, float* rstd, float* running_mean, float* running_var,
-                                   float momentum, void* stream);
+                                   float momentum, int64_t* num_batches_tracked, void* stream);
 
 /* out = dropout(act((y - mean) * rstd * gamma + beta)).
  * act: 0 none, 1 relu / leaky-relu with `negative_slope`.  p = 0 disables dropout; the keep

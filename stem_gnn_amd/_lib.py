@@ -67,7 +67,7 @@ _SIGNATURES = {
     "stemgnn_inv_degree": (c_int, [P, I64, P, P]),
     "stemgnn_bn_workspace_bytes": (c_size_t, [I64, I64]),
     "stemgnn_bn_stats": (c_int, [P, I64, I64, c_float, P, P, P, P, c_float, P, c_size_t, P]),
-    "stemgnn_bn_stats_from_partials": (c_int, [P, I64, I64, I64, c_float, P, P, P, P, c_float, P]),
+    "stemgnn_bn_stats_from_partials": (c_int, [P, I64, I64, I64, c_float, P, P, P, P, c_float, P, P]),
     "stemgnn_linear_stats_partial_bytes": (c_size_t, [I64, I64]),
     "stemgnn_linear_stats_blocks": (I64, [I64, I64]),
     "stemgnn_clip_grad_max_tensors": (I32, []),

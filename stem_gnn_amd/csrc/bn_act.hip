@@ -163,9 +163,10 @@ __device__ inline void reduce_partials(const float* __restrict__ partial, int bl
 __global__ void __launch_bounds__(kBlock)
 k_stats_finalize(const float* __restrict__ partial, int blocks, int64_t N, int D, float eps,
                  float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ running_mean,
-                 float* __restrict__ running_var, float momentum) {
+                 float* __restrict__ running_var, float momentum, int64_t* __restrict__ num_batches_tracked) {
   const int cl = threadIdx.x % kFinCols, slice = threadIdx.x / kFinCols;
   const int c = blockIdx.x * kFinCols + cl;
+  if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) num_batches_tracked[0] += 1;  // BatchNorm1d's counter
   double s, q;
   reduce_partials(partial, blocks, D, c, slice, &s, &q);
   if (slice != 0 || c >= D) return;
@@ -300,20 +301,21 @@ int stemgnn_bn_stats(const float* y, int64_t N, int64_t D, float eps, float* mea
                                                nullptr, nullptr, ep, partial);
   STEMGNN_LAUNCH_CHECK();
   k_stats_finalize<<<static_cast<int>((D + kFinCols - 1) / kFinCols), kBlock, 0, st>>>(
-      partial, blocks, N, static_cast<int>(D), eps, mean, rstd, running_mean, running_var, momentum);
+      partial, blocks, N, static_cast<int>(D), eps, mean, rstd, running_mean, running_var, momentum, nullptr);
   STEMGNN_LAUNCH_CHECK();
   return STEMGNN_OK;
 }
 
 int stemgnn_bn_stats_from_partials(const float* partial, int64_t blocks, int64_t N, int64_t D, float eps, float* mean,
                                    float* rstd, float* running_mean, float* running_var, float momentum,
-                                   void* stream_) {
+                                   int64_t* num_batches_tracked, void* stream_) {
   hipStream_t st = static_cast<hipStream_t>(stream_);
   if (!dims_ok(N, D) || N == 0 || blocks <= 0 || blocks > (1 << 24) || !partial || !mean || !rstd)
     return STEMGNN_ERR_INVALID_ARG;
   if ((running_mean == nullptr) != (running_var == nullptr)) return STEMGNN_ERR_INVALID_ARG;
   k_stats_finalize<<<static_cast<int>((D + kFinCols - 1) / kFinCols), kBlock, 0, st>>>(
-      partial, static_cast<int>(blocks), N, static_cast<int>(D), eps, mean, rstd, running_mean, running_var, momentum);
+      partial, static_cast<int>(blocks), N, static_cast<int>(D), eps, mean, rstd, running_mean, running_var, momentum,
+      num_batches_tracked);
   STEMGNN_LAUNCH_CHECK();
   return STEMGNN_OK;
 }

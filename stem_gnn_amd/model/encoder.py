@@ -300,15 +300,20 @@ class Encoder(nn.Module):
             self.last_dropout_keys.append((seed, offset))
         if use_bn:
             momentum = norm.momentum
+            fused_stats = partial is not None and z.size(0) > 1
+            nbt = None
             if norm.track_running_stats:
-                norm.num_batches_tracked.add_(1)
-                if momentum is None:
-                    momentum = 1.0 / float(norm.num_batches_tracked)
+                if fused_stats and momentum is not None and norm.num_batches_tracked.is_cuda:
+                    nbt = norm.num_batches_tracked  # bumped inside the statistics launch
+                else:
+                    norm.num_batches_tracked.add_(1)
+                    if momentum is None:
+                        momentum = 1.0 / float(norm.num_batches_tracked)
             rm = norm.running_mean if norm.track_running_stats else None
             rv = norm.running_var if norm.track_running_stats else None
             stats = None
-            if partial is not None and z.size(0) > 1:
-                stats = ops.bn_stats_from_partials(partial, partial.size(0), z.size(0), norm.eps, rm, rv, momentum)
+            if fused_stats:
+                stats = ops.bn_stats_from_partials(partial, partial.size(0), z.size(0), norm.eps, rm, rv, momentum, nbt)
             return ops.BnActDropFn.apply(z, norm.weight, norm.bias, rm, rv, True, momentum, norm.eps, act,
                                          self._slope, p, seed, offset, stats)
         return ops.BnActDropFn.apply(z, None, None, None, None, False, 0.0, 0.0, act, self._slope, p, seed, offset)

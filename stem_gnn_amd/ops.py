@@ -435,13 +435,18 @@ def bn_stats(y: Tensor, eps: float, running_mean: Optional[Tensor], running_var:
 
 
 def bn_stats_from_partials(partial: Tensor, blocks: int, num_rows: int, eps: float, running_mean: Optional[Tensor],
-                           running_var: Optional[Tensor], momentum: float) -> Tuple[Tensor, Tensor]:
-    """Finalise BatchNorm statistics from the column partials LinearFn's fused epilogue wrote."""
+                           running_var: Optional[Tensor], momentum: float,
+                           num_batches_tracked: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+    """Finalise BatchNorm statistics from the column partials LinearFn's fused epilogue wrote (and bump the
+    module's int64 call counter in the same launch when it is given)."""
+    if num_batches_tracked is not None:
+        _req(num_batches_tracked, torch.int64, "num_batches_tracked")
     D = partial.size(-1)
     mean = torch.empty(D, dtype=torch.float32, device=partial.device)
     rstd = torch.empty_like(mean)
     check(lib.stemgnn_bn_stats_from_partials(_p(partial), blocks, num_rows, D, float(eps), _p(mean), _p(rstd),
-                                             _p(running_mean), _p(running_var), float(momentum), _stream()),
+                                             _p(running_mean), _p(running_var), float(momentum),
+                                             _p(num_batches_tracked), _stream()),
           "bn_stats_from_partials")
     return mean, rstd
 
