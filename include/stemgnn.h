@@ -256,7 +256,7 @@ int stemgnn_bn_act_drop_bwd(const float* g_out, const float* y, int64_t num_rows
 int stemgnn_dropout_keep_mask(int64_t n, float p, uint64_t seed, uint64_t offset, uint8_t* keep, void* stream);
 
 /* ------------------------------------------------------------------------------------
- * K3 / K5: dense projections on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, exact fp32).
+ * K3 / K5: dense projections on the matrix cores, fp32 results (see stemgnn_linear_set_mode).
  * Replaces lin_l(agg) + lin_r(x) (model/encoder.py:83-87), project_in / project_out
  * (model/vq.py:881,1041) and the decoders' nn.Linear (model/pt_model.py:42,80,94).
  * All matrices dense row-major fp32; K1, K2, N multiples of 4.
@@ -298,7 +298,7 @@ int stemgnn_transpose(const float* in, int64_t rows, int64_t cols, float* out, v
  * K6+K7+K8: cosine-similarity codebook assignment, fused.
  * Replaces l2norm (model/vq.py:891) + CosineSimCodebook.forward's einsum / argmax /
  * one-hot / einsum (vq.py:650-657) + straight-through and commitment MSE
- * (vq.py:931-937,1007-1009).  fp32 MFMA (v_mfma_f32_32x32x2_f32), exact fp32.
+ * (vq.py:931-937,1007-1009).  fp32-accurate similarity product (same mode as the dense products).
  *   xp      [N, H*Dc]  project_in output, head h in columns [h*Dc, (h+1)*Dc)
  *   embed   [H, K, Dc]
  *   xn      [N, H*Dc]  optional (may be NULL): l2-normalised input

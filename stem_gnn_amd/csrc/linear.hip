@@ -1,24 +1,28 @@
-// K3 / K5: dense per-layer projections on the fp32 matrix cores of gfx950.
+// K3 / K5: dense per-layer projections on the matrix cores of gfx950, fp32 results.
 //
 // Reference: MySAGEConv's lin_l(agg) + lin_r(x) (STEM-GNN/model/encoder.py:83-87),
 // VectorQuantize.project_in / project_out (model/vq.py:881,1041) and the decoders' nn.Linear
 // layers (model/pt_model.py:42,80,94; model/encoder.py:364).  The reference leaves these to
-// ATen/cuBLAS plus separate bias-add, add and bias-gradient reduction kernels.  The activations
-// here are tall and skinny (M ~ 1e5 rows, N, K in {128, 256, 512}), a shape the vendor GEMM
-// library serves badly on this chip (12-30 TFLOP/s for the weight-gradient product), so the
-// three products are hand-written around v_mfma_f32_32x32x2_f32 (exact fp32; the reference runs
-// fp32 without autocast):
+// ATen/cuBLAS plus separate bias-add, add, transpose and bias-gradient reduction kernels.  The
+// activations here are tall and skinny (M ~ 1e5 rows, N, K in {128, 256, 512}), a shape the vendor GEMM
+// library serves badly on this chip (12-30 TFLOP/s for the weight-gradient product), so the three
+// products are hand-written:
 //
 //   forward     Y[M,N]  = X1[M,K1] W1[N,K1]^T (+ X2[M,K2] W2[N,K2]^T) + b      (fused K-concat)
 //                         optional per-column sum / sum-of-squares partials of Y (BatchNorm stats)
 //   backward-W  dW[N,K] = dY[M,N]^T X[M,K],  db[N] = colsum(dY)   (split over M, two-stage,
 //                         deterministic: no atomics)
-//   backward-X  dX[M,K] = dY[M,N] W[N,K]  = forward with the transposed weight
+//   backward-X  dX[M,K] = dY[M,N] W[N,K]  = the forward tile reading W as stored (BT)
+//
+// Two instruction paths, both fp32-accurate (the reference runs fp32 without autocast):
+//   *_x3 (default)  v_mfma_f32_32x32x16_bf16 on exact three-way bf16 pieces of the fp32 operands
+//                   (common.h: split3 / mfma_x3): six MFMAs of 32 cycles per 16 k;
+//   plain           v_mfma_f32_32x32x2_f32: eight MFMAs of 64 cycles per 16 k; kept as the cross-check
+//                   (stemgnn_linear_set_mode(0) / STEMGNN_GEMM=f32).
 //
 // Tiling: 256-thread block = 4 waves in a 2x2 grid, 128x128 output tile, each wave 64x64 =
 // 2x2 MFMA tiles (64 accumulator registers); K (or M for backward-W) is consumed in chunks of
-// 32 staged through LDS with register prefetch of the next chunk.  MFMA-bound:
-// 2*M*N*K flop at 157 TFLOP/s vs (M*K + M*N)*4 bytes of HBM traffic.
+// 32 staged through LDS with register prefetch of the next chunk.
 #include "common.h"
 
 #include <atomic>

@@ -566,7 +566,7 @@ def transpose(w: Tensor) -> Tensor:
 
 
 class LinearFn(torch.autograd.Function):
-    """y = x1 w1^T (+ x2 w2^T) + b on the fp32 MFMA path; returns (y, column partials or None).
+    """y = x1 w1^T (+ x2 w2^T) + b on the matrix cores (fp32 result, csrc/linear.hip); returns (y, column partials or None).
     Replaces nn.Linear / lin_l + lin_r (reference model/encoder.py:83-87, model/vq.py:881,1041)."""
 
     @staticmethod

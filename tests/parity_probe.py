@@ -1,8 +1,9 @@
-"""Print per-step, per-term relative differences between the HIP path and the CPU oracle."""
+"""Print per-step, per-term relative differences between the HIP path and the CPU oracle (a test aid: it lives
+under tests/ because only tests may use the oracle).  Run on the GPU box: python tests/parity_probe.py"""
 import os, sys
 import torch, torch.nn as nn
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from oracle import stem_oracle as O
 from test_gpu_model import make_models
 from stem_gnn_amd import ops

@@ -230,7 +230,7 @@ def test_pretrain_steps_loss_parity(dev):
     om, gm = make_models(D, L, H, K, D, dev)
     params = default_params()  # the reference's lr 1e-4 (config/pretrain.yaml:18).  Adam turns rounding-level gradient
     # differences on near-zero-gradient elements into +-lr steps, so at a 10x larger lr a single such
-    # element shows up as a transient 1e-4 loss difference (tools/parity_probe.py prints both regimes).
+    # element shows up as a transient 1e-4 loss difference (tests/parity_probe.py prints both regimes).
     torch.manual_seed(11)
     x = torch.nn.functional.normalize(torch.randn(N, D), dim=-1)
     half = torch.randint(0, N, (2, E // 2))
