@@ -403,6 +403,21 @@ size_t stemgnn_clip_grad_workspace_bytes(int64_t total_elements, int32_t count);
 int stemgnn_clip_grad_norm(float* const* grads, const int64_t* sizes, int32_t count, float max_norm, float* out,
                            void* workspace, size_t workspace_bytes, void* stream);
 
+/* out[0] = total L2 norm of the gradients, out[1] = min(1, max_norm / (out[0] + 1e-6)); nothing is scaled.
+ * Same host arrays and workspace as stemgnn_clip_grad_norm. */
+int stemgnn_grad_norm_coef(const float* const* grads, const int64_t* sizes, int32_t count, float max_norm, float* out,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
+/* One AdamW update (torch.optim.AdamW semantics, amsgrad off; reference pretrain.py:134-136,63) of `count`
+ * (<= stemgnn_clip_grad_max_tensors()) tensors in one launch.  params / grads / exp_avg / exp_avg_sq / sizes are
+ * HOST arrays of device pointers and element counts; `step` is the 1-based update count (bias correction);
+ * grad_coef (device, may be NULL) multiplies every gradient as it is read -- pass out + 1 of
+ * stemgnn_grad_norm_coef to apply clip_grad_norm_ without a pass over the gradients. */
+int stemgnn_adamw_step(float* const* params, const float* const* grads, float* const* exp_avg,
+                       float* const* exp_avg_sq, const int64_t* sizes, int32_t count, float lr, float beta1,
+                       float beta2, float eps, float weight_decay, int64_t step, const float* grad_coef,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -73,6 +73,8 @@ _SIGNATURES = {
     "stemgnn_clip_grad_max_tensors": (I32, []),
     "stemgnn_clip_grad_workspace_bytes": (c_size_t, [I64, I32]),
     "stemgnn_clip_grad_norm": (c_int, [P, P, I32, c_float, P, P, c_size_t, P]),
+    "stemgnn_grad_norm_coef": (c_int, [P, P, I32, c_float, P, P, c_size_t, P]),
+    "stemgnn_adamw_step": (c_int, [P, P, P, P, P, I32, c_float, c_float, c_float, c_float, c_float, I64, P, P]),
     "stemgnn_linear_set_mode": (c_int, [c_int]),
     "stemgnn_linear_bwd_data": (c_int, [P, P, I64, I64, I64, P, P]),
     "stemgnn_linear_fwd": (c_int, [P, P, I64, P, P, I64, P, I64, I64, P, P, P, P]),

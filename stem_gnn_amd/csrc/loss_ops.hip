@@ -120,17 +120,21 @@ __global__ void __launch_bounds__(256) k_cos_bwd(const float* __restrict__ z, co
 // row ids[i] of the dense codebook gradient (zero elsewhere; ids are distinct).
 constexpr int kOrthoMaxPerLane = 16;  // Dc <= 1024
 
-template <bool BWD>
+// One wave per (head, selected code i); Q = columns per lane (Dc <= 64 Q).  The loop over the other codes j is
+// latency-bound (id -> row -> two wave reductions per j), so the ids of a 64-wide chunk are read at once and four
+// rows are in flight per round.
+template <bool BWD, int Q>
 __global__ void __launch_bounds__(64)
 k_ortho(const float* __restrict__ embed, const int64_t* __restrict__ ids, int H, int K, int Dc, int M, float scale,
         const float* __restrict__ g, double* __restrict__ partial /*[H*M]*/, float* __restrict__ g_embed) {
+  constexpr int U = 4;
   const int h = blockIdx.x / M, i = blockIdx.x - h * M, lane = threadIdx.x;
   const float* eh = embed + static_cast<int64_t>(h) * K * Dc;
   const float* ei = eh + ids[i] * Dc;
-  float ci[kOrthoMaxPerLane], gc[kOrthoMaxPerLane];
+  float ci[Q], gc[Q];
   float ss = 0.f;
 #pragma unroll
-  for (int q = 0; q < kOrthoMaxPerLane; ++q) {
+  for (int q = 0; q < Q; ++q) {
     const int c = lane + 64 * q;
     ci[q] = c < Dc ? ei[c] : 0.f;
     gc[q] = 0.f;
@@ -139,27 +143,43 @@ k_ortho(const float* __restrict__ embed, const int64_t* __restrict__ ids, int H,
   ss = wave_sum(ss);
   const float inv_i = 1.0f / fmaxf(sqrtf(ss), kNormEps);
 #pragma unroll
-  for (int q = 0; q < kOrthoMaxPerLane; ++q) ci[q] *= inv_i;
+  for (int q = 0; q < Q; ++q) ci[q] *= inv_i;
   double acc = 0.0;
-  for (int j = 0; j < M; ++j) {
-    const float* ej = eh + ids[j] * Dc;
-    float ej_v[kOrthoMaxPerLane];
-    float sj = 0.f, dij = 0.f;
+  for (int j0 = 0; j0 < M; j0 += 64) {
+    const int cnt = min(64, M - j0);
+    const int my_id = lane < cnt ? static_cast<int>(ids[j0 + lane]) : 0;
+    for (int jj = 0; jj < cnt; jj += U) {
+      float ej_v[U][Q];
 #pragma unroll
-    for (int q = 0; q < kOrthoMaxPerLane; ++q) {
-      const int c = lane + 64 * q;
-      ej_v[q] = c < Dc ? ej[c] : 0.f;
-      sj += ej_v[q] * ej_v[q];
-      dij += ci[q] * ej_v[q];
-    }
-    sj = wave_sum(sj);
-    dij = wave_sum(dij);
-    const float inv_j = 1.0f / fmaxf(sqrtf(sj), kNormEps);
-    const float gij = dij * inv_j;
-    acc += static_cast<double>(gij) * gij;
-    if (BWD) {
+      for (int u = 0; u < U; ++u) {
+        const int id = __shfl(my_id, jj + u < cnt ? jj + u : jj, 64);  // clamp: duplicate row, masked below
+        const float* ej = eh + static_cast<int64_t>(id) * Dc;
 #pragma unroll
-      for (int q = 0; q < kOrthoMaxPerLane; ++q) gc[q] += gij * ej_v[q] * inv_j;
+        for (int q = 0; q < Q; ++q) {
+          const int c = lane + 64 * q;
+          ej_v[u][q] = c < Dc ? ej[c] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float sj = 0.f, dij = 0.f;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+          sj += ej_v[u][q] * ej_v[u][q];
+          dij += ci[q] * ej_v[u][q];
+        }
+        sj = wave_sum(sj);
+        dij = wave_sum(dij);
+        if (jj + u < cnt) {  // wave-uniform
+          const float inv_j = 1.0f / fmaxf(sqrtf(sj), kNormEps);
+          const float gij = dij * inv_j;
+          acc += static_cast<double>(gij) * gij;
+          if (BWD) {
+#pragma unroll
+            for (int q = 0; q < Q; ++q) gc[q] += gij * ej_v[u][q] * inv_j;
+          }
+        }
+      }
     }
   }
   if (!BWD) {
@@ -168,15 +188,25 @@ k_ortho(const float* __restrict__ embed, const int64_t* __restrict__ ids, int H,
     const float coef = g[0] * scale * 4.0f / (static_cast<float>(H) * M * M);
     float dotp = 0.f;
 #pragma unroll
-    for (int q = 0; q < kOrthoMaxPerLane; ++q) dotp += gc[q] * ci[q];
+    for (int q = 0; q < Q; ++q) dotp += gc[q] * ci[q];
     dotp = wave_sum(dotp);
     float* ge = g_embed + (static_cast<int64_t>(h) * K + ids[i]) * Dc;
 #pragma unroll
-    for (int q = 0; q < kOrthoMaxPerLane; ++q) {
+    for (int q = 0; q < Q; ++q) {
       const int c = lane + 64 * q;
       if (c < Dc) ge[c] = coef * (gc[q] - ci[q] * dotp) * inv_i;
     }
   }
+}
+
+template <bool BWD>
+void launch_ortho(int grid, hipStream_t st, const float* embed, const int64_t* ids, int H, int K, int Dc, int M,
+                  float scale, const float* g, double* partial, float* g_embed) {
+  const int q = (Dc + 63) / 64;
+  if (q <= 2) k_ortho<BWD, 2><<<grid, 64, 0, st>>>(embed, ids, H, K, Dc, M, scale, g, partial, g_embed);
+  else if (q <= 4) k_ortho<BWD, 4><<<grid, 64, 0, st>>>(embed, ids, H, K, Dc, M, scale, g, partial, g_embed);
+  else if (q <= 8) k_ortho<BWD, 8><<<grid, 64, 0, st>>>(embed, ids, H, K, Dc, M, scale, g, partial, g_embed);
+  else k_ortho<BWD, 16><<<grid, 64, 0, st>>>(embed, ids, H, K, Dc, M, scale, g, partial, g_embed);
 }
 
 }  // namespace
@@ -259,9 +289,8 @@ int stemgnn_ortho_loss_fwd(const float* embed, const int64_t* ids, int64_t heads
   if (workspace_bytes < stemgnn_loss_workspace_bytes(heads * num_ids)) return STEMGNN_ERR_WORKSPACE;
   double* partial = reinterpret_cast<double*>(align_up(reinterpret_cast<uintptr_t>(workspace), 256));
   const int H = static_cast<int>(heads), M = static_cast<int>(num_ids);
-  k_ortho<false><<<static_cast<unsigned>(H * M), 64, 0, st>>>(embed, ids, H, static_cast<int>(codebook_size),
-                                                              static_cast<int>(code_dim), M, scale, nullptr, partial,
-                                                              nullptr);
+  launch_ortho<false>(H * M, st, embed, ids, H, static_cast<int>(codebook_size), static_cast<int>(code_dim), M, scale,
+                      nullptr, partial, nullptr);
   STEMGNN_LAUNCH_CHECK();
   k_finish_sum<<<1, 256, 0, st>>>(partial, H * M, static_cast<double>(scale) / (static_cast<double>(H) * M * M),
                                   -static_cast<double>(scale) / M, loss);
@@ -278,9 +307,8 @@ int stemgnn_ortho_loss_bwd(const float* embed, const int64_t* ids, int64_t heads
     return STEMGNN_ERR_INVALID_ARG;
   STEMGNN_HIP_TRY(hipMemsetAsync(g_embed, 0, sizeof(float) * heads * codebook_size * code_dim, st));
   const int H = static_cast<int>(heads), M = static_cast<int>(num_ids);
-  k_ortho<true><<<static_cast<unsigned>(H * M), 64, 0, st>>>(embed, ids, H, static_cast<int>(codebook_size),
-                                                             static_cast<int>(code_dim), M, scale, g_loss, nullptr,
-                                                             g_embed);
+  launch_ortho<true>(H * M, st, embed, ids, H, static_cast<int>(codebook_size), static_cast<int>(code_dim), M, scale,
+                     g_loss, nullptr, g_embed);
   STEMGNN_LAUNCH_CHECK();
   return STEMGNN_OK;
 }

@@ -910,6 +910,73 @@ def clip_grad_norm_(parameters, max_norm: float) -> Tensor:
     return out[0]
 
 
+def _grad_table(grads):
+    import ctypes
+    n = len(grads)
+    return ((ctypes.c_void_p * n)(*[g.data_ptr() for g in grads]), (ctypes.c_int64 * n)(*[g.numel() for g in grads]), n)
+
+
+def grad_norm_coef(grads, max_norm: float) -> Tensor:
+    """-> device tensor [total L2 norm, min(1, max_norm / (norm + 1e-6))] of dense fp32 gradients on one device
+    (at most `_CLIP_MAX` tensors); nothing is scaled."""
+    dev = grads[0].device
+    ptrs, sizes, n = _grad_table(grads)
+    out = torch.empty(2, dtype=torch.float32, device=dev)
+    ws = _workspace(lib.stemgnn_clip_grad_workspace_bytes(sum(sizes), n), dev)
+    check(lib.stemgnn_grad_norm_coef(ptrs, sizes, n, float(max_norm), _p(out), _p(ws), ws.numel(), _stream()),
+          "grad_norm_coef")
+    return out
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    """torch.optim.AdamW (amsgrad off, maximize off; reference pretrain.py:134-136) as ONE launch per parameter
+    group over a table of the tensors, with an optional device-side gradient factor (the clipping coefficient of
+    ``grad_norm_coef``) applied while the gradients are read.  Same update arithmetic as ATen's fused kernel;
+    ``state[p]`` holds ``step`` (python int), ``exp_avg``, ``exp_avg_sq``."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_coef: Optional[Tensor] = None):
+        import ctypes
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            ps = [p for p in group["params"] if p.grad is not None]
+            if not ps:
+                continue
+            for p in ps:
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                if (p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous() or not p.grad.is_contiguous()
+                        or p.grad.dtype != torch.float32):
+                    raise RuntimeError("FusedAdamW: dense contiguous fp32 CUDA parameters and gradients only")
+            b1, b2 = group["betas"]
+            for lo in range(0, len(ps), _CLIP_MAX):
+                chunk = ps[lo:lo + _CLIP_MAX]
+                n = len(chunk)
+                steps = {self.state[p]["step"] for p in chunk}
+                if len(steps) != 1:
+                    raise RuntimeError("FusedAdamW: parameters of one group must share their step count")
+                step = steps.pop() + 1
+                arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])  # noqa: E731
+                check(lib.stemgnn_adamw_step(arr(chunk), arr([p.grad for p in chunk]),
+                                             arr([self.state[p]["exp_avg"] for p in chunk]),
+                                             arr([self.state[p]["exp_avg_sq"] for p in chunk]),
+                                             (ctypes.c_int64 * n)(*[p.numel() for p in chunk]), n, float(group["lr"]),
+                                             float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
+                                             step, _p(grad_coef), _stream()), "adamw_step")
+                for p in chunk:
+                    self.state[p]["step"] = step
+        return loss
+
+
 def gather_rows(table: Tensor, index: Tensor) -> Tensor:
     """out[i] = table[index[i]] (device-side node_text_feat[x] of reference pretrain.py:33-38)."""
     _req(table, torch.float32, "table", 2)

@@ -62,9 +62,11 @@ def build_model(params: Dict, device) -> PretrainModel:
 
 def build_optimizer(model: nn.Module, params: Dict):
     """reference pretrain.py:134-136: AdamW over ALL parameters (sem_encoder's never get grads)."""
-    # same update rule as the reference's AdamW; `fused=True` only changes how many kernels apply it
-    kw = {"fused": True} if next(model.parameters()).is_cuda else {}
-    opt = AdamW(model.parameters(), lr=params["pretrain_lr"], weight_decay=params["pretrain_weight_decay"], **kw)
+    # same update rule as the reference's AdamW, applied by one launch over a table of the tensors
+    if next(model.parameters()).is_cuda:
+        opt = ops.FusedAdamW(model.parameters(), lr=params["pretrain_lr"], weight_decay=params["pretrain_weight_decay"])
+    else:
+        opt = AdamW(model.parameters(), lr=params["pretrain_lr"], weight_decay=params["pretrain_weight_decay"])
     sched = get_scheduler(opt, params["use_schedular"], params["pretrain_epochs"])
     return opt, sched
 
@@ -138,8 +140,14 @@ def pretrain_step(model: PretrainModel, optimizer, scheduler, params: Dict, x, e
     loss.backward()
     if grad_sync is not None:
         grad_sync()
-    ops.clip_grad_norm_(_trainable(model), 1.0)  # pretrain.py:62
-    optimizer.step()
+    grads = [p.grad for p in _trainable(model) if p.grad is not None]
+    if isinstance(optimizer, ops.FusedAdamW) and 0 < len(grads) <= ops._CLIP_MAX:
+        # clip_grad_norm_(…, 1.0) + AdamW (pretrain.py:62-63): norm and factor in two launches, the factor applied
+        # by the optimizer kernel while it reads the gradients (p.grad itself stays unclipped)
+        optimizer.step(grad_coef=ops.grad_norm_coef(grads, 1.0)[1:])
+    else:
+        ops.clip_grad_norm_(_trainable(model), 1.0)  # pretrain.py:62
+        optimizer.step()
     if scheduler:
         scheduler.step()
     model.ema_update_sem_encoder(decay=params["sem_encoder_decay"])  # pretrain.py:66

@@ -640,3 +640,34 @@ def test_sample_edges_matches_subset_and_indexing(dev):
     assert torch.equal(sel[:, k:], neg) and torch.equal(sel[:, :k], ei[:, perm])
     perm2, sel2, t2, m2 = ops.sample_edges(ei, None, 1, key=key)     # k = 1, no types, no mask
     assert t2 is None and m2 is None and torch.equal(sel2[:, 0], ei[:, perm2[0]])
+
+
+def test_fused_adamw_matches_torch_adamw(dev):
+    """ops.FusedAdamW (+ the clipping factor folded into its read of the gradients) against
+    clip_grad_norm_ + torch.optim.AdamW over several steps, lr changed between steps like the scheduler does."""
+    from stem_gnn_amd import ops
+    torch.manual_seed(0)
+    shapes = [(128, 256), (128,), (1,), (512, 128), (4, 64, 32), (70001,)]
+    ps = [torch.nn.Parameter(torch.randn(s, device=dev)) for s in shapes]
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    opt = ops.FusedAdamW(ps, lr=1e-2, weight_decay=1e-2)
+    ref = torch.optim.AdamW(qs, lr=1e-2, weight_decay=1e-2)
+    for step in range(6):
+        scale = 3.0 if step % 2 == 0 else 1e-3          # clipping active / inactive
+        for p, q in zip(ps, qs):
+            g = torch.randn(p.shape, device=dev) * scale
+            p.grad, q.grad = g.clone(), g.clone()
+        lr = 1e-2 * (1 + step) / 4
+        for o in (opt, ref):
+            for grp in o.param_groups:
+                grp["lr"] = lr
+        out = ops.grad_norm_coef([p.grad for p in ps], 1.0)
+        opt.step(grad_coef=out[1:])
+        total = torch.nn.utils.clip_grad_norm_(qs, 1.0)
+        ref.step()
+        torch.testing.assert_close(out[0], total, rtol=1e-5, atol=0)
+        for p, q in zip(ps, qs):
+            torch.testing.assert_close(p.detach(), q.detach(), rtol=2e-5, atol=2e-6)
+    for p, q in zip(ps, qs):
+        torch.testing.assert_close(opt.state[p]["exp_avg"], ref.state[q]["exp_avg"], rtol=1e-4, atol=1e-7)
+        torch.testing.assert_close(opt.state[p]["exp_avg_sq"], ref.state[q]["exp_avg_sq"], rtol=1e-4, atol=1e-9)
