@@ -305,14 +305,15 @@ int stemgnn_transpose(const float* in, int64_t rows, int64_t cols, float* out, v
  *   norm    [N, H]     ||xp_h|| before clamping at 1e-12 (saved for backward with xp)
  *   ind     [N, H]     int64 arg-max code (lowest index wins ties)
  *   quant   [N, H*Dc]  training: xn + (q - xn) (straight-through value); eval: q
- *   sqerr   [1]        sum over all elements of (q - xn)^2 (commitment numerator)
+ *   sqerr   [1]        sqerr_scale * sum over all elements of (q - xn)^2 (commitment numerator; pass
+ *                      commitment_weight / (N*H*Dc) for the weighted mean of vq.py:1007-1009)
  * Dc must be a multiple of 4 and <= 1024, K <= 65536.
  * ------------------------------------------------------------------------------------ */
 size_t stemgnn_vq_workspace_bytes(int64_t num_rows, int64_t heads, int64_t code_dim, int64_t codebook_size);
 
 int stemgnn_vq_assign_fwd(const float* xp, int64_t num_rows, int64_t heads, int64_t code_dim,
                           const float* embed, int64_t codebook_size, int training,
-                          float* xn, float* norm, int64_t* ind, float* quant, float* sqerr,
+                          float* xn, float* norm, int64_t* ind, float* quant, float* sqerr, float sqerr_scale,
                           void* workspace, size_t workspace_bytes, void* stream);
 
 /* g_xp = d/dxp [ <g_quant, quant> + g_loss * commit_weight * mean((q - xn)^2) ]
@@ -402,6 +403,12 @@ int32_t stemgnn_clip_grad_max_tensors(void);
 size_t stemgnn_clip_grad_workspace_bytes(int64_t total_elements, int32_t count);
 int stemgnn_clip_grad_norm(float* const* grads, const int64_t* sizes, int32_t count, float max_norm, float* out,
                            void* workspace, size_t workspace_bytes, void* stream);
+
+/* out[0] = sum_i weights[i] * terms[i][0] over up to 8 scalar loss terms (reference pretrain.py:51-58: the
+ * lambda-weighted total), fixed order; terms / weights are HOST arrays (device pointers / floats).
+ * Backward: g_terms[i] = g_out[0] * weights[i]. */
+int stemgnn_weighted_sum(const float* const* terms, const float* weights, int32_t count, float* out, void* stream);
+int stemgnn_weighted_sum_bwd(const float* weights, int32_t count, const float* g_out, float* g_terms, void* stream);
 
 /* out[0] = total L2 norm of the gradients, out[1] = min(1, max_norm / (out[0] + 1e-6)); nothing is scaled.
  * Same host arrays and workspace as stemgnn_clip_grad_norm. */

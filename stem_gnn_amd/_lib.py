@@ -73,6 +73,8 @@ _SIGNATURES = {
     "stemgnn_clip_grad_max_tensors": (I32, []),
     "stemgnn_clip_grad_workspace_bytes": (c_size_t, [I64, I32]),
     "stemgnn_clip_grad_norm": (c_int, [P, P, I32, c_float, P, P, c_size_t, P]),
+    "stemgnn_weighted_sum": (c_int, [P, P, I32, P, P]),
+    "stemgnn_weighted_sum_bwd": (c_int, [P, I32, P, P, P]),
     "stemgnn_grad_norm_coef": (c_int, [P, P, I32, c_float, P, P, c_size_t, P]),
     "stemgnn_adamw_step": (c_int, [P, P, P, P, P, I32, c_float, c_float, c_float, c_float, c_float, I64, P, P]),
     "stemgnn_linear_set_mode": (c_int, [c_int]),
@@ -86,7 +88,7 @@ _SIGNATURES = {
                                         P, P, P, P, c_size_t, P]),
     "stemgnn_dropout_keep_mask": (c_int, [I64, c_float, c_uint64, c_uint64, P, P]),
     "stemgnn_vq_workspace_bytes": (c_size_t, [I64, I64, I64, I64]),
-    "stemgnn_vq_assign_fwd": (c_int, [P, I64, I64, I64, P, I64, c_int, P, P, P, P, P, P, c_size_t, P]),
+    "stemgnn_vq_assign_fwd": (c_int, [P, I64, I64, I64, P, I64, c_int, P, P, P, P, P, c_float, P, c_size_t, P]),
     "stemgnn_vq_assign_bwd": (c_int, [P, P, c_float, P, P, P, P, I64, I64, I64, I64, P, P]),
     "stemgnn_vq_ema_workspace_bytes": (c_size_t, [I64, I64, I64, I64]),
     "stemgnn_vq_ema_stats": (c_int, [P, P, P, I64, I64, I64, I64, P, P, P, c_size_t, P]),

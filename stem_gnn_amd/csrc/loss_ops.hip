@@ -209,6 +209,26 @@ void launch_ortho(int grid, hipStream_t st, const float* embed, const int64_t* i
   else k_ortho<BWD, 16><<<grid, 64, 0, st>>>(embed, ids, H, K, Dc, M, scale, g, partial, g_embed);
 }
 
+// total = sum_i w_i * term_i over up to 8 scalar loss terms living in separate device buffers (reference
+// pretrain.py:51-58), and its backward g_i = g * w_i, one launch each.
+struct ScalarTable {
+  const float* p[8];
+  float w[8];
+  int32_t count;
+};
+
+__global__ void k_weighted_sum(ScalarTable t, float* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float s = 0.f;
+  for (int i = 0; i < t.count; ++i) s += t.w[i] * t.p[i][0];  // fixed order
+  out[0] = s;
+}
+
+__global__ void k_weighted_sum_bwd(ScalarTable t, const float* __restrict__ g, float* __restrict__ g_terms) {
+  const int i = threadIdx.x;
+  if (blockIdx.x == 0 && i < t.count) g_terms[i] = g[0] * t.w[i];
+}
+
 }  // namespace
 }  // namespace stemgnn
 
@@ -219,6 +239,31 @@ extern "C" {
 size_t stemgnn_loss_workspace_bytes(int64_t n) {
   // mse: <= 256 block partials; cosine: one double per row; ortho: one per (head, id)
   return static_cast<size_t>(n < 256 ? 256 : n) * sizeof(double) + 512;
+}
+
+int stemgnn_weighted_sum(const float* const* terms, const float* weights, int32_t count, float* out, void* stream_) {
+  if (count < 0 || count > 8 || !out || (count > 0 && (!terms || !weights))) return STEMGNN_ERR_INVALID_ARG;
+  ScalarTable t;
+  t.count = count;
+  for (int i = 0; i < count; ++i) {
+    if (!terms[i]) return STEMGNN_ERR_INVALID_ARG;
+    t.p[i] = terms[i];
+    t.w[i] = weights[i];
+  }
+  k_weighted_sum<<<1, 64, 0, static_cast<hipStream_t>(stream_)>>>(t, out);
+  STEMGNN_LAUNCH_CHECK();
+  return STEMGNN_OK;
+}
+
+int stemgnn_weighted_sum_bwd(const float* weights, int32_t count, const float* g_out, float* g_terms, void* stream_) {
+  if (count < 0 || count > 8 || (count > 0 && (!weights || !g_out || !g_terms))) return STEMGNN_ERR_INVALID_ARG;
+  if (count == 0) return STEMGNN_OK;
+  ScalarTable t;
+  t.count = count;
+  for (int i = 0; i < count; ++i) { t.p[i] = nullptr; t.w[i] = weights[i]; }
+  k_weighted_sum_bwd<<<1, 64, 0, static_cast<hipStream_t>(stream_)>>>(t, g_out, g_terms);
+  STEMGNN_LAUNCH_CHECK();
+  return STEMGNN_OK;
 }
 
 int stemgnn_mse_loss_fwd(const float* pred, const float* target, int64_t n, float scale, float* loss, void* workspace,

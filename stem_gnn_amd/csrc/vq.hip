@@ -270,7 +270,7 @@ k_vq_assign(const float* __restrict__ xp, int64_t N, int H, int Dc, const float*
   }
 }
 
-__global__ void __launch_bounds__(kBlock) k_sum_partials(const float* __restrict__ partial, int64_t n,
+__global__ void __launch_bounds__(kBlock) k_sum_partials(const float* __restrict__ partial, int64_t n, double scale,
                                                          float* __restrict__ out) {
   __shared__ double red[kBlock];
   double s = 0.0;
@@ -281,7 +281,7 @@ __global__ void __launch_bounds__(kBlock) k_sum_partials(const float* __restrict
     if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) out[0] = static_cast<float>(red[0]);
+  if (threadIdx.x == 0) out[0] = static_cast<float>(red[0] * scale);
 }
 
 // Backward: one G-lane group per (row, head).
@@ -382,7 +382,7 @@ size_t stemgnn_vq_workspace_bytes(int64_t N, int64_t H, int64_t Dc, int64_t K) {
 
 int stemgnn_vq_assign_fwd(const float* xp, int64_t N, int64_t H, int64_t Dc, const float* embed, int64_t K,
                           int training, float* xn, float* norm, int64_t* ind, float* quant, float* sqerr,
-                          void* workspace, size_t workspace_bytes, void* stream_) {
+                          float sqerr_scale, void* workspace, size_t workspace_bytes, void* stream_) {
   hipStream_t st = static_cast<hipStream_t>(stream_);
   if (!vq_dims_ok(N, H, Dc, K)) return STEMGNN_ERR_INVALID_ARG;
   if (!fits_i32(N) || !fits_i32(N * H)) return STEMGNN_ERR_TOO_LARGE;
@@ -410,7 +410,7 @@ int stemgnn_vq_assign_fwd(const float* xp, int64_t N, int64_t H, int64_t Dc, con
   else STEMGNN_VQ_LAUNCH(4);
 #undef STEMGNN_VQ_LAUNCH
   STEMGNN_LAUNCH_CHECK();
-  k_sum_partials<<<1, kBlock, 0, st>>>(partial, rb * H, sqerr);
+  k_sum_partials<<<1, kBlock, 0, st>>>(partial, rb * H, static_cast<double>(sqerr_scale), sqerr);
   STEMGNN_LAUNCH_CHECK();
   return STEMGNN_OK;
 }

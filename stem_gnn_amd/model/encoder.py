@@ -356,12 +356,20 @@ class Encoder(nn.Module):
         if env_reg_total is not None and self.training and env_layers > 0:
             self._last_env_reg = env_reg_total / env_layers
         else:
-            self._last_env_reg = z.new_zeros(1)
+            self._last_env_reg = self._zero_reg(z.device)
         return z
+
+    def _zero_reg(self, device):
+        """A constant zeros(1) per device (encoder.py:319-322 builds one per call: a fill launch per forward)."""
+        cache = self.__dict__.setdefault("_zero_reg_cache", {})
+        t = cache.get(device)
+        if t is None:
+            t = cache[device] = torch.zeros(1, device=device)
+        return t
 
     def get_env_reg(self, reset=True):
         if self._last_env_reg is None:
-            reg = torch.zeros(1, device=next(self.parameters()).device)
+            reg = self._zero_reg(next(self.parameters()).device)
         else:
             reg = self._last_env_reg
         if reset:

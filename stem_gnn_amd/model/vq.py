@@ -224,14 +224,15 @@ class VectorQuantize(nn.Module):
             with torch.no_grad():
                 cb.init_embed_(l2norm(xp.detach().view(n, h, dc).permute(1, 0, 2)))
         will_ema = self.training and cb.ema_update and not freeze_codebook
-        quant, embed_ind, mse = ops.VqAssignFn.apply(xp, cb.embed, h, self.training, will_ema)
+        commit = self.training and self.commitment_weight > 0
+        quant, embed_ind, mse = ops.VqAssignFn.apply(xp, cb.embed, h, self.training, will_ema,
+                                                     self.commitment_weight if commit else 1.0)
         if will_ema:
             cb.ema_update_(xp.detach().contiguous(), embed_ind)
-        loss = torch.zeros(1, device=x.device, requires_grad=self.training)  # vq.py:983
         if self.training:
             terms = []
-            if self.commitment_weight > 0:
-                terms.append(mse * self.commitment_weight)  # vq.py:1007-1009
+            if commit:
+                terms.append(mse)  # commitment_weight * mse_loss(q.detach(), x), scaled inside the op (vq.py:1007-1009)
             if self.has_codebook_orthogonal_loss:  # vq.py:1011-1028
                 codebook = cb.embed
                 num_codes = codebook.shape[-2]
@@ -250,6 +251,10 @@ class VectorQuantize(nn.Module):
             if terms:
                 total = terms[0] if len(terms) == 1 else terms[0] + terms[1]
                 loss = total.reshape(1)
+            else:
+                loss = torch.zeros(1, device=x.device, requires_grad=True)  # vq.py:983
+        else:
+            loss = torch.zeros(1, device=x.device)  # vq.py:983
         if h == 1:
             embed_ind = embed_ind.view(n)  # heads == 1 is not "multiheaded" (vq.py:865)
         orig_quantize = quant  # [N, H*Dc], heads already merged 'b n (h d)' (vq.py:1034)

@@ -615,12 +615,12 @@ def linear(x: Tensor, lin: "torch.nn.Linear") -> Tensor:
 # ----------------------------------------------------------------------------------------
 class VqAssignFn(torch.autograd.Function):
     """(quant, ind, mse) = cosine-codebook assignment of xp [N, H*Dc] against embed [H, K, Dc]
-    (reference model/vq.py:891, 650-657, 931-937, 1007).  mse = mean((q - xn)^2) carries the
+    (reference model/vq.py:891, 650-657, 931-937, 1007).  mse = loss_weight * mean((q - xn)^2) carries the
     commitment gradient; embed receives no gradient through this op (q is detached in the
     reference: vq.py:931-937 with VectorQuantize.learnable_codebook == False)."""
 
     @staticmethod
-    def forward(ctx, xp, embed, heads, training, snapshot_embed=False):
+    def forward(ctx, xp, embed, heads, training, snapshot_embed=False, loss_weight=1.0):
         xp = xp.contiguous()
         embed_c = embed.detach().contiguous()
         if snapshot_embed:
@@ -639,12 +639,14 @@ class VqAssignFn(torch.autograd.Function):
         quant = torch.empty_like(xp)
         sqerr = torch.empty(1, dtype=torch.float32, device=dev)
         ws = _workspace(lib.stemgnn_vq_workspace_bytes(N, H, Dc, K), dev)
+        numel = max(N * H * Dc, 1)
         check(lib.stemgnn_vq_assign_fwd(_p(xp), N, H, Dc, _p(embed_c), K, int(bool(training)), None, _p(norm), _p(ind),
-                                        _p(quant), _p(sqerr), _p(ws), ws.numel(), _stream()), "vq_assign_fwd")
+                                        _p(quant), _p(sqerr), float(loss_weight) / float(numel), _p(ws), ws.numel(),
+                                        _stream()), "vq_assign_fwd")
         ctx.save_for_backward(xp, norm, ind, embed_c)
         ctx.mark_non_differentiable(ind)
-        numel = max(N * H * Dc, 1)
-        return quant, ind, sqerr / float(numel)
+        ctx.loss_weight = float(loss_weight)
+        return quant, ind, sqerr
 
     @staticmethod
     def backward(ctx, g_quant, _g_ind, g_mse):
@@ -656,9 +658,9 @@ class VqAssignFn(torch.autograd.Function):
         g_quant = g_quant.contiguous()
         g_loss = None if g_mse is None else g_mse.contiguous().float()
         g_xp = torch.empty_like(xp)
-        check(lib.stemgnn_vq_assign_bwd(_p(g_quant), _p(g_loss), 1.0, _p(xp), _p(norm), _p(ind), _p(embed), N, H, Dc, K,
-                                        _p(g_xp), _stream()), "vq_assign_bwd")
-        return g_xp, None, None, None, None
+        check(lib.stemgnn_vq_assign_bwd(_p(g_quant), _p(g_loss), ctx.loss_weight, _p(xp), _p(norm), _p(ind), _p(embed), N,
+                                        H, Dc, K, _p(g_xp), _stream()), "vq_assign_bwd")
+        return g_xp, None, None, None, None, None
 
 
 def vq_ema_stats(xp: Tensor, norm: Tensor, ind: Tensor, codebook_size: int) -> Tuple[Tensor, Tensor]:
@@ -908,6 +910,33 @@ def clip_grad_norm_(parameters, max_norm: float) -> Tensor:
     check(lib.stemgnn_clip_grad_norm(ptrs, sizes, n, float(max_norm), _p(out), _p(ws), ws.numel(), _stream()),
           "clip_grad_norm")
     return out[0]
+
+
+class WeightedSumFn(torch.autograd.Function):
+    """sum_i w_i * term_i of scalar device tensors (the lambda-weighted total loss, reference pretrain.py:51-58):
+    one launch forward, one backward, instead of stack + mul + sum and their three backward kernels."""
+
+    @staticmethod
+    def forward(ctx, weights, *terms):
+        import ctypes
+        n = len(terms)
+        ts = [t.reshape(1).contiguous() for t in terms]
+        for t in ts:
+            _req(t, torch.float32, "loss term", 1)
+        out = torch.empty(1, dtype=torch.float32, device=ts[0].device)
+        ctx.w = (ctypes.c_float * n)(*[float(w) for w in weights])
+        ctx.n = n
+        ctx.shapes = [t.shape for t in terms]
+        check(lib.stemgnn_weighted_sum((ctypes.c_void_p * n)(*[t.data_ptr() for t in ts]), ctx.w, n, _p(out), _stream()),
+              "weighted_sum")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        gt = torch.empty(ctx.n, dtype=torch.float32, device=g.device)
+        check(lib.stemgnn_weighted_sum_bwd(ctx.w, ctx.n, _p(g.reshape(1).contiguous()), _p(gt), _stream()),
+              "weighted_sum_bwd")
+        return (None, *[gt[i].reshape(shape) for i, shape in enumerate(ctx.shapes)])
 
 
 def _grad_table(grads):

@@ -88,15 +88,18 @@ _LOSS_KEYS = ("feat_recon_loss", "topo_recon_loss", "topo_sem_recon_loss", "sem_
 
 def total_loss(losses: Dict[str, torch.Tensor], params: Dict) -> torch.Tensor:
     """reference pretrain.py:51-58: feat_lambda*feat + topo_lambda*topo + topo_sem_lambda*topo_sem +
-    sem_lambda*sem + commit + lamda_env*env, as one stacked weighted sum (3 kernels instead of 11)."""
+    sem_lambda*sem + commit + lamda_env*env, as one weighted-sum launch (stack + mul + sum on the CPU)."""
     w = (float(params["feat_lambda"]), float(params["topo_lambda"]), float(params["topo_sem_lambda"]),
          float(params["sem_lambda"]), 1.0, float(params.get("lamda_env", 0.0)))
-    dev = losses["feat_recon_loss"].device
+    terms = [losses[k] for k in _LOSS_KEYS]
+    if terms[0].is_cuda and all(t.numel() == 1 and t.dtype == torch.float32 for t in terms):
+        return ops.WeightedSumFn.apply(w, *terms)
+    dev = terms[0].device
     key = (w, dev)
     wt = _WEIGHT_CACHE.get(key)
     if wt is None:
         wt = _WEIGHT_CACHE[key] = torch.tensor(w, dtype=torch.float32, device=dev)
-    stacked = torch.stack([losses[k].reshape(()).float() for k in _LOSS_KEYS])
+    stacked = torch.stack([t.reshape(()).float() for t in terms])
     return (stacked * wt).sum().reshape(1)
 
 
