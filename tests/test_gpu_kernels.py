@@ -671,3 +671,40 @@ def test_fused_adamw_matches_torch_adamw(dev):
     for p, q in zip(ps, qs):
         torch.testing.assert_close(opt.state[p]["exp_avg"], ref.state[q]["exp_avg"], rtol=1e-4, atol=1e-7)
         torch.testing.assert_close(opt.state[p]["exp_avg_sq"], ref.state[q]["exp_avg_sq"], rtol=1e-4, atol=1e-9)
+
+
+def test_csr_round_trip_properties_hypothesis(dev):
+    """Property test (SURVEY §4 'indexing'): for arbitrary small COO lists -- duplicates, self loops, isolated nodes,
+    empty -- both CSR views are stable groupings whose permutation inverts back to the input, and the aggregation over
+    them equals a dense adjacency product."""
+    from hypothesis import given, settings, strategies as st
+    from stem_gnn_amd import ops
+    from stem_gnn_amd.graph import GraphStructure
+    from stem_gnn_amd.model.encoder import aggregate
+
+    @settings(max_examples=40, deadline=None)
+    @given(st.integers(1, 40).flatmap(lambda n: st.tuples(st.just(n), st.lists(
+        st.tuples(st.integers(0, n - 1), st.integers(0, n - 1)), min_size=0, max_size=120))))
+    def check(case):
+        n, edges = case
+        ei = torch.tensor(edges, dtype=torch.int64).reshape(-1, 2).t().contiguous()
+        e = ei.size(1)
+        for key_row in (1, 0):
+            rowptr, other, eid, bad = ops.csr_build(ei.to(dev), n, key_row)
+            assert int(bad.item()) == 0
+            rp, ot, pm = rowptr.cpu().long(), other.cpu().long(), eid.cpu().long()
+            assert rp[0] == 0 and rp[-1] == e and bool((rp[1:] >= rp[:-1]).all())
+            assert sorted(pm.tolist()) == list(range(e))
+            keys = torch.repeat_interleave(torch.arange(n), rp[1:] - rp[:-1])
+            assert torch.equal(ei[key_row][pm], keys) and torch.equal(ei[1 - key_row][pm], ot)
+            same = keys[1:] == keys[:-1]
+            assert bool((pm[1:][same] > pm[:-1][same]).all())
+        x = torch.randn(n, 8)
+        adj = torch.zeros(n, n)
+        if e:
+            adj.index_put_((ei[1], ei[0]), torch.ones(e), accumulate=True)
+        ref = adj @ torch.relu(x) / adj.sum(1, keepdim=True).clamp(min=1)
+        out = aggregate(x.to(dev), GraphStructure(ei.to(dev), n), None).cpu()
+        torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-5)
+
+    check()
