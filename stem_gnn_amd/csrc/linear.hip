@@ -191,6 +191,14 @@ k_linear_fwd(const float* __restrict__ x1, const float* __restrict__ w1, int K1,
 }
 
 // The same tile on the bf16 matrix cores (split3 / mfma_x3 above): chunks are split while they are staged.
+// Staging row of float4 slot idx (8 slots per row).  ds_write_b64 is served in groups of 16 consecutive lanes = two
+// rows; with the 80-byte plane stride rows r and r+1 share 12 of their 16 banks (2-way conflict: a third of the LDS
+// cycles of this kernel, SQ_LDS_BANK_CONFLICT), rows r and r+4 share none -- so the rows of every group of eight
+// are taken in the order 0 4 1 5 2 6 3 7.  Global loads are unaffected: 8 lanes still read one 128-byte row segment.
+__device__ __forceinline__ int stage_row(int idx) {
+  const int r = idx >> 3;
+  return (r & ~7) | ((r & 1) << 2) | ((r >> 1) & 3);
+}
 template <int BM, bool STATS, bool BT = false>
 __global__ void __launch_bounds__(kBlock, 2)
 k_linear_fwd_x3(const float* __restrict__ x1, const float* __restrict__ w1, int K1, const float* __restrict__ x2,
@@ -225,7 +233,7 @@ k_linear_fwd_x3(const float* __restrict__ x1, const float* __restrict__ w1, int 
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int idx = t * kBlock + tid;  // 16-byte column = idx % 8, row = idx / 8
-      const int r = idx >> 3, k = k0 + 4 * (idx & 7);
+      const int r = stage_row(idx), k = k0 + 4 * (idx & 7);
       const int n = n0 + r;
       if (BT) {
         // weight given as [K][N] (backward-data: dX = dY W): rows k0 + 4 (tid & 7) + t, columns n0 + 4 (tid >> 3) ..+3
@@ -245,7 +253,7 @@ k_linear_fwd_x3(const float* __restrict__ x1, const float* __restrict__ w1, int 
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int idx = t * kBlock + tid;
-      const int off = (idx >> 3) * kLdP + 8 * (idx & 7);
+      const int off = stage_row(idx) * kLdP + 8 * (idx & 7);
       uint2 h, m, l;
       if (!BT) {
         split3(rb[t], h, m, l);

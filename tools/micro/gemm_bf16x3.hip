@@ -155,6 +155,15 @@ k_gemm_bf16x3(const float* __restrict__ x, const uint16_t* __restrict__ wp, int 
         }
         continue;
       }
+      if (ABL & 16) {  // product outer, tile inner: consecutive MFMAs write different accumulators
+        constexpr int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+#pragma unroll
+          for (int tn = 0; tn < 2; ++tn) acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa[t]], b[tn][pb[t]], acc[tn], 0, 0, 0);
+        }
+        continue;
+      }
 #pragma unroll
       for (int tn = 0; tn < 2; ++tn) {
         floatx16 c = acc[tn];
@@ -456,9 +465,9 @@ int main() {
   std::vector<float> hy(M * NMAX), hy2(M * NMAX);
   for (auto kn : {std::pair<int, int>{128, 128}, {256, 128}, {512, 128}, {128, 512}}) {
     const int K = kn.first, N = kn.second;
-    printf("  double-buffered variants: kc16/occ2 %.1f  kc16/occ2/sched2 %.1f  kc32/occ1 %.1f us\n",
-           time_us(launch_v3<16, 2, 0>, x, w, K, M, N, y2), time_us(launch_v3<16, 2, 2>, x, w, K, M, N, y2),
-           time_us(launch_v3<32, 1, 0>, x, w, K, M, N, y2));
+    printf("  8-wave tile: chained accumulators %.1f us, interleaved accumulators %.1f us; MFMA only (no loads/stores): %.1f / %.1f us\n",
+           time_us(launch_split<2, 0>, x, w, K, M, N, y2), time_us(launch_split<2, 16>, x, w, K, M, N, y2),
+           time_us(launch_split<2, 9>, x, w, K, M, N, y2), time_us(launch_split<2, 25>, x, w, K, M, N, y2));
     const double us_s1 = time_us(launch_split<1>, x, w, K, M, N, y);
     const double us_s = time_us(launch_split<2>, x, w, K, M, N, y);
     const double us_f = time_us(launch_f32, x, w, K, M, N, y2);

@@ -5,7 +5,7 @@ from collections import defaultdict
 acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
 for f in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"][:60] + "|grid" + r.get("Grid_Size", "")
+        k = r["Kernel_Name"][:110] + "|grid" + r.get("Grid_Size", "")
         a = acc[k][r["Counter_Name"]]
         a[0] += float(r["Counter_Value"]); a[1] += 1
 for k, cs in acc.items():
