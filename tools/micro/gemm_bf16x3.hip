@@ -352,6 +352,132 @@ static void launch_v3(const float* x, const float* w, int K, int64_t M, int N, f
   k_gemm_v3<KC, OCC, SCHED><<<grid, kBlock, lds>>>(x, g_planes, K, M, N, y);
 }
 
+// v6: the library tile (4 waves, one LDS buffer, in-kernel split of both operands) with TWO register sets: the loads
+// of chunk s+2 are issued while chunk s is multiplied, so two chunks per block are in flight.  Unrolled by two so the
+// sets are static; loads are clamped instead of predicated so every iteration issues the same eight loads.
+template <int OCC>
+__global__ void __launch_bounds__(kBlock, OCC)
+k_gemm_v6(const float* __restrict__ x, const float* __restrict__ w, int K, int64_t M, int N, float* __restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sA = smem;
+  unsigned char* sB = smem + 3 * kPlane;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, hi = lane >> 5, lj = lane & 31;
+  const int64_t m0 = static_cast<int64_t>(blockIdx.x) * kBM;
+  const int n0 = blockIdx.y * kBN;
+  const int steps = K / kKC;
+  const float *pa[4], *pb[4];
+  int off[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int idx = t * kBlock + tid;
+    int64_t m = m0 + (idx >> 3);
+    if (m >= M) m = M - 1;
+    int n = n0 + (idx >> 3);
+    if (n >= N) n = N - 1;
+    pa[t] = x + m * K + 4 * (idx & 7);
+    pb[t] = w + static_cast<int64_t>(n) * K + 4 * (idx & 7);
+    off[t] = (idx >> 3) * kLdB + 8 * (idx & 7);
+  }
+  float4 ra0[4], rb0[4], ra1[4], rb1[4];
+  auto fetch = [&](int step, float4 (&qa)[4], float4 (&qb)[4]) {
+    const int k0 = (step < steps ? step : steps - 1) * kKC;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) qa[t] = ld4(pa[t] + k0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) qb[t] = ld4(pb[t] + k0);
+  };
+  auto stash = [&](const float4 (&qa)[4], const float4 (&qb)[4]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      uint2 h, m, l;
+      split3(qa[t], h, m, l);
+      *reinterpret_cast<uint2*>(sA + off[t]) = h;
+      *reinterpret_cast<uint2*>(sA + kPlane + off[t]) = m;
+      *reinterpret_cast<uint2*>(sA + 2 * kPlane + off[t]) = l;
+      split3(qb[t], h, m, l);
+      *reinterpret_cast<uint2*>(sB + off[t]) = h;
+      *reinterpret_cast<uint2*>(sB + kPlane + off[t]) = m;
+      *reinterpret_cast<uint2*>(sB + 2 * kPlane + off[t]) = l;
+    }
+  };
+  floatx16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  auto mma = [&]() {
+#pragma unroll
+    for (int ks = 0; ks < kKC / 16; ++ks) {
+      const int ko = ks * 32 + hi * 16;
+      bf16x8 a[2][3], b[2][3];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          a[t][p] = *reinterpret_cast<const bf16x8*>(sA + p * kPlane + (wm * 64 + t * 32 + lj) * kLdB + ko);
+          b[t][p] = *reinterpret_cast<const bf16x8*>(sB + p * kPlane + (wn * 64 + t * 32 + lj) * kLdB + ko);
+        }
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+          floatx16 c = acc[tm][tn];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][2], b[tn][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][2], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][1], b[tn][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][1], b[tn][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][0], c, 0, 0, 0);
+          acc[tm][tn] = c;
+        }
+    }
+  };
+  fetch(0, ra0, rb0);
+  fetch(1, ra1, rb1);
+  for (int step = 0; step < steps; step += 2) {  // steps even
+    stash(ra0, rb0);
+    __syncthreads();
+    fetch(step + 2, ra0, rb0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma();
+    __syncthreads();
+    stash(ra1, rb1);
+    __syncthreads();
+    fetch(step + 3, ra1, rb1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma();
+    __syncthreads();
+  }
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+      const int n = n0 + wn * 64 + tn * 32 + lj;
+      float* yr = y + (m0 + wm * 64 + tm * 32 + 4 * hi) * N + n;
+      const int64_t mrem = M - (m0 + wm * 64 + tm * 32 + 4 * hi);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int dr = (r & 3) + 8 * (r >> 2);
+        if (dr < mrem && n < N) yr[static_cast<int64_t>(dr) * N] = acc[tm][tn][r];
+      }
+    }
+}
+
+template <int OCC>
+static void launch_v6(const float* x, const float* w, int K, int64_t M, int N, float* y) {
+  dim3 grid(static_cast<unsigned>((M + kBM - 1) / kBM), (N + kBN - 1) / kBN);
+  static bool once = [] {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_v6<OCC>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        6 * kPlane);
+    return true;
+  }();
+  (void)once;
+  k_gemm_v6<OCC><<<grid, kBlock, 6 * kPlane>>>(x, w, K, M, N, y);
+}
+
 // the fp32-MFMA tile of csrc/linear.hip, for the side-by-side number
 constexpr int kLd = kKC + 4;
 template <int OCC>
@@ -465,6 +591,19 @@ int main() {
   std::vector<float> hy(M * NMAX), hy2(M * NMAX);
   for (auto kn : {std::pair<int, int>{128, 128}, {256, 128}, {512, 128}, {128, 512}}) {
     const int K = kn.first, N = kn.second;
+    printf("  v6 (two register sets, 4 waves): occ2 %.1f us\n", time_us(launch_v6<2>, x, w, K, M, N, y2));
+    {
+      std::vector<float> h3(M * N);
+      hipMemcpy(h3.data(), y2, M * N * 4, hipMemcpyDeviceToHost);
+      double e3 = 0;
+      for (int64_t m = 0; m < M; m += 499)
+        for (int n = 0; n < N; ++n) {
+          double r = 0;
+          for (int k = 0; k < K; ++k) r += static_cast<double>(hx[m * K + k]) * hw[static_cast<int64_t>(n) * K + k];
+          e3 = fmax(e3, fabs(h3[m * N + n] - r));
+        }
+      printf("  v6 max|err| vs fp64: %.3g\n", e3);
+    }
     printf("  8-wave tile: chained accumulators %.1f us, interleaved accumulators %.1f us; MFMA only (no loads/stores): %.1f / %.1f us\n",
            time_us(launch_split<2, 0>, x, w, K, M, N, y2), time_us(launch_split<2, 16>, x, w, K, M, N, y2),
            time_us(launch_split<2, 9>, x, w, K, M, N, y2), time_us(launch_split<2, 25>, x, w, K, M, N, y2));
