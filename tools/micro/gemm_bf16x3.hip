@@ -355,7 +355,7 @@ static void launch_v3(const float* x, const float* w, int K, int64_t M, int N, f
 // v6: the library tile (4 waves, one LDS buffer, in-kernel split of both operands) with TWO register sets: the loads
 // of chunk s+2 are issued while chunk s is multiplied, so two chunks per block are in flight.  Unrolled by two so the
 // sets are static; loads are clamped instead of predicated so every iteration issues the same eight loads.
-template <int OCC>
+template <int OCC, int FENCE>
 __global__ void __launch_bounds__(kBlock, OCC)
 k_gemm_v6(const float* __restrict__ x, const float* __restrict__ w, int K, int64_t M, int N, float* __restrict__ y) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -443,12 +443,14 @@ k_gemm_v6(const float* __restrict__ x, const float* __restrict__ w, int K, int64
     fetch(step + 2, ra0, rb0);
     __builtin_amdgcn_sched_barrier(0);
     mma();
+    if (FENCE) __builtin_amdgcn_sched_barrier(0);  // keeps the next stash (and its wait for set 1) below the MFMAs
     __syncthreads();
     stash(ra1, rb1);
     __syncthreads();
     fetch(step + 3, ra1, rb1);
     __builtin_amdgcn_sched_barrier(0);
     mma();
+    if (FENCE) __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
   }
 #pragma unroll
@@ -466,16 +468,16 @@ k_gemm_v6(const float* __restrict__ x, const float* __restrict__ w, int K, int64
     }
 }
 
-template <int OCC>
+template <int OCC, int FENCE>
 static void launch_v6(const float* x, const float* w, int K, int64_t M, int N, float* y) {
   dim3 grid(static_cast<unsigned>((M + kBM - 1) / kBM), (N + kBN - 1) / kBN);
   static bool once = [] {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_v6<OCC>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_v6<OCC, FENCE>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         6 * kPlane);
     return true;
   }();
   (void)once;
-  k_gemm_v6<OCC><<<grid, kBlock, 6 * kPlane>>>(x, w, K, M, N, y);
+  k_gemm_v6<OCC, FENCE><<<grid, kBlock, 6 * kPlane>>>(x, w, K, M, N, y);
 }
 
 // the fp32-MFMA tile of csrc/linear.hip, for the side-by-side number
@@ -591,7 +593,8 @@ int main() {
   std::vector<float> hy(M * NMAX), hy2(M * NMAX);
   for (auto kn : {std::pair<int, int>{128, 128}, {256, 128}, {512, 128}, {128, 512}}) {
     const int K = kn.first, N = kn.second;
-    printf("  v6 (two register sets, 4 waves): occ2 %.1f us\n", time_us(launch_v6<2>, x, w, K, M, N, y2));
+    printf("  v6 (two register sets, 4 waves): free schedule %.1f us, fenced %.1f us\n",
+           time_us(launch_v6<2, 0>, x, w, K, M, N, y2), time_us(launch_v6<2, 1>, x, w, K, M, N, y2));
     {
       std::vector<float> h3(M * N);
       hipMemcpy(h3.data(), y2, M * N * 4, hipMemcpyDeviceToHost);
