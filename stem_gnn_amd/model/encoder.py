@@ -140,7 +140,13 @@ class MixtureSageLayer(nn.Module):
         # scatter_mean(x[col], row) == plain mean aggregation over the flipped graph
         agg = ops.MeanAggFn.apply(x, flipped)
         combined = torch.cat([agg, x], dim=-1)
-        outputs = torch.einsum("nd,kdo->nko", combined, self.weights)
+        k, d2, o = self.weights.shape
+        if combined.is_cuda and d2 % 4 == 0 and (k * o) % 4 == 0:
+            # einsum('nd,kdo->nko') as ONE product against the experts laid side by side [2D, K*O]
+            wide = self.weights.permute(1, 0, 2).reshape(d2, k * o)
+            outputs = ops.MatmulFn.apply(combined, wide).view(-1, k, o)
+        else:
+            outputs = torch.einsum("nd,kdo->nko", combined, self.weights)
         if self.residual:
             outputs = outputs + x.unsqueeze(1)
         return outputs

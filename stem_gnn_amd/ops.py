@@ -603,6 +603,30 @@ class LinearFn(torch.autograd.Function):
         return gx1, gw1, gx2, gw2, gb, None
 
 
+class MatmulFn(torch.autograd.Function):
+    """y [M, N] = a [M, K] @ w [K, N] with the weight's contraction index slow (the K-expert product of
+    MixtureSageLayer, reference model/encoder.py:126: einsum('nd,kdo->nko') is this with w = the experts laid side by
+    side).  Forward is the backward-data tile (weight read as stored), the two gradients are the forward and the
+    weight-gradient tiles -- no transposed copies."""
+
+    @staticmethod
+    def forward(ctx, a, w):
+        a, w = a.contiguous(), w.contiguous()
+        ctx.save_for_backward(a, w)
+        return linear_bwd_data(a, w)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, w = ctx.saved_tensors
+        g = g.contiguous()
+        ga = gw = None
+        if ctx.needs_input_grad[0]:
+            ga = linear_fwd(g, w, None, None, None)[0]      # g w^T
+        if ctx.needs_input_grad[1]:
+            gw, _ = linear_bwd_weight(a, g, False)           # a^T g
+        return ga, gw
+
+
 def linear(x: Tensor, lin: "torch.nn.Linear") -> Tensor:
     """nn.Linear forward through LinearFn (any leading dims)."""
     lead = x.shape[:-1]
