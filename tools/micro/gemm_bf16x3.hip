@@ -468,6 +468,132 @@ k_gemm_v6(const float* __restrict__ x, const float* __restrict__ w, int K, int64
     }
 }
 
+template <int OCC, int FENCE, int STEPS>
+__global__ void __launch_bounds__(kBlock, OCC)
+k_gemm_v7(const float* __restrict__ x, const float* __restrict__ w, int K, int64_t M, int N, float* __restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sA = smem;
+  unsigned char* sB = smem + 3 * kPlane;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, hi = lane >> 5, lj = lane & 31;
+  const int64_t m0 = static_cast<int64_t>(blockIdx.x) * kBM;
+  const int n0 = blockIdx.y * kBN;
+  constexpr int steps = STEPS;  // K == 32 * STEPS: the K loop is straight-line code, so every s_waitcnt is counted exactly
+  const float *pa[4], *pb[4];
+  int off[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int idx = t * kBlock + tid;
+    int64_t m = m0 + (idx >> 3);
+    if (m >= M) m = M - 1;
+    int n = n0 + (idx >> 3);
+    if (n >= N) n = N - 1;
+    pa[t] = x + m * K + 4 * (idx & 7);
+    pb[t] = w + static_cast<int64_t>(n) * K + 4 * (idx & 7);
+    off[t] = (idx >> 3) * kLdB + 8 * (idx & 7);
+  }
+  float4 ra0[4], rb0[4], ra1[4], rb1[4];
+  auto fetch = [&](int step, float4 (&qa)[4], float4 (&qb)[4]) {
+    const int k0 = (step < steps ? step : steps - 1) * kKC;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) qa[t] = ld4(pa[t] + k0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) qb[t] = ld4(pb[t] + k0);
+  };
+  auto stash = [&](const float4 (&qa)[4], const float4 (&qb)[4]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      uint2 h, m, l;
+      split3(qa[t], h, m, l);
+      *reinterpret_cast<uint2*>(sA + off[t]) = h;
+      *reinterpret_cast<uint2*>(sA + kPlane + off[t]) = m;
+      *reinterpret_cast<uint2*>(sA + 2 * kPlane + off[t]) = l;
+      split3(qb[t], h, m, l);
+      *reinterpret_cast<uint2*>(sB + off[t]) = h;
+      *reinterpret_cast<uint2*>(sB + kPlane + off[t]) = m;
+      *reinterpret_cast<uint2*>(sB + 2 * kPlane + off[t]) = l;
+    }
+  };
+  floatx16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  auto mma = [&]() {
+#pragma unroll
+    for (int ks = 0; ks < kKC / 16; ++ks) {
+      const int ko = ks * 32 + hi * 16;
+      bf16x8 a[2][3], b[2][3];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          a[t][p] = *reinterpret_cast<const bf16x8*>(sA + p * kPlane + (wm * 64 + t * 32 + lj) * kLdB + ko);
+          b[t][p] = *reinterpret_cast<const bf16x8*>(sB + p * kPlane + (wn * 64 + t * 32 + lj) * kLdB + ko);
+        }
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+          floatx16 c = acc[tm][tn];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][2], b[tn][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][2], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][1], b[tn][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][1], b[tn][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][0], c, 0, 0, 0);
+          acc[tm][tn] = c;
+        }
+    }
+  };
+  fetch(0, ra0, rb0);
+  fetch(1, ra1, rb1);
+#pragma unroll
+  for (int step = 0; step < steps; step += 2) {  // steps even, fully unrolled
+    stash(ra0, rb0);
+    __syncthreads();
+    if (step + 2 < steps) fetch(step + 2, ra0, rb0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma();
+    if (FENCE) __builtin_amdgcn_sched_barrier(0);  // keeps the next stash (and its wait for set 1) below the MFMAs
+    __syncthreads();
+    stash(ra1, rb1);
+    __syncthreads();
+    if (step + 3 < steps) fetch(step + 3, ra1, rb1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma();
+    if (FENCE) __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+      const int n = n0 + wn * 64 + tn * 32 + lj;
+      float* yr = y + (m0 + wm * 64 + tm * 32 + 4 * hi) * N + n;
+      const int64_t mrem = M - (m0 + wm * 64 + tm * 32 + 4 * hi);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int dr = (r & 3) + 8 * (r >> 2);
+        if (dr < mrem && n < N) yr[static_cast<int64_t>(dr) * N] = acc[tm][tn][r];
+      }
+    }
+}
+
+template <int OCC, int FENCE, int STEPS>
+static void launch_v7(const float* x, const float* w, int K, int64_t M, int N, float* y) {
+  dim3 grid(static_cast<unsigned>((M + kBM - 1) / kBM), (N + kBN - 1) / kBN);
+  static bool once = [] {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_v7<OCC, FENCE, STEPS>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 6 * kPlane);
+    return true;
+  }();
+  (void)once;
+  k_gemm_v7<OCC, FENCE, STEPS><<<grid, kBlock, 6 * kPlane>>>(x, w, K, M, N, y);
+}
+
 template <int OCC, int FENCE>
 static void launch_v6(const float* x, const float* w, int K, int64_t M, int N, float* y) {
   dim3 grid(static_cast<unsigned>((M + kBM - 1) / kBM), (N + kBN - 1) / kBN);
@@ -593,6 +719,13 @@ int main() {
   std::vector<float> hy(M * NMAX), hy2(M * NMAX);
   for (auto kn : {std::pair<int, int>{128, 128}, {256, 128}, {512, 128}, {128, 512}}) {
     const int K = kn.first, N = kn.second;
+    {
+      double t7 = 0, t7f = 0;
+      if (K == 128) { t7 = time_us(launch_v7<2, 0, 4>, x, w, K, M, N, y2); t7f = time_us(launch_v7<2, 1, 4>, x, w, K, M, N, y2); }
+      if (K == 256) { t7 = time_us(launch_v7<2, 0, 8>, x, w, K, M, N, y2); t7f = time_us(launch_v7<2, 1, 8>, x, w, K, M, N, y2); }
+      if (K == 512) { t7 = time_us(launch_v7<2, 0, 16>, x, w, K, M, N, y2); t7f = time_us(launch_v7<2, 1, 16>, x, w, K, M, N, y2); }
+      printf("  v7 (two register sets, K loop fully unrolled): free schedule %.1f us, fenced %.1f us\n", t7, t7f);
+    }
     printf("  v6 (two register sets, 4 waves): free schedule %.1f us, fenced %.1f us\n",
            time_us(launch_v6<2, 0>, x, w, K, M, N, y2), time_us(launch_v6<2, 1>, x, w, K, M, N, y2));
     {
