@@ -155,3 +155,42 @@ class NeighborLoader:
     def __iter__(self):
         for i in range(0, self.nodes.numel(), self.batch_size):
             yield self.sampler.sample(self.nodes[i:i + self.batch_size])
+
+
+class PrefetchLoader:
+    """Wraps a loader of device-resident batches (e.g. NeighborLoader over a HipNeighborSampler): batch i+1 is
+    sampled on a side HIP stream BEFORE the caller enqueues step i, so the sampler's launches and its one
+    device->host size read overlap the steps already queued on the current stream instead of holding them up.
+    ``prepare(batch)`` (optional) runs on the side stream too, e.g. the feature gather and the transposed CSR.
+
+    ``uses`` names the batch attributes the consumer's kernels read (tensors or objects with ``record_stream``, like
+    GraphStructure): they were allocated on the side stream, so they are handed to the current stream with
+    ``record_stream`` -- only those, because every recorded block turns its later free into an event round trip."""
+
+    def __init__(self, loader, device, prepare=None, uses=("feat", "x", "xe", "graph")):
+        self.loader, self.device, self.prepare, self.uses = loader, torch.device(device), prepare, tuple(uses)
+        self.side = torch.cuda.Stream(device=self.device)
+
+    def __len__(self):
+        return len(self.loader)
+
+    def _load(self, it):
+        with torch.cuda.stream(self.side):
+            b = next(it, None)
+            if b is not None and self.prepare is not None:
+                b = self.prepare(b) or b
+            return b
+
+    def __iter__(self):
+        it = iter(self.loader)
+        nxt = self._load(it)
+        while nxt is not None:
+            cur = nxt
+            main = torch.cuda.current_stream(self.device)
+            main.wait_stream(self.side)
+            for name in self.uses:
+                v = getattr(cur, name, None)
+                if v is not None and (not isinstance(v, Tensor) or v.is_cuda):
+                    v.record_stream(main)
+            nxt = self._load(it)  # before the caller's step: it overlaps the steps still queued on the device
+            yield cur

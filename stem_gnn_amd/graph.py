@@ -160,6 +160,13 @@ class GraphStructure:
             setattr(self, attr, ops.SplitPlan(self.num_edges, self.rowptr.device))
         return getattr(self, attr)
 
+    def record_stream(self, stream) -> None:
+        """Tell the caching allocator that `stream` uses this structure's tensors (built on another stream, e.g. by
+        a loader that samples one batch ahead)."""
+        for v in vars(self).values():
+            if isinstance(v, Tensor) and v.is_cuda:
+                v.record_stream(stream)
+
     def in_degree(self) -> Tensor:
         return (self.rowptr[1:] - self.rowptr[:-1]).long()
 

@@ -206,7 +206,8 @@ def _pretrain_epoch(model, loader, optimizer, params, scheduler, no_codebook, lo
             x = ops.gather_rows(ntf, data.x.to(device).long().contiguous())  # node_text_feat[data.x]
         else:
             x = ntf
-        edge_index = data.edge_index.to(device)
+        graph = getattr(data, "graph", None)  # the HIP sampler hands the batch's CSR over ready-made
+        edge_index = graph if graph is not None else data.edge_index.to(device)
         edge_attr = EdgeTypeAttr(data.edge_text_feat.to(device), data.xe.to(device))  # edge_text_feat[xe], lazily
         loss, losses, _ = pretrain_step(model, optimizer, scheduler, params, x, edge_index, edge_attr, bs,
                                         record_draws=False, no_codebook=no_codebook, grad_sync=grad_sync)

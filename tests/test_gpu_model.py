@@ -328,3 +328,33 @@ def test_finetune_consumer_flow(dev):
     torch.nn.functional.cross_entropy(logits, torch.randint(0, 7, (300,), device=dev)).backward()
     assert zg.grad is not None and bool(torch.isfinite(zg.grad).all())
     assert tuple(vq.codebook.shape) == (H, K, D)
+
+
+def test_prefetch_loader_yields_the_same_batches(dev):
+    """PrefetchLoader samples one batch ahead on a side stream: same batches, same order, usable on the current
+    stream right away (values checked after more allocator traffic on both streams)."""
+    from stem_gnn_amd import ops
+    from stem_gnn_amd.data.sampler import HipNeighborSampler, NeighborLoader, PrefetchLoader
+    from stem_gnn_amd.data.synthetic import make_graph
+    g = make_graph(20_000, 200_000, 32, 3, kind="U", device=dev)
+
+    def make_loader():
+        s = HipNeighborSampler(g.edge_index, g.xe, g.num_nodes, g.x, g.node_text_feat, g.edge_text_feat, [5, 5], seed=3)
+        return NeighborLoader(s, torch.arange(4096, device=dev), 512, shuffle=True, seed=1)
+
+    plain = [(b.n_id.clone(), b.edge_index.clone(), b.xe.clone()) for b in make_loader()]
+
+    def prepare(b):
+        b.feat = ops.gather_rows(g.node_text_feat, b.x.contiguous())
+        b.graph.ensure_transpose()
+
+    got = []
+    for b in PrefetchLoader(make_loader(), dev, prepare):
+        junk = torch.randn(1 << 20, device=dev).sum()          # allocator + stream traffic between hand-over and use
+        got.append((b.n_id, b.edge_index, b.xe, b.feat, b.graph.rowptr_t, junk))
+    torch.cuda.synchronize()
+    assert len(got) == len(plain) == 8
+    for (n_id, ei, xe, feat, rpt, _), (n0, e0, x0) in zip(got, plain):
+        assert torch.equal(n_id, n0) and torch.equal(ei, e0) and torch.equal(xe, x0)
+        assert torch.equal(feat, g.node_text_feat[n_id])
+        assert int(rpt[-1]) == ei.size(1)
