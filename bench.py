@@ -154,7 +154,11 @@ def main():
                               [10] * params["num_layers"], seed=100 + rank)
         loader = NeighborLoader(sampler, torch.arange(g.num_nodes, device=dev), args.batch_size, shuffle=True,
                                 rank=rank, world_size=world, seed=7)
-        it = iter(loader)
+        def epochs():  # batch stream that starts a new epoch when a rank's shard runs out (same count on all ranks)
+            while True:
+                yield from loader
+
+        it = epochs()
         torch.cuda.synchronize()
         t_s = time.perf_counter()
         for _ in range(total):
