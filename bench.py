@@ -271,6 +271,32 @@ def main():
                          "avg_launch_us": (k1_ms * 1e3 / k1_launches) if k1_launches else None,
                          "algorithmic_bytes_per_launch": (k1_bytes / k1_launches) if k1_launches else None},
         }
+        # The dense products are the largest share of the step: the layer product lin_l(agg) + lin_r(x)
+        # at this batch's row count, timed back to back.  Executed matrix-core work is six bf16 MFMA products per
+        # fp32 product (csrc/linear.hip), priced against the dense bf16 peak; informational, not the judged roofline.
+        xb = batches[args.warmup][0]
+        Mb = int(xb.size(0))
+        wl_, wr_ = model.encoder.layers[0].lin_l.weight.detach(), model.encoder.layers[0].lin_r.weight.detach()
+        bl_ = model.encoder.layers[0].lin_l.bias.detach()
+        agg_ = torch.randn_like(xb)
+        for _ in range(3):
+            ops.linear_fwd(agg_, wl_, xb, wr_, bl_, False)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 30
+        ev0.record()
+        for _ in range(reps):
+            ops.linear_fwd(agg_, wl_, xb, wr_, bl_, False)
+        ev1.record()
+        torch.cuda.synchronize()
+        us = ev0.elapsed_time(ev1) / reps * 1e3
+        flop = 2.0 * Mb * (2 * D) * D
+        x3 = ops.linear_set_mode(-1) == 1
+        out["roofline_dense"] = {
+            "bound": "mfma", "kernel": "k_linear_fwd_x3 (lin_l(agg) + lin_r(x), one launch)" if x3 else "k_linear_fwd",
+            "rows": Mb, "us_per_launch": us, "fp32_equivalent_tflops": flop / us / 1e6,
+            "achieved": (6.0 if x3 else 1.0) * flop / us / 1e6, "peak": 2500.0 if x3 else 157.0, "unit": "TFLOP/s",
+            "frac": (6.0 if x3 else 1.0) * flop / us / 1e6 / (2500.0 if x3 else 157.0),
+            "hbm_floor_us": (3.0 * Mb * D * 4) / 6.3e12 * 1e6}
         if world == 1 and not args.no_cpu_baseline:
             x, ei, xe, bs = batches[args.warmup]
             out["cpu_baseline"] = cpu_baseline(params, (x.cpu(), ei.edge_index.cpu(), g.edge_text_feat.cpu(), xe.cpu()), bs,
