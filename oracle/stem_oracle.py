@@ -548,3 +548,40 @@ def eval_node_full_batch(model: OracleTaskModel, x, edge_index, edge_attr, y, sp
         out = {k: hit[m].mean().item() * 100 for k, m in (("train", split["train"]), ("val", split["valid"]),
                                                            ("test", split["test"]))}
     return out, pred
+
+
+def edge_embeddings(z: Tensor, edge_index: Tensor) -> Tensor:
+    """task/link.py:7-8: the mean of the two endpoint embeddings."""
+    return (z[edge_index[0]] + z[edge_index[1]]) / 2
+
+
+def ft_link_full_batch_step(model: OracleTaskModel, optimizer, x, edge_index, edge_attr, y, train_mask, params,
+                            dropout_masks=None, ortho_ids=None, scheduler=None) -> Dict[str, Tensor]:
+    """ft_link with loader=None (task/link.py:19-48): encode the graph, classify the TRAIN edges from the mean of
+    their endpoint embeddings (labels = one class per edge, e.g. the relation type), one optimizer step."""
+    model.train()
+    z = model.encode(x, edge_index, edge_attr, dropout_masks)
+    env_loss = params.get("lamda_env", 0.0) * model.encoder.get_env_reg()
+    edge_z = edge_embeddings(z, edge_index[:, train_mask])
+    act_loss = model.compute_activation_loss(edge_z, y[train_mask], ortho_ids=ortho_ids) * 1.0
+    jac_loss = model.decoder_jacobian_penalty()
+    loss = act_loss + jac_loss + env_loss
+    optimizer.zero_grad()
+    loss.backward()
+    optimizer.step()
+    if scheduler:
+        scheduler.step()
+    return {"act_loss": act_loss.detach(), "jac_loss": jac_loss.detach(), "env_loss": env_loss.detach(),
+            "loss": loss.detach()}
+
+
+def eval_link_full_batch(model: OracleTaskModel, x, edge_index, edge_attr, y, split: Dict[str, Tensor]):
+    """eval_link with loader=None (task/link.py:98-108,125-140): per-edge class probabilities, accuracy * 100 per mask."""
+    model.eval()
+    with torch.no_grad():
+        z = model.encode(x, edge_index, edge_attr)
+        pred = model.get_lin_logits(edge_embeddings(z, edge_index)).mean(1).softmax(dim=-1)
+        hit = (pred.argmax(dim=-1) == y).float()
+        out = {k: hit[m].mean().item() * 100 for k, m in (("train", split["train"]), ("val", split["valid"]),
+                                                           ("test", split["test"]))}
+    return out, pred

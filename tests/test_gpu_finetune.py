@@ -155,3 +155,47 @@ def test_eval_metrics_match_their_definitions(dev):
         p, q = s[v, i][t[v, i] == 1], s[v, i][t[v, i] == 0]
         exp.append(((p[:, None] > q[None, :]).double().mean() + 0.5 * (p[:, None] == q[None, :]).double().mean()).item())
     assert abs(eval_auc(s, t) - sum(exp) / 2) < 1e-9
+
+
+def test_link_classification_finetune_step_and_eval(dev):
+    """task/link.py, full batch, on a small knowledge-graph-shaped stand-in (typed edges, relation class per edge):
+    edge embedding = mean of the endpoint embeddings -> TaskModel; loss terms, parameters and predictions against
+    the oracle with the dropout draws replayed."""
+    from stem_gnn_amd import ops
+    from stem_gnn_amd.task.link import ft_link, eval_link
+    from stem_gnn_amd.utils.others import freeze_params
+    D, L, H, K, C = 128, 2, 4, 64, 11
+    params = {"separate_decoder_for_each_head": True, "decoder_jac_coeff": 0.0, "use_vq": 1, "setting": "standard",
+              "task": "link", "lamda_env": 0.0}
+    data, _, _ = cora_like(seed=3, n=3000, e=16000, d=D, c=C, t=C)
+    data.x = torch.arange(3000)                       # span_node_and_edge_idx: one text row per node
+    E = data.edge_index.size(1)
+    g = torch.Generator().manual_seed(5)
+    labels = data.xe.clone()                           # the relation type is the class (WN18RR / FB15K237 style)
+    perm = torch.randperm(E, generator=g)
+    split = {}
+    for name, lo, hi in (("train", 0, 8000), ("valid", 8000, 10000), ("test", 10000, 14000)):
+        m = torch.zeros(E, dtype=torch.bool)
+        m[perm[lo:hi]] = True
+        split[name] = m
+    om, gm = build_pair(D, L, H, K, C, dev, params, normalize="batch")   # config/finetune.yaml link.*: normalize batch
+    freeze_params(om.vq); freeze_params(gm.vq)
+    opt_o = torch.optim.AdamW(om.parameters(), lr=1e-3)
+    opt_g = torch.optim.AdamW(gm.parameters(), lr=1e-3)
+    ops.manual_seed(4)
+    N = 3000
+    ea_cpu = data.edge_text_feat[data.xe]
+    ids = torch.arange(32)
+    gm.vq._rand_code_ids = lambda n, k, device: ids.to(device)
+    for step in range(3):
+        out_g = ft_link(gm, data, None, opt_g, split, labels, params)
+        masks = [ops.dropout_keep_mask(N * D, 0.15, s, o, dev).view(N, D).cpu() for (s, o) in gm.encoder.last_dropout_keys]
+        out_o = O.ft_link_full_batch_step(om, opt_o, data.node_text_feat, data.edge_index, ea_cpu, labels,
+                                          split["train"], params, dropout_masks=masks, ortho_ids=ids)
+        for k in ("act_loss", "jac_loss", "env_loss", "loss"):
+            assert abs(out_g[k] - float(out_o[k])) <= 1e-4 * max(1.0, abs(float(out_o[k]))), (step, k, out_g, out_o)
+    res_g = eval_link(gm, data, None, split, labels, params)
+    res_o, pred_o = O.eval_link_full_batch(om, data.node_text_feat, data.edge_index, ea_cpu, labels, split)
+    assert res_g["metric"] == "acc"
+    for k in ("train", "val", "test"):
+        assert abs(res_g[k] - res_o[k]) <= 2 * 100.0 / int(split["valid" if k == "val" else k].sum()) + 1e-6
