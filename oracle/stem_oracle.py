@@ -496,6 +496,17 @@ class OracleTaskModel(nn.Module):
     def encode(self, x, edge_index, edge_attr=None, dropout_masks=None):
         return self.encoder(x, edge_index, edge_attr, dropout_masks=dropout_masks)
 
+    def encode_graph(self, x, edge_index, edge_attr=None, batch=None, pool="mean", dropout_masks=None):
+        """ft_model.py:61-69 with global_mean_pool / global_add_pool restated as segment sums over ``batch``."""
+        z = self.encoder(x, edge_index, edge_attr, dropout_masks=dropout_masks)
+        n = int(batch.max()) + 1
+        out = torch.zeros(n, z.size(1), dtype=z.dtype).index_add_(0, batch, z)
+        if pool == "mean":
+            out = out / torch.bincount(batch, minlength=n).clamp(min=1).to(z.dtype).unsqueeze(1)
+        elif pool != "sum":
+            raise NotImplementedError(pool)
+        return out
+
     def get_lin_logits(self, z: Tensor, ortho_ids: Optional[Tensor] = None) -> Tensor:  # ft_model.py:90-103
         if self.use_vq:
             quantize, _, _, codes = self.vq(z, ortho_ids)

@@ -199,3 +199,59 @@ def test_link_classification_finetune_step_and_eval(dev):
     assert res_g["metric"] == "acc"
     for k in ("train", "val", "test"):
         assert abs(res_g[k] - res_o[k]) <= 2 * 100.0 / int(split["valid" if k == "val" else k].sum()) + 1e-6
+
+
+def test_graph_level_multitask_finetune_and_auc(dev):
+    """task/graph.py on molecule-shaped batches (disjoint unions of small graphs, dense per-edge text rows, a label
+    matrix with missing entries): the step's losses against the oracle, and ROC-AUC evaluation runs end to end."""
+    from stem_gnn_amd import ops
+    from stem_gnn_amd.task.graph import ft_graph, eval_graph
+    D, L, H, K, T = 64, 2, 4, 32, 3
+    params = {"separate_decoder_for_each_head": True, "decoder_jac_coeff": 1e-4, "use_vq": 1, "setting": "standard",
+              "task": "graph", "lamda_env": 0.0}
+    g = torch.Generator().manual_seed(0)
+
+    def make_batch(num_graphs):
+        sizes = torch.randint(8, 30, (num_graphs,), generator=g)
+        n = int(sizes.sum())
+        batch = torch.repeat_interleave(torch.arange(num_graphs), sizes)
+        start = torch.cumsum(sizes, 0) - sizes
+        src, dst = [], []
+        for i in range(num_graphs):
+            e = int(sizes[i]) * 2
+            u = torch.randint(0, int(sizes[i]), (e,), generator=g) + int(start[i])
+            v = torch.randint(0, int(sizes[i]), (e,), generator=g) + int(start[i])
+            src.append(torch.cat([u, v])); dst.append(torch.cat([v, u]))
+        b = Data()
+        b.edge_index = torch.stack([torch.cat(src), torch.cat(dst)])
+        b.node_text_feat = torch.nn.functional.normalize(torch.randn(n, D, generator=g), dim=-1)
+        b.edge_text_feat = torch.nn.functional.normalize(torch.randn(b.edge_index.size(1), D, generator=g), dim=-1)
+        b.batch = batch
+        y = torch.randint(0, 2, (num_graphs, T), generator=g).float()
+        y[torch.rand(num_graphs, T, generator=g) < 0.2] = float("nan")      # missing labels
+        b.y = y
+        return b
+
+    loader = [make_batch(48) for _ in range(3)]
+    om, gm = build_pair(D, L, H, K, T, dev, params, normalize="batch")
+    opt_o = torch.optim.AdamW(om.parameters(), lr=1e-3)
+    opt_g = torch.optim.AdamW(gm.parameters(), lr=1e-3)
+    ops.manual_seed(2)
+    ids = torch.arange(32)
+    gm.vq._rand_code_ids = lambda n, k, device: ids.to(device)
+    # one batch at a time so the oracle can replay each batch's dropout draws
+    for b in loader:
+        out_g = ft_graph(gm, None, [b], opt_g, None, None, params)
+        n = b.node_text_feat.size(0)
+        masks = [ops.dropout_keep_mask(n * D, 0.15, s, o, dev).view(n, D).cpu() for (s, o) in gm.encoder.last_dropout_keys]
+        om.train()
+        z = om.encode_graph(b.node_text_feat, b.edge_index, b.edge_text_feat, b.batch, "mean", dropout_masks=masks)
+        act = om.compute_activation_loss(z, b.y.clone().double(), task="multi", ortho_ids=ids)
+        loss = act + om.decoder_jacobian_penalty()
+        opt_o.zero_grad(); loss.backward(); opt_o.step()
+        act, loss = act.detach(), loss.detach()
+        assert abs(out_g["act_loss"] - float(act)) <= 1e-4 * max(1.0, abs(float(act))), (out_g, float(act))
+        assert abs(out_g["loss"] - float(loss)) <= 1e-4 * max(1.0, abs(float(loss)))
+    res = eval_graph(gm, None, [loader, loader[:1], None], None, None, params)
+    assert res["metric"] == "auc" and 0.0 <= res["train"] <= 100.0 and 0.0 <= res["val"] <= 100.0
+    assert res["test"] != res["test"]                                     # no loader -> NaN (task/graph.py:74-75)
