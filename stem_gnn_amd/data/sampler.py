@@ -12,7 +12,7 @@ pre-sampled into HBM); SURVEY.md §8f rank 1 replaces it with a fused HIP sample
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import List, Optional
+from typing import List
 
 import torch
 from torch import Tensor

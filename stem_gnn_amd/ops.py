@@ -5,9 +5,9 @@ is no eager/CPU fallback.
 """
 from __future__ import annotations
 
+import ctypes
 import os
 import threading
-from ctypes import c_void_p
 from typing import Optional, Tuple
 
 import torch
@@ -204,7 +204,6 @@ def sample_batch(rowptr: Tensor, src: Tensor, etype: Optional[Tensor], num_nodes
                  seed: int, offset: int, local_of: Tensor):
     """One neighbour-sampled mini-batch on the device -> (n_id, b_rowptr, b_src, b_type, coo, N_b, E_b).
     One 8-byte device->host copy per batch (the two counts)."""
-    import ctypes
     _req(seeds, torch.int64, "seeds", 1)
     B, L, dev = seeds.numel(), len(fanouts), seeds.device
     level, cap_nodes, cap_edges = B, B, 0
@@ -255,7 +254,6 @@ class KernelTimer:
 
     def collect(self):
         """-> (total kernel ms, launches, total algorithmic bytes)"""
-        import ctypes
         ms, n = ctypes.c_double(0.0), ctypes.c_int64(0)
         check(lib.stemgnn_profile_k1_collect(ctypes.byref(ms), ctypes.byref(n)), "profile_k1_collect")
         total = sum(k1_algorithmic_bytes(N, g.live_edges_host(), D, mode, T) for (N, g, D, mode, T) in self.bytes)
@@ -917,7 +915,6 @@ def clip_grad_norm_(parameters, max_norm: float) -> Tensor:
     """torch.nn.utils.clip_grad_norm_(parameters, max_norm) (L2; reference pretrain.py:62) in three launches.
     Returns the total norm (0-dim tensor).  Gradients that are not dense fp32 on one device, or more than the
     table holds, go through torch's own implementation."""
-    import ctypes
     grads = [p.grad for p in parameters if p.grad is not None]
     if not grads:
         return torch.zeros(())
@@ -942,7 +939,6 @@ class WeightedSumFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, weights, *terms):
-        import ctypes
         n = len(terms)
         ts = [t.reshape(1).contiguous() for t in terms]
         for t in ts:
@@ -964,7 +960,6 @@ class WeightedSumFn(torch.autograd.Function):
 
 
 def _grad_table(grads):
-    import ctypes
     n = len(grads)
     return ((ctypes.c_void_p * n)(*[g.data_ptr() for g in grads]), (ctypes.c_int64 * n)(*[g.numel() for g in grads]), n)
 
@@ -992,7 +987,6 @@ class FusedAdamW(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None, grad_coef: Optional[Tensor] = None):
-        import ctypes
         loss = None
         if closure is not None:
             with torch.enable_grad():

@@ -22,8 +22,8 @@ from .graph import EdgeTypeAttr, as_graph
 from .model.encoder import Encoder, InnerProductDecoder
 from .model.pt_model import PretrainModel
 from .model.vq import VectorQuantize
-from .utils.graph_utils import dropout_adj, mask_feature
-from .utils.others import get_scheduler, seed_everything
+from .utils.graph_utils import mask_feature
+from .utils.others import get_scheduler
 
 
 def default_params() -> Dict:
