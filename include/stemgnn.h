@@ -126,7 +126,9 @@ int stemgnn_negative_sample_into(const int32_t* rowptr, const int32_t* src, cons
  * nodes hop by hop in order of first appearance.  Outputs: n_id [cap_nodes] (global id per
  * local node), the batch's by-target CSR b_rowptr [cap_nodes+1] / b_src / b_type [cap_edges],
  * its COO b_coo int64 [2, cap_edges] (row stride cap_edges; edge j == CSR slot j) and
- * counts[2] = (N_b, E_b) on the device.  cap_nodes >= B(1 + f + .. + f^L), cap_edges >= B(f + .. + f^L).
+ * counts[3] = (N_b, E_b, A_b) on the device, A_b = the number of leading local nodes that were expanded (only
+ * those can have in-edges: rows >= A_b of the batch CSR are empty).  cap_nodes >= B(1 + f + .. + f^L),
+ * cap_edges >= B(f + .. + f^L).
  * ------------------------------------------------------------------------------------ */
 int stemgnn_sampler_init_map(int32_t* local_of, int64_t num_nodes, void* stream);
 size_t stemgnn_sampler_workspace_bytes(int64_t batch_size, int64_t hops, int64_t max_fanout);
@@ -272,12 +274,14 @@ int stemgnn_linear_set_mode(int mode);
 /* y [M, N] = x1 [M, K1] w1[N, K1]^T (+ x2 [M, K2] w2 [N, K2]^T when K2 > 0) + bias [N] (NULL: none).
  * stats_partial (may be NULL): receives per-row-block column sums / sums of squares of y,
  * [stemgnn_linear_stats_blocks(M, N)][2][N]; *stats_blocks_host (host pointer, may be NULL)
- * receives that block count. */
+ * receives that block count.  x1_rows: rows >= x1_rows of x1 are KNOWN TO BE ZERO (the aggregate of a sampled
+ * batch, whose edges all end in the leading, expanded nodes): row tiles past them skip the x1 half of the
+ * contraction.  Pass -1 (or M) when no such promise holds. */
 size_t stemgnn_linear_stats_partial_bytes(int64_t num_rows, int64_t out_dim);
 int64_t stemgnn_linear_stats_blocks(int64_t num_rows, int64_t out_dim);
 int stemgnn_linear_fwd(const float* x1, const float* w1, int64_t k1, const float* x2, const float* w2, int64_t k2,
                        const float* bias, int64_t num_rows, int64_t out_dim, float* y, float* stats_partial,
-                       int64_t* stats_blocks_host, void* stream);
+                       int64_t* stats_blocks_host, int64_t x1_rows, void* stream);
 
 /* Backward w.r.t. the input of y = x w^T: dx[M, K] = dy[M, N] w[N, K] (autograd of nn.Linear, reference
  * model/encoder.py:83-87, model/vq.py:881,1041).  The weight is read as stored; no transposed copy is made.

@@ -79,7 +79,7 @@ _SIGNATURES = {
     "stemgnn_adamw_step": (c_int, [P, P, P, P, P, I32, c_float, c_float, c_float, c_float, c_float, I64, P, P]),
     "stemgnn_linear_set_mode": (c_int, [c_int]),
     "stemgnn_linear_bwd_data": (c_int, [P, P, I64, I64, I64, P, P]),
-    "stemgnn_linear_fwd": (c_int, [P, P, I64, P, P, I64, P, I64, I64, P, P, P, P]),
+    "stemgnn_linear_fwd": (c_int, [P, P, I64, P, P, I64, P, I64, I64, P, P, P, I64, P]),
     "stemgnn_linear_bwd_weight_workspace_bytes": (c_size_t, [I64, I64, I64]),
     "stemgnn_linear_bwd_weight": (c_int, [P, P, I64, I64, I64, P, P, P, c_size_t, P]),
     "stemgnn_transpose": (c_int, [P, I64, I64, P, P]),

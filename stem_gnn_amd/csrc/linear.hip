@@ -47,7 +47,7 @@ __global__ void __launch_bounds__(kBlock, 2)
 k_linear_fwd(const float* __restrict__ x1, const float* __restrict__ w1, int K1, const float* __restrict__ x2,
              const float* __restrict__ w2, int K2, const float* __restrict__ bias, int64_t M, int N,
              float* __restrict__ y, float* __restrict__ stats_partial /*[blocks][2][N]*/, int64_t row_base,
-             int64_t stats_block0) {
+             int64_t stats_block0, int64_t x1_rows) {
   // BM = 128: waves 2(m) x 2(n), 64x64 per wave.  BM = 32 (tail tiles): waves 1 x 4, 32x32 per wave.
   constexpr int WM = BM == 128 ? 2 : 1;
   constexpr int WN = 4 / WM;
@@ -122,8 +122,11 @@ k_linear_fwd(const float* __restrict__ x1, const float* __restrict__ w1, int K1,
     bias_v[tn] = (bias != nullptr && n < N) ? bias[n] : 0.f;
   }
 
-  fetch(0);
-  for (int step = 0; step < steps; ++step) {
+  // rows >= x1_rows of the first operand are zero (an aggregate over a sampled batch: only the leading, expanded
+  // nodes receive edges): a tile past them starts at the second operand's chunks
+  const int first_step = (m0 >= x1_rows) ? c1 : 0;
+  if (first_step < steps) fetch(first_step);
+  for (int step = first_step; step < steps; ++step) {
     stash();
     __syncthreads();
     if (step + 1 < steps) fetch(step + 1);
@@ -204,7 +207,7 @@ __global__ void __launch_bounds__(kBlock, 2)
 k_linear_fwd_x3(const float* __restrict__ x1, const float* __restrict__ w1, int K1, const float* __restrict__ x2,
              const float* __restrict__ w2, int K2, const float* __restrict__ bias, int64_t M, int N,
              float* __restrict__ y, float* __restrict__ stats_partial /*[blocks][2][N]*/, int64_t row_base,
-             int64_t stats_block0) {
+             int64_t stats_block0, int64_t x1_rows) {
   // BM = 128: waves 2(m) x 2(n), 64x64 per wave.  BM = 32 (tail tiles): waves 1 x 4, 32x32 per wave.
   constexpr int WM = BM == 128 ? 2 : 1;
   constexpr int WN = 4 / WM;
@@ -285,8 +288,11 @@ k_linear_fwd_x3(const float* __restrict__ x1, const float* __restrict__ w1, int 
     bias_v[tn] = (bias != nullptr && n < N) ? bias[n] : 0.f;
   }
 
-  fetch(0);
-  for (int step = 0; step < steps; ++step) {
+  // rows >= x1_rows of the first operand are zero (an aggregate over a sampled batch: only the leading, expanded
+  // nodes receive edges): a tile past them starts at the second operand's chunks
+  const int first_step = (m0 >= x1_rows) ? c1 : 0;
+  if (first_step < steps) fetch(first_step);
+  for (int step = first_step; step < steps; ++step) {
     stash();
     __syncthreads();
     if (step + 1 < steps) fetch(step + 1);
@@ -698,9 +704,10 @@ int64_t stemgnn_linear_stats_blocks(int64_t M, int64_t N) {
 
 int stemgnn_linear_fwd(const float* x1, const float* w1, int64_t K1, const float* x2, const float* w2, int64_t K2,
                        const float* bias, int64_t M, int64_t N, float* y, float* stats_partial,
-                       int64_t* stats_blocks_host, void* stream_) {
+                       int64_t* stats_blocks_host, int64_t x1_rows, void* stream_) {
   hipStream_t st = static_cast<hipStream_t>(stream_);
   if (!lin_dims_ok(M, N, K1) || K2 < 0 || K2 % 4 != 0) return STEMGNN_ERR_INVALID_ARG;
+  const int64_t x1r = (x1_rows < 0 || x1_rows > M) ? M : x1_rows;
   if (!fits_i32(M)) return STEMGNN_ERR_TOO_LARGE;
   if (stats_blocks_host) *stats_blocks_host = stemgnn_linear_stats_blocks(M, N);
   if (M == 0) return STEMGNN_OK;
@@ -713,11 +720,11 @@ int stemgnn_linear_fwd(const float* x1, const float* w1, int64_t K1, const float
   if (plan.main_tiles > 0) {
     dim3 grid(static_cast<unsigned>(plan.main_tiles), static_cast<unsigned>(gy));
     if (stats_partial) {
-      if (x3) k_linear_fwd_x3<128, true><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, stats_partial, 0, 0);
-      else k_linear_fwd<128, true><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, stats_partial, 0, 0);
+      if (x3) k_linear_fwd_x3<128, true><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, stats_partial, 0, 0, x1r);
+      else k_linear_fwd<128, true><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, stats_partial, 0, 0, x1r);
     } else {
-      if (x3) k_linear_fwd_x3<128, false><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, nullptr, 0, 0);
-      else k_linear_fwd<128, false><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, nullptr, 0, 0);
+      if (x3) k_linear_fwd_x3<128, false><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, nullptr, 0, 0, x1r);
+      else k_linear_fwd<128, false><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, nullptr, 0, 0, x1r);
     }
     STEMGNN_LAUNCH_CHECK();
   }
@@ -728,14 +735,14 @@ int stemgnn_linear_fwd(const float* x1, const float* w1, int64_t K1, const float
     const int64_t row_base = plan.main_tiles * kBM;
     if (stats_partial) {
       if (x3) k_linear_fwd_x3<32, true><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, stats_partial,
-                                                                 row_base, plan.main_tiles);
+                                                                 row_base, plan.main_tiles, x1r);
       else k_linear_fwd<32, true><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, stats_partial,
-                                                           row_base, plan.main_tiles);
+                                                           row_base, plan.main_tiles, x1r);
     } else {
       if (x3) k_linear_fwd_x3<32, false><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, nullptr,
-                                                                  row_base, plan.main_tiles);
+                                                                  row_base, plan.main_tiles, x1r);
       else k_linear_fwd<32, false><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, nullptr,
-                                                            row_base, plan.main_tiles);
+                                                            row_base, plan.main_tiles, x1r);
     }
     STEMGNN_LAUNCH_CHECK();
   }
@@ -757,15 +764,15 @@ int stemgnn_linear_bwd_data(const float* dy, const float* w, int64_t M, int64_t 
   const bool x3 = gemm_x3();
   if (plan.main_tiles > 0) {
     dim3 grid(static_cast<unsigned>(plan.main_tiles), static_cast<unsigned>(gy));
-    if (x3) k_linear_fwd_x3<128, false, true><<<grid, kBlock, 0, st>>>(dy, w, kc, nullptr, nullptr, 0, nullptr, M, n, dx, nullptr, 0, 0);
-    else k_linear_fwd<128, false, true><<<grid, kBlock, 0, st>>>(dy, w, kc, nullptr, nullptr, 0, nullptr, M, n, dx, nullptr, 0, 0);
+    if (x3) k_linear_fwd_x3<128, false, true><<<grid, kBlock, 0, st>>>(dy, w, kc, nullptr, nullptr, 0, nullptr, M, n, dx, nullptr, 0, 0, M);
+    else k_linear_fwd<128, false, true><<<grid, kBlock, 0, st>>>(dy, w, kc, nullptr, nullptr, 0, nullptr, M, n, dx, nullptr, 0, 0, M);
     STEMGNN_LAUNCH_CHECK();
   }
   if (plan.tail_tiles > 0) {
     dim3 grid(static_cast<unsigned>(plan.tail_tiles), static_cast<unsigned>(gy));
     const int64_t row_base = plan.main_tiles * kBM;
-    if (x3) k_linear_fwd_x3<32, false, true><<<grid, kBlock, 0, st>>>(dy, w, kc, nullptr, nullptr, 0, nullptr, M, n, dx, nullptr, row_base, 0);
-    else k_linear_fwd<32, false, true><<<grid, kBlock, 0, st>>>(dy, w, kc, nullptr, nullptr, 0, nullptr, M, n, dx, nullptr, row_base, 0);
+    if (x3) k_linear_fwd_x3<32, false, true><<<grid, kBlock, 0, st>>>(dy, w, kc, nullptr, nullptr, 0, nullptr, M, n, dx, nullptr, row_base, 0, M);
+    else k_linear_fwd<32, false, true><<<grid, kBlock, 0, st>>>(dy, w, kc, nullptr, nullptr, 0, nullptr, M, n, dx, nullptr, row_base, 0, M);
     STEMGNN_LAUNCH_CHECK();
   }
   return STEMGNN_OK;

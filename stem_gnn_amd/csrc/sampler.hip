@@ -160,13 +160,13 @@ k_emit_edges(const int32_t* __restrict__ s_src, const int32_t* __restrict__ s_ty
 // publishes (N_b, E_b); clears the global->local scratch map.
 __global__ void __launch_bounds__(kThreads)
 k_finish(int hops, const BatchCounters* __restrict__ ctr, int32_t cap_nodes, const int32_t* __restrict__ n_id,
-         int32_t* __restrict__ local_of, int32_t* __restrict__ b_rowptr, int32_t* __restrict__ counts /*[2]*/) {
+         int32_t* __restrict__ local_of, int32_t* __restrict__ b_rowptr, int32_t* __restrict__ counts /*[3]*/) {
   const int i = blockIdx.x * kThreads + threadIdx.x;
   int nb = ctr->nodes[hops + 1];
   if (nb > cap_nodes) nb = cap_nodes;
   const int eb = ctr->edges[hops];
   const int expanded = ctr->nodes[hops];  // nodes [0, expanded) were frontier nodes of some hop
-  if (i == 0) { counts[0] = nb; counts[1] = eb; }
+  if (i == 0) { counts[0] = nb; counts[1] = eb; counts[2] = expanded < nb ? expanded : nb; }
   if (i > cap_nodes) return;
   if (i >= expanded && i <= nb) b_rowptr[i] = eb;
   if (i < nb) local_of[n_id[i]] = kUnassigned;

@@ -125,7 +125,7 @@ class HipNeighborSampler:
     def sample(self, seeds: Tensor) -> Batch:
         from ..graph import GraphStructure
         self.calls += 1
-        n_id, rowptr, src, etype, coo, nb, eb = ops.sample_batch(self.rowptr, self.src, self.etype, self.num_nodes,
+        n_id, rowptr, src, etype, coo, nb, eb, ab = ops.sample_batch(self.rowptr, self.src, self.etype, self.num_nodes,
                                                                  seeds.contiguous(), self.fanouts, self.seed,
                                                                  self.calls * 64, self.local_of)
         n_id64 = n_id.long()
@@ -133,7 +133,7 @@ class HipNeighborSampler:
                   node_text_feat=self.ntf, edge_text_feat=self.etf)
         b.graph = GraphStructure.from_csr(rowptr, src, coo, nb, etype_slot=etype,
                                           max_in_degree=self.batch_max_in_degree,
-                                          max_out_degree=self.batch_max_out_degree)
+                                          max_out_degree=self.batch_max_out_degree, active_rows=ab)
         return b
 
 

@@ -9,6 +9,8 @@ distinct ``edge_index`` tensor.  A loader can hand batches over as GraphStructur
 """
 from __future__ import annotations
 
+import os
+
 from collections import OrderedDict
 from typing import Optional
 
@@ -70,6 +72,10 @@ class GraphStructure:
         # let the aggregation skip the heavy-row split passes (ops.SplitPlan) without a device sync.
         self.max_in_degree: Optional[int] = None
         self.max_out_degree: Optional[int] = None
+        # Rows >= active_rows are promised to have no in-edges (a neighbour-sampled batch: only the nodes that were
+        # expanded, which come first, receive edges).  The aggregation then computes -- and its consumers read --
+        # rows [0, active_rows) only.  None = no promise, every row is computed.
+        self.active_rows: Optional[int] = None
         self._plan_in = self._plan_out = None
         if edge_index is None:  # filled in by a factory (dropout_undirected)
             self.num_edges = 0
@@ -95,10 +101,15 @@ class GraphStructure:
     @classmethod
     def from_csr(cls, rowptr: Tensor, src: Tensor, edge_index: Tensor, num_nodes: int,
                  etype_slot: Optional[Tensor] = None, max_in_degree: Optional[int] = None,
-                 max_out_degree: Optional[int] = None) -> "GraphStructure":
+                 max_out_degree: Optional[int] = None, active_rows: Optional[int] = None,
+                 validate: bool = False) -> "GraphStructure":
         """Adopt a by-target CSR whose slot j IS edge j of `edge_index` (what the HIP sampler emits)."""
         g = cls(None, num_nodes)
         g.max_in_degree, g.max_out_degree = max_in_degree, max_out_degree
+        if active_rows is not None and 0 <= active_rows < num_nodes and not os.environ.get("STEMGNN_NO_ACTIVE_ROWS"):
+            if validate and int(rowptr[active_rows].item()) != int(rowptr[-1].item()):
+                raise RuntimeError("from_csr: rows >= active_rows must have no in-edges")
+            g.active_rows = int(active_rows)
         g.num_edges = int(src.numel())
         g._edge_index = edge_index
         g.rowptr, g.src = rowptr, src
@@ -183,6 +194,9 @@ class GraphStructure:
         (out.rowptr, out.src, out.eid, out.etype_slot, out.dst_t, out.eid_t, out.etype_slot_t,
          out.inv_deg) = ops.graph_dropout_undirected(self, p, seed, offset, keep)
         out.rowptr_t = out.rowptr  # the augmented graph is symmetric: identical degree sequence
+        # every kept edge has source id <= target id < active_rows (only row <= col survives, pretrain.py:42-44 /
+        # dropout_adj), so after mirroring both endpoints of every edge are still below active_rows
+        out.active_rows = self.active_rows
         if self.max_in_degree is not None and self.max_out_degree is not None:
             # a node keeps at most all of its in- and out-edges, each mirrored once
             out.max_in_degree = out.max_out_degree = self.max_in_degree + self.max_out_degree

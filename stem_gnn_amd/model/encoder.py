@@ -104,9 +104,11 @@ class MySAGEConv(nn.Module):
         also returns the BatchNorm column partials of the output (fused epilogue)."""
         agg = aggregate(x[0], edge_index, edge_attr)
         x_r = x[1]
+        # a sampled batch promises that only its leading rows receive edges: the product skips the zero part of agg
+        rows = getattr(edge_index, "active_rows", None) if isinstance(edge_index, GraphStructure) else None
         if self.root_weight and x_r is not None:
             out, partial = ops.LinearFn.apply(agg, self.lin_l.weight, x_r, self.lin_r.weight, self.lin_l.bias,
-                                              want_stats and not self.normalize)
+                                              want_stats and not self.normalize, -1 if rows is None else rows)
         else:
             out, partial = ops.LinearFn.apply(agg, self.lin_l.weight, None, None, self.lin_l.bias,
                                               want_stats and not self.normalize)

@@ -202,8 +202,8 @@ def sampler_init_map(num_nodes: int, device) -> Tensor:
 
 def sample_batch(rowptr: Tensor, src: Tensor, etype: Optional[Tensor], num_nodes: int, seeds: Tensor, fanouts,
                  seed: int, offset: int, local_of: Tensor):
-    """One neighbour-sampled mini-batch on the device -> (n_id, b_rowptr, b_src, b_type, coo, N_b, E_b).
-    One 8-byte device->host copy per batch (the two counts)."""
+    """One neighbour-sampled mini-batch on the device -> (n_id, b_rowptr, b_src, b_type, coo, N_b, E_b, A_b); A_b =
+    leading nodes that were expanded (rows >= A_b have no in-edges).  One 12-byte device->host copy per batch."""
     _req(seeds, torch.int64, "seeds", 1)
     B, L, dev = seeds.numel(), len(fanouts), seeds.device
     level, cap_nodes, cap_edges = B, B, 0
@@ -217,14 +217,14 @@ def sample_batch(rowptr: Tensor, src: Tensor, etype: Optional[Tensor], num_nodes
     b_src = torch.empty(cap_edges, **i32)
     b_type = torch.empty(cap_edges, **i32)
     coo = torch.empty(2, cap_edges, dtype=torch.int64, device=dev)
-    counts = torch.empty(2, **i32)
+    counts = torch.empty(3, **i32)
     ws = _workspace(lib.stemgnn_sampler_workspace_bytes(B, L, max(fanouts)), dev)
     fan = (ctypes.c_int32 * L)(*[int(f) for f in fanouts])
     check(lib.stemgnn_sample_batch(_p(rowptr), _p(src), _p(etype), num_nodes, _p(seeds), B, fan, L, seed, offset,
                                    _p(local_of), cap_nodes, cap_edges, _p(n_id), _p(b_rowptr), _p(b_src), _p(b_type),
                                    _p(coo), _p(counts), _p(ws), ws.numel(), _stream()), "sample_batch")
-    nb, eb = counts.tolist()
-    return n_id[:nb], b_rowptr[:nb + 1], b_src[:eb], b_type[:eb], coo[:, :eb].contiguous(), nb, eb
+    nb, eb, ab = counts.tolist()
+    return n_id[:nb], b_rowptr[:nb + 1], b_src[:eb], b_type[:eb], coo[:, :eb].contiguous(), nb, eb, ab
 
 
 def inv_degree(rowptr: Tensor) -> Tensor:
@@ -505,8 +505,9 @@ def linear_set_mode(mode: int) -> int:
 
 
 def linear_fwd(x1: Tensor, w1: Tensor, x2: Optional[Tensor], w2: Optional[Tensor], bias: Optional[Tensor],
-               want_stats: bool = False):
-    """y = x1 w1^T (+ x2 w2^T) + bias; optionally the per-row-block column partials of y."""
+               want_stats: bool = False, x1_rows: int = -1):
+    """y = x1 w1^T (+ x2 w2^T) + bias; optionally the per-row-block column partials of y.  ``x1_rows`` >= 0
+    promises that rows >= x1_rows of x1 are zero (row tiles past them skip x1's half of the contraction)."""
     _req(x1, torch.float32, "x1", 2)
     _req(w1, torch.float32, "w1", 2)
     M, K1 = x1.shape
@@ -528,7 +529,7 @@ def linear_fwd(x1: Tensor, w1: Tensor, x2: Optional[Tensor], w2: Optional[Tensor
     if want_stats:
         partial = torch.empty(max(blocks, 1), 2, N, dtype=torch.float32, device=x1.device)
     check(lib.stemgnn_linear_fwd(_p(x1), _p(w1), K1, _p(x2), _p(w2), K2, _p(bias), M, N, _p(y), _p(partial), None,
-                                 _stream()), "linear_fwd")
+                                 int(x1_rows), _stream()), "linear_fwd")
     return y, partial, blocks
 
 
@@ -565,17 +566,26 @@ def transpose(w: Tensor) -> Tensor:
 
 class LinearFn(torch.autograd.Function):
     """y = x1 w1^T (+ x2 w2^T) + b on the matrix cores (fp32 result, csrc/linear.hip); returns (y, column partials or None).
-    Replaces nn.Linear / lin_l + lin_r (reference model/encoder.py:83-87, model/vq.py:881,1041)."""
+    Replaces nn.Linear / lin_l + lin_r (reference model/encoder.py:83-87, model/vq.py:881,1041).
+
+    ``x1_rows`` (>= 0): rows >= x1_rows of x1 are zero by construction (the aggregate of a sampled batch).  The forward
+    skips x1's half of the contraction past them; the backward computes x1's gradient for rows < x1_rows only (the
+    rest of the returned buffer is NOT written: its only consumer, the aggregation backward, never reads it) and
+    contracts w1's gradient over those rows only."""
 
     @staticmethod
-    def forward(ctx, x1, w1, x2, w2, bias, want_stats):
+    def forward(ctx, x1, w1, x2, w2, bias, want_stats, x1_rows=-1):
         x1 = x1.contiguous()
         w1c = w1.contiguous()
         x2c = None if x2 is None else x2.contiguous()
         w2c = None if w2 is None else w2.contiguous()
-        y, partial, blocks = linear_fwd(x1, w1c, x2c, w2c, bias, want_stats)
+        rows = int(x1_rows)
+        if rows < 0 or rows >= x1.size(0) or x2c is None:
+            rows = -1  # without a second operand every row still needs its bias: no saving, keep the plain path
+        y, partial, blocks = linear_fwd(x1, w1c, x2c, w2c, bias, want_stats, rows)
         ctx.save_for_backward(x1, w1c, x2c, w2c)
         ctx.has_bias = bias is not None
+        ctx.x1_rows = rows
         if partial is not None:
             ctx.mark_non_differentiable(partial)
         return y, partial
@@ -585,11 +595,25 @@ class LinearFn(torch.autograd.Function):
         x1, w1, x2, w2 = ctx.saved_tensors
         gy = gy.contiguous()
         need = ctx.needs_input_grad
+        rows = ctx.x1_rows
         gx1 = gw1 = gx2 = gw2 = gb = None
-        if need[0]:
-            gx1 = linear_bwd_data(gy, w1)
-        if need[1]:
-            gw1, gb = linear_bwd_weight(gy, x1, ctx.has_bias and need[4])
+        if rows >= 0:
+            gy1, x1p = gy[:rows], x1[:rows]  # leading rows: contiguous views
+            if need[0]:
+                gx1 = torch.empty_like(x1)
+                if rows > 0:
+                    check(lib.stemgnn_linear_bwd_data(_p(gy1), _p(w1), rows, gy.size(1), w1.size(1), _p(gx1), _stream()),
+                          "linear_bwd_data")
+            if need[1]:
+                if rows > 0:
+                    gw1, _ = linear_bwd_weight(gy1, x1p, False)
+                else:
+                    gw1 = torch.zeros_like(w1)
+        else:
+            if need[0]:
+                gx1 = linear_bwd_data(gy, w1)
+            if need[1]:
+                gw1, gb = linear_bwd_weight(gy, x1, ctx.has_bias and need[4])
         if x2 is not None:
             if need[2]:
                 gx2 = linear_bwd_data(gy, w2)
@@ -598,7 +622,7 @@ class LinearFn(torch.autograd.Function):
                 gb = gb if gb is not None else gb2
         if ctx.has_bias and need[4] and gb is None:
             gb = gy.sum(dim=0)
-        return gx1, gw1, gx2, gw2, gb, None
+        return gx1, gw1, gx2, gw2, gb, None, None
 
 
 class MatmulFn(torch.autograd.Function):

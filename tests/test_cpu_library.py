@@ -40,7 +40,7 @@ def test_host_side_argument_validation_needs_no_gpu(L):
                                  None) == -2
     assert lib.stemgnn_vq_assign_fwd(None, 10, 4, 130, None, 128, 1, None, None, None, None, ctypes.c_void_p(8), 1.0,
                                      None, 0, None) == -1
-    assert lib.stemgnn_linear_fwd(None, None, 126, None, None, 0, None, 10, 128, None, None, None, None) == -1
+    assert lib.stemgnn_linear_fwd(None, None, 126, None, None, 0, None, 10, 128, None, None, None, -1, None) == -1
     assert lib.stemgnn_bn_act_drop_fwd(None, 10, 128, None, None, None, None, 2, 0.0, 0.0, 0, 0, None, None) == -1
     with pytest.raises(L.StemGnnLibraryError):
         L.check(-1, "probe")

@@ -708,3 +708,30 @@ def test_csr_round_trip_properties_hypothesis(dev):
         torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-5)
 
     check()
+
+
+@pytest.mark.parametrize("m,rows,k1,k2,n", [(1000, 130, 128, 128, 128), (1000, 0, 64, 32, 96), (777, 776, 32, 64, 64),
+                                            (4100, 129, 128, 128, 512), (300, 300, 32, 32, 32)])
+def test_linear_with_zero_tail_promise(dev, m, rows, k1, k2, n):
+    """x1_rows: rows >= x1_rows of the first operand are zero (aggregate of a sampled batch).  Same y / statistics as
+    the plain call; gradients of x1 for the promised-non-zero rows, of w1 contracted over those rows, of x2 / w2 /
+    bias over all rows -- against torch on the zero-padded operand."""
+    from stem_gnn_amd import ops
+    torch.manual_seed(m + rows)
+    x1 = torch.randn(m, k1)
+    x1[rows:] = 0
+    x2, w1, w2, b = torch.randn(m, k2), torch.randn(n, k1) / 8, torch.randn(n, k2) / 8, torch.randn(n)
+    g = torch.randn(m, n)
+    ref = [t.clone().requires_grad_(True) for t in (x1, w1, x2, w2, b)]
+    yr = ref[0] @ ref[1].t() + ref[2] @ ref[3].t() + ref[4]
+    (yr * g).sum().backward()
+    gp = [t.to(dev).requires_grad_(True) for t in (x1, w1, x2, w2, b)]
+    y, partial = ops.LinearFn.apply(gp[0], gp[1], gp[2], gp[3], gp[4], True, rows)
+    y0, partial0 = ops.LinearFn.apply(gp[0].detach(), gp[1].detach(), gp[2].detach(), gp[3].detach(), gp[4].detach(), True)
+    assert torch.equal(y, y0) or float((y - y0).abs().max()) < 1e-6   # skipped chunks only ever added exact zeros
+    torch.testing.assert_close(partial.sum(0), partial0.sum(0), rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(y.detach().cpu(), yr.detach(), rtol=1e-4, atol=1e-4)
+    (y * g.to(dev)).sum().backward()
+    torch.testing.assert_close(gp[0].grad[:rows].cpu(), ref[0].grad[:rows], rtol=1e-4, atol=1e-4)
+    for i in (1, 2, 3, 4):
+        torch.testing.assert_close(gp[i].grad.cpu(), ref[i].grad, rtol=1e-4, atol=2e-3 if i in (1, 3) else 1e-3)
