@@ -8,10 +8,20 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 constexpr int kBlock = 256, kBM = 128, kBN = 128, kKC = 32;
 __device__ inline float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
+#ifdef GLDS_ASM
+// issued through inline asm so that the compiler's waitcnt pass does not know the LDS is written asynchronously
+// (with the builtin it puts s_waitcnt vmcnt(0) in front of the first ds_read after it, which serialises the prefetch)
+__device__ inline void glds16(const float* g, float* l) {
+  const uint32_t lds_addr = __builtin_amdgcn_readfirstlane(
+      static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) void*)l)));
+  asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_addr), "v"(g) : "memory", "m0");
+}
+#else
 __device__ inline void glds16(const float* g, float* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
+#endif
 
 template <int OCC>
 __global__ void __launch_bounds__(kBlock, OCC)
