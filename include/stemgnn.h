@@ -392,6 +392,11 @@ int stemgnn_edge_concat_bwd(const float* g_out, int64_t num_nodes, int64_t dim, 
  * moved to the device).  index int64, rows fp32. */
 int stemgnn_gather_rows(const float* table, int64_t num_table_rows, int64_t dim, const int64_t* index,
                         int64_t n, float* out, void* stream);
+/* The same, counting the indices outside [0, num_table_rows) into bad_count [1] (device int32, zeroed by the call):
+ * the reference's node_text_feat[data.x] (pretrain.py:33) raises IndexError for them; out-of-range rows are
+ * written as zeros here and the caller raises when bad_count != 0. */
+int stemgnn_gather_rows_checked(const float* table, int64_t num_table_rows, int64_t dim, const int64_t* index,
+                                int64_t n, float* out, int32_t* bad_count, void* stream);
 
 /* K14: teacher EMA (model/pt_model.py:104-106) on flat parameter buffers, in place:
  *   teacher = teacher * decay + student * (1 - decay). */

@@ -104,6 +104,7 @@ _SIGNATURES = {
     "stemgnn_edge_concat_fwd": (c_int, [P, I64, I64, P, I64, P, P]),
     "stemgnn_edge_concat_bwd": (c_int, [P, I64, I64, P, I64, P, P]),
     "stemgnn_gather_rows": (c_int, [P, I64, I64, P, I64, P, P]),
+    "stemgnn_gather_rows_checked": (c_int, [P, I64, I64, P, I64, P, P, P]),
     "stemgnn_ema_lerp": (c_int, [P, P, I64, c_float, P]),
 }
 

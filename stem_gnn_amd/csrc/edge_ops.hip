@@ -107,12 +107,13 @@ k_edge_concat_bwd(const float* __restrict__ g_out, int64_t N, int D, const int64
 template <int G>
 __global__ void __launch_bounds__(kBlock)
 k_gather_rows(const float* __restrict__ table, int64_t R, int D, const int64_t* __restrict__ index, int64_t n,
-              float* __restrict__ out) {
+              float* __restrict__ out, int32_t* __restrict__ bad_count) {
   const int lane = threadIdx.x % G;
   const int64_t i = static_cast<int64_t>(blockIdx.x) * (kBlock / G) + threadIdx.x / G;
   if (i >= n) return;
   const int64_t r = index[i];
   const bool ok = r >= 0 && r < R;
+  if (!ok && bad_count != nullptr && lane == 0) atomicAdd(bad_count, 1);  // the reference's indexing raises here
   const int nvec = D / 4;
   for (int c = lane; c < nvec; c += G)
     st4(out + i * D + 4 * c, ok ? ld4(table + r * D + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f));
@@ -252,7 +253,19 @@ int stemgnn_gather_rows(const float* table, int64_t R, int64_t D, const int64_t*
   if (R < 0 || n < 0 || !dim_ok(D)) return STEMGNN_ERR_INVALID_ARG;
   if (n == 0) return STEMGNN_OK;
   if (!table || !index || !out) return STEMGNN_ERR_INVALID_ARG;
-  STEMGNN_EDGE_DISPATCH(k_gather_rows, n, table, R, static_cast<int>(D), index, n, out);
+  STEMGNN_EDGE_DISPATCH(k_gather_rows, n, table, R, static_cast<int>(D), index, n, out,
+                        static_cast<int32_t*>(nullptr));
+  return STEMGNN_OK;
+}
+
+int stemgnn_gather_rows_checked(const float* table, int64_t R, int64_t D, const int64_t* index, int64_t n, float* out,
+                                int32_t* bad_count, void* stream_) {
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  if (R < 0 || n < 0 || !dim_ok(D) || !bad_count) return STEMGNN_ERR_INVALID_ARG;
+  STEMGNN_HIP_TRY(hipMemsetAsync(bad_count, 0, sizeof(int32_t), st));
+  if (n == 0) return STEMGNN_OK;
+  if (!table || !index || !out) return STEMGNN_ERR_INVALID_ARG;
+  STEMGNN_EDGE_DISPATCH(k_gather_rows, n, table, R, static_cast<int>(D), index, n, out, bad_count);
   return STEMGNN_OK;
 }
 

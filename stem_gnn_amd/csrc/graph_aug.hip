@@ -111,7 +111,8 @@ k_negative_sample(const int32_t* __restrict__ rowptr, const int32_t* __restrict_
   int64_t r = 0, c = 1 % N;
   for (int attempt = 0; attempt < 64; ++attempt) {
     uint32_t u[4];
-    Philox::gen(seed, offset + static_cast<uint64_t>(attempt), static_cast<uint64_t>(i), u);
+    // retries live in the counter block's high bits, not in the key: (seed, offset + 1) belongs to the next op
+    Philox::gen(seed, offset, (static_cast<uint64_t>(attempt) << 40) | static_cast<uint64_t>(i), u);
     const uint64_t x = (static_cast<uint64_t>(u[0]) << 32 | u[1]) % population;
     r = static_cast<int64_t>(x / static_cast<uint64_t>(N - 1));
     c = static_cast<int64_t>(x % static_cast<uint64_t>(N - 1));

@@ -68,10 +68,12 @@ struct SplitArgs {
   int skip_above;
   int fill;
   int items;
+  int cap_items;        // capacities of the plan buffers: appends past them are dropped, never written
+  int cap_heavy;
 };
 
 inline SplitArgs no_split() {
-  return SplitArgs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0x7fffffff, 0, 0};
+  return SplitArgs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0x7fffffff, 0, 0, 0, 0};
 }
 
 template <int G>
@@ -81,11 +83,19 @@ __device__ __forceinline__ void plan_append(const SplitArgs& sp, int row, int be
   if (lane == 0) {
     i0 = atomicAdd(sp.counts, n);
     h = atomicAdd(sp.counts + 1, 1);
-    sp.heavy_row[h] = row;
-    sp.heavy_span[2 * h] = i0;
-    sp.heavy_span[2 * h + 1] = n;
+    // The host sizes the plan so that this cannot overflow when E bounds the CSR's live edges (plan_ok); a caller
+    // that under-states E gets dropped items (counts[0] / counts[1] then exceed the capacities, which the owner of
+    // the plan can read back), never an out-of-bounds write.
+    const bool fits = h < sp.cap_heavy && i0 + n <= sp.cap_items;
+    if (h < sp.cap_heavy) {
+      sp.heavy_row[h] = row;
+      sp.heavy_span[2 * h] = fits ? i0 : 0;
+      sp.heavy_span[2 * h + 1] = fits ? n : 0;
+    }
+    if (!fits) i0 = -1;
   }
   i0 = __shfl(i0, 0, G);
+  if (i0 < 0) return;
   for (int c = lane; c < n; c += G) {
     sp.item_row[i0 + c] = row;
     sp.item_beg[i0 + c] = beg + c * sp.chunk;
@@ -122,7 +132,7 @@ k_sage_agg_fwd(const float* __restrict__ x, int64_t N, int D, const int32_t* __r
     out[i] = nullptr;
     inv[i] = 1.0f;
     if (sp.items) {  // ITEM mode: one chunk of a heavy row -> unscaled partial row
-      live[i] = unit < sp.counts[0];
+      live[i] = unit < min(sp.counts[0], sp.cap_items);
       if (live[i]) {
         const int r = sp.item_row[unit];
         beg[i] = sp.item_beg[unit];
@@ -295,7 +305,7 @@ k_sage_agg_bwd(const float* __restrict__ g_agg, const float* __restrict__ x, int
   float* out = nullptr;
   bool live;
   if (sp.items) {  // ITEM mode (see SplitArgs)
-    live = unit < sp.counts[0];
+    live = unit < min(sp.counts[0], sp.cap_items);
     if (live) {
       row = sp.item_row[unit];
       beg = sp.item_beg[unit];
@@ -535,6 +545,8 @@ inline SplitArgs split_args(const SplitPlan* plan, int pass) {
   sp.item_row = plan->item_row; sp.item_beg = plan->item_beg; sp.heavy_row = plan->heavy_row;
   sp.heavy_span = plan->heavy_span; sp.counts = plan->counts; sp.partial = plan->partial;
   sp.chunk = plan->chunk;
+  sp.cap_items = static_cast<int>(plan->cap_items);
+  sp.cap_heavy = static_cast<int>(plan->cap_heavy);
   if (pass == 0) { sp.skip_above = plan->heavy_above; sp.fill = plan->build; }
   else sp.items = 1;
   return sp;

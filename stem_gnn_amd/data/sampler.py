@@ -5,9 +5,8 @@ draws up to ``fanout`` of its in-neighbours uniformly WITHOUT replacement; the s
 every sampled edge (neighbour -> node); local numbering puts the seeds first, then nodes in
 hop order; ``batch_size`` = number of seeds.
 
-Round-1 implementation: device-side index arithmetic with torch ops over a CSC built by the
-HIP graph builder (int32, resident on the GPU).  It sits OUTSIDE the measured step (batches are
-pre-sampled into HBM); SURVEY.md §8f rank 1 replaces it with a fused HIP sampler.
+``HipNeighborSampler`` is the fused device sampler (csrc/sampler.hip); a torch-op restatement of the same
+contract lives in tests/torch_sampler.py as a test aid.
 """
 from __future__ import annotations
 
@@ -29,71 +28,6 @@ class Batch:
     xe: Tensor                # int64 [Eb] edge-type ids
     node_text_feat: Tensor
     edge_text_feat: Tensor
-
-
-class NeighborSampler:
-    def __init__(self, edge_index: Tensor, xe: Tensor, num_nodes: int, x: Tensor, node_text_feat: Tensor,
-                 edge_text_feat: Tensor, num_neighbors: List[int], seed: int = 0):
-        dev = edge_index.device
-        self.num_nodes = num_nodes
-        self.fanouts = list(num_neighbors)
-        rowptr, src, eid, _ = ops.csr_build(edge_index.contiguous(), num_nodes, 1)  # in-neighbour lists
-        self.rowptr = rowptr.long()
-        self.src = src
-        self.xe_csc = xe.to(torch.int32)[eid.long()].contiguous()
-        self.x, self.ntf, self.etf = x, node_text_feat, edge_text_feat
-        self.gen = torch.Generator(device=dev).manual_seed(seed)
-        self._local = torch.full((num_nodes,), -1, dtype=torch.int64, device=dev)  # global -> local scratch
-
-    def _sample_hop(self, frontier: Tensor, fanout: int):
-        """-> (dst_global [M], src_global [M], etype [M]) for the sampled in-edges of `frontier`."""
-        dev = frontier.device
-        start = self.rowptr[frontier]
-        deg = self.rowptr[frontier + 1] - start
-        total = int(deg.sum().item())
-        if total == 0:
-            e = torch.empty(0, dtype=torch.int64, device=dev)
-            return e, e, e
-        seg = torch.repeat_interleave(torch.arange(frontier.numel(), device=dev), deg)
-        seg_start = torch.cumsum(deg, 0) - deg
-        within = torch.arange(total, device=dev) - seg_start[seg]
-        slot = start[seg] + within
-        if fanout >= 0:
-            key = torch.rand(total, generator=self.gen, device=dev, dtype=torch.float64)
-            order = torch.argsort(seg.double() + key)  # random order inside each segment
-            rank = torch.arange(total, device=dev) - seg_start[seg[order]]
-            pick = order[rank < fanout]
-            pick, _ = torch.sort(pick)  # keep CSC order among the chosen edges
-            seg, slot = seg[pick], slot[pick]
-        return frontier[seg], self.src[slot].long(), self.xe_csc[slot].long()
-
-    def sample(self, seeds: Tensor) -> Batch:
-        dev = seeds.device
-        local = self._local
-        nodes = [seeds]
-        local[seeds] = torch.arange(seeds.numel(), device=dev)
-        count = seeds.numel()
-        frontier = seeds
-        srcs, dsts, ets = [], [], []
-        for fanout in self.fanouts:
-            d, s, t = self._sample_hop(frontier, fanout)
-            srcs.append(s); dsts.append(d); ets.append(t)
-            new = torch.unique(s[local[s] < 0]) if s.numel() else s
-            if new.numel():
-                local[new] = torch.arange(count, count + new.numel(), device=dev)
-                count += new.numel()
-                nodes.append(new)
-            frontier = new
-            if frontier.numel() == 0:
-                break
-        n_id = torch.cat(nodes)
-        src = torch.cat(srcs) if srcs else seeds.new_empty(0)
-        dst = torch.cat(dsts) if dsts else seeds.new_empty(0)
-        et = torch.cat(ets) if ets else seeds.new_empty(0)
-        edge_index = torch.stack([local[src], local[dst]], dim=0).contiguous()
-        local[n_id] = -1  # reset the scratch map
-        return Batch(batch_size=seeds.numel(), n_id=n_id, x=self.x[n_id], edge_index=edge_index, xe=et,
-                     node_text_feat=self.ntf, edge_text_feat=self.etf)
 
 
 class HipNeighborSampler:
@@ -140,7 +74,7 @@ class HipNeighborSampler:
 class NeighborLoader:
     """Iterates shuffled seed batches (one epoch), sharded round-robin across ranks."""
 
-    def __init__(self, sampler: NeighborSampler, input_nodes: Tensor, batch_size: int, shuffle: bool = True,
+    def __init__(self, sampler, input_nodes: Tensor, batch_size: int, shuffle: bool = True,
                  rank: int = 0, world_size: int = 1, seed: int = 0):
         self.sampler, self.batch_size = sampler, batch_size
         nodes = input_nodes

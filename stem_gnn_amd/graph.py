@@ -28,6 +28,7 @@ def set_validation(flag: bool) -> None:
     validation on they raise IndexError like an out-of-range index would in the reference."""
     global _VALIDATE
     _VALIDATE = bool(flag)
+    ops.set_gather_validation(flag)  # the feature-row lookups follow the same policy
 
 
 class EdgeTypeAttr:
@@ -77,6 +78,9 @@ class GraphStructure:
         # rows [0, active_rows) only.  None = no promise, every row is computed.
         self.active_rows: Optional[int] = None
         self._plan_in = self._plan_out = None
+        # CSR slots the structure may hold (>= its live edge count): num_edges, except for an augmented graph, whose
+        # arrays hold up to two slots (edge + mirror) per original edge.  Sizes the heavy-row split plan.
+        self.slot_capacity = 0
         if edge_index is None:  # filled in by a factory (dropout_undirected)
             self.num_edges = 0
             self.rowptr = self.src = self.eid = self._bad = None
@@ -84,7 +88,7 @@ class GraphStructure:
         if edge_index.dim() != 2 or edge_index.size(0) != 2:
             raise RuntimeError(f"edge_index: expected shape [2, E], got {tuple(edge_index.shape)}")
         self._edge_index = edge_index.contiguous()
-        self.num_edges = int(edge_index.size(1))
+        self.num_edges = self.slot_capacity = int(edge_index.size(1))
         self.rowptr, self.src, self.eid, self._bad = ops.csr_build(self._edge_index, self.num_nodes, 1)
         if edge_type is not None:
             self.set_edge_type(edge_type)
@@ -110,7 +114,7 @@ class GraphStructure:
             if validate and int(rowptr[active_rows].item()) != int(rowptr[-1].item()):
                 raise RuntimeError("from_csr: rows >= active_rows must have no in-edges")
             g.active_rows = int(active_rows)
-        g.num_edges = int(src.numel())
+        g.num_edges = g.slot_capacity = int(src.numel())
         g._edge_index = edge_index
         g.rowptr, g.src = rowptr, src
         g.eid = torch.arange(g.num_edges, dtype=torch.int32, device=src.device)
@@ -168,7 +172,7 @@ class GraphStructure:
             side = "in"
         attr = "_plan_in" if side == "in" else "_plan_out"
         if getattr(self, attr) is None:
-            setattr(self, attr, ops.SplitPlan(self.num_edges, self.rowptr.device))
+            setattr(self, attr, ops.SplitPlan(self.slot_capacity, self.rowptr.device))
         return getattr(self, attr)
 
     def record_stream(self, stream) -> None:
@@ -189,6 +193,7 @@ class GraphStructure:
         self.ensure_transpose()
         out = GraphStructure(None, self.num_nodes)
         out.num_edges = self.num_edges
+        out.slot_capacity = max(2 * self.num_edges, 1)  # every kept edge is mirrored: up to 2E live slots
         seed, offset = (0, 0) if keep is not None else ops.next_dropout_key()
         out.keep_key = (seed, offset)
         (out.rowptr, out.src, out.eid, out.etype_slot, out.dst_t, out.eid_t, out.etype_slot_t,

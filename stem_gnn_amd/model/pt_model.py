@@ -243,7 +243,7 @@ class PretrainModel(nn.Module):
                 k = max(int(full_ei.size(1) * topo_recon_ratio), 1)
                 perm, sem_ei, sel_type, _ = ops.sample_edges(full_ei.contiguous(), orig_edge_attr.etype, k)
                 self.last_draws["topo_sem_perm"] = perm
-                target = ops.gather_rows(orig_edge_attr.table, sel_type)
+                target = ops.gather_rows(orig_edge_attr.table, sel_type, validate=False)  # ids the graph build already saw
             else:
                 perm = self._sample_edges(full_ei.size(1), topo_recon_ratio, z.device, "topo_sem_perm", draws)
                 sem_ei = full_ei[:, perm]

@@ -297,7 +297,7 @@ def sage_agg_fwd(x: Tensor, graph, edge_attr: Optional[Tensor], etab: Optional[T
         check(lib.stemgnn_sage_agg_fwd(_p(x), N, D, _p(graph.rowptr), _p(graph.src), _p(graph.eid), _p(edge_attr),
                                        _p(etab), _p(etype_slot), T, _p(agg), _stream()), "sage_agg_fwd")
     else:
-        check(lib.stemgnn_sage_agg_fwd_split(_p(x), N, D, graph.num_edges, _p(graph.rowptr), _p(graph.src),
+        check(lib.stemgnn_sage_agg_fwd_split(_p(x), N, D, graph.slot_capacity, _p(graph.rowptr), _p(graph.src),
                                              _p(graph.eid), _p(edge_attr), _p(etab), _p(etype_slot), T, _p(agg), 1,
                                              *plan.args(D, x.device), _stream()), "sage_agg_fwd_split")
     if k1_timer.enabled:
@@ -321,7 +321,7 @@ def sage_agg_bwd(g_agg: Tensor, x: Tensor, graph, edge_attr: Optional[Tensor], e
                                        _p(graph.inv_deg), _p(edge_attr), _p(etab), _p(ets), T, _p(g_x), _stream()),
               "sage_agg_bwd")
     else:
-        check(lib.stemgnn_sage_agg_bwd_split(_p(g_agg), _p(x), N, D, graph.num_edges, _p(graph.rowptr_t),
+        check(lib.stemgnn_sage_agg_bwd_split(_p(g_agg), _p(x), N, D, graph.slot_capacity, _p(graph.rowptr_t),
                                              _p(graph.dst_t), _p(graph.eid_t), _p(graph.inv_deg), _p(edge_attr),
                                              _p(etab), _p(ets), T, _p(g_x), 1, *plan.args(D, x.device), _stream()),
               "sage_agg_bwd_split")
@@ -337,6 +337,7 @@ class SplitPlan:
     The first aggregation call over the CSR fills it on the device; later calls reuse it."""
 
     def __init__(self, num_edges: int, device):
+        """``num_edges``: an upper bound of the CSR's LIVE slots (GraphStructure.slot_capacity)."""
         self.chunk, self.heavy = SPLIT_CHUNK, max(SPLIT_HEAVY, SPLIT_CHUNK)
         self.cap_items = 2 * (num_edges // self.chunk) + 2
         self.cap_heavy = num_edges // self.chunk + 1
@@ -393,7 +394,7 @@ class MeanAggFn(torch.autograd.Function):
             check(lib.stemgnn_mean_agg_fwd(_p(x), N, D, _p(graph.rowptr), _p(graph.src), _p(agg), _stream()),
                   "mean_agg_fwd")
         else:
-            check(lib.stemgnn_sage_agg_fwd_split(_p(x), N, D, graph.num_edges, _p(graph.rowptr), _p(graph.src), None,
+            check(lib.stemgnn_sage_agg_fwd_split(_p(x), N, D, graph.slot_capacity, _p(graph.rowptr), _p(graph.src), None,
                                                  None, None, None, 0, _p(agg), 0, *plan.args(D, x.device), _stream()),
                   "mean_agg_fwd_split")
         ctx.graph = graph
@@ -411,7 +412,7 @@ class MeanAggFn(torch.autograd.Function):
             check(lib.stemgnn_mean_agg_bwd(_p(g_agg), N, D, _p(g.rowptr_t), _p(g.dst_t), _p(g.inv_deg), _p(g_x),
                                            _stream()), "mean_agg_bwd")
         else:
-            check(lib.stemgnn_sage_agg_bwd_split(_p(g_agg), None, N, D, g.num_edges, _p(g.rowptr_t), _p(g.dst_t), None,
+            check(lib.stemgnn_sage_agg_bwd_split(_p(g_agg), None, N, D, g.slot_capacity, _p(g.rowptr_t), _p(g.dst_t), None,
                                                  _p(g.inv_deg), None, None, None, 0, _p(g_x), 0,
                                                  *plan.args(D, g_agg.device), _stream()), "mean_agg_bwd_split")
         return g_x, None
@@ -1048,11 +1049,31 @@ class FusedAdamW(torch.optim.Optimizer):
         return loss
 
 
-def gather_rows(table: Tensor, index: Tensor) -> Tensor:
-    """out[i] = table[index[i]] (device-side node_text_feat[x] of reference pretrain.py:33-38)."""
+_validate_gather = True
+
+
+def set_gather_validation(flag: bool) -> None:
+    """Check every ``gather_rows`` index against the table (one device->host read per call) and raise IndexError
+    like the reference's ``node_text_feat[data.x]`` does.  ``graph.set_validation`` switches this together with the
+    edge_index range check; a loader that produces its own indices turns both off."""
+    global _validate_gather
+    _validate_gather = bool(flag)
+
+
+def gather_rows(table: Tensor, index: Tensor, validate: Optional[bool] = None) -> Tensor:
+    """out[i] = table[index[i]] (device-side node_text_feat[x] of reference pretrain.py:33-38).  Out-of-range
+    indices raise IndexError when validation is on (the default); with validation off their rows read as zeros."""
     _req(table, torch.float32, "table", 2)
     _req(index, torch.int64, "index", 1)
     out = torch.empty(index.numel(), table.size(1), dtype=torch.float32, device=table.device)
+    if _validate_gather if validate is None else validate:
+        bad = torch.empty(1, dtype=torch.int32, device=table.device)
+        check(lib.stemgnn_gather_rows_checked(_p(table), table.size(0), table.size(1), _p(index), index.numel(), _p(out),
+                                              _p(bad), _stream()), "gather_rows")
+        n_bad = int(bad.item())
+        if n_bad:
+            raise IndexError(f"gather_rows: {n_bad} of {index.numel()} indices lie outside [0, {table.size(0)})")
+        return out
     check(lib.stemgnn_gather_rows(_p(table), table.size(0), table.size(1), _p(index), index.numel(), _p(out), _stream()),
           "gather_rows")
     return out

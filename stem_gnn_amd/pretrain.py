@@ -176,6 +176,18 @@ def pretrain_step(model: PretrainModel, optimizer, scheduler, params: Dict, x, e
     return loss.detach(), {k: v.detach() for k, v in losses.items()}, out_draws
 
 
+def batch_features(data, device) -> torch.Tensor:
+    """The batch's node feature rows, by the reference's rule (pretrain.py:30-35): ``node_text_feat[data.x]`` when
+    ``data.x`` and ``data.node_text_feat`` have different row counts (x = row ids into a shared table, what
+    HipNeighborSampler emits), ``node_text_feat`` itself when they match (features already sliced per batch node,
+    what PyG's NeighborLoader emits for a node-level attribute).  The lookup runs on the device and, with
+    validation on, raises IndexError for an out-of-range id like the reference's indexing does."""
+    ntf = data.node_text_feat.to(device)
+    if data.x.size(0) != ntf.size(0):
+        return ops.gather_rows(ntf, data.x.to(device).long().contiguous())
+    return ntf
+
+
 def pretrain(model, loader, optimizer, params, scheduler=None, no_codebook=False, log_fn=None, grad_sync=None):
     """reference pretrain.py:25-79.  ``loader`` yields batches with attributes
     ``batch_size``, ``x`` (node ids into ``node_text_feat``) or features, ``edge_index``, ``xe``,
@@ -201,11 +213,7 @@ def _pretrain_epoch(model, loader, optimizer, params, scheduler, no_codebook, lo
     last = None
     for data in loader:
         bs = data.batch_size
-        ntf = data.node_text_feat.to(device)
-        if data.x.size(0) != ntf.size(0) or data.x.dtype == torch.int64:
-            x = ops.gather_rows(ntf, data.x.to(device).long().contiguous())  # node_text_feat[data.x]
-        else:
-            x = ntf
+        x = batch_features(data, device)
         graph = getattr(data, "graph", None)  # the HIP sampler hands the batch's CSR over ready-made
         edge_index = graph if graph is not None else data.edge_index.to(device)
         edge_attr = EdgeTypeAttr(data.edge_text_feat.to(device), data.xe.to(device))  # edge_text_feat[xe], lazily

@@ -16,7 +16,9 @@ def seed_everything(seed: int) -> None:
     torch.manual_seed(seed)
     if torch.cuda.is_available():
         torch.cuda.manual_seed_all(seed)
-    ops.manual_seed(seed)
+    # the device-side draws (dropout, edge dropout, edge / negative samples) must differ between data-parallel
+    # ranks that are seeded alike: the rank goes into the high half of the Philox key
+    ops.manual_seed((int(seed) & 0xFFFFFFFF) | (int(os.environ.get("RANK", "0")) << 32))
 
 
 class CosineLambdaLR:

@@ -26,12 +26,14 @@ def test_accuracy_and_auc_definitions():
 
 
 def test_pooling_and_multitask_loss():
-    from stem_gnn_amd.model.ft_model import _pool, compute_multitask_loss
+    from stem_gnn_amd.model.ft_model import _segment_pool, compute_multitask_loss
     torch.manual_seed(1)
     z = torch.randn(50, 6)
     batch = torch.sort(torch.randint(0, 7, (50,))).values
+    batch[-1] = 6  # the pooled size is batch.max() + 1, as in PyG
     for how, ref in (("sum", lambda r: r.sum(0)), ("mean", lambda r: r.mean(0)), ("max", lambda r: r.max(0).values)):
-        out = _pool(z, batch, how, size=7)
+        out = _segment_pool(z, batch, how)
+        assert out.shape == (7, 6)
         for g in range(7):
             rows = z[batch == g]
             if rows.numel():
@@ -43,6 +45,14 @@ def test_pooling_and_multitask_loss():
     torch.testing.assert_close(a, b)
     # definition: mean BCE-with-logits over all entries (none missing here)
     torch.testing.assert_close(a.double(), nn.functional.binary_cross_entropy_with_logits(pred.double(), y.double()))
+    # missing labels (NaN) are left out of the sum and of the count, and 0 is relabelled -1 in place
+    y2 = y.clone()
+    y2[::3, 1] = float("nan")
+    y_arg = y2.clone()
+    a2 = compute_multitask_loss(pred, y_arg)
+    b2 = O.compute_multitask_loss(pred, y2.clone())
+    torch.testing.assert_close(a2, b2)
+    assert bool(((y_arg == -1) == (y2 == 0)).all())
 
 
 def test_checkpoint_helpers(tmp_path):

@@ -235,6 +235,50 @@ def test_heavy_row_split_on_augmented_graph_and_plain_mean(dev):
     torch.testing.assert_close(xm.grad.cpu(), xr.grad, rtol=1e-4, atol=1e-4 * xr.grad.abs().max().item())
 
 
+def test_split_plan_capacity_on_one_directional_graph(dev):
+    """Every edge points to a higher id, 65 out + 65 in per interior node: dropout_undirected keeps every src <= dst
+    edge that survives the draw and mirrors it, so the augmented CSR holds up to 2E live slots with degrees of ~130 --
+    just above SPLIT_HEAVY, where the number of chunk items per edge is largest (3 items per 130 edges).  The plan
+    must be sized from the 2E slot capacity (ops.SplitPlan over GraphStructure.slot_capacity), not from the
+    attribute-row count E."""
+    from stem_gnn_amd import ops
+    from stem_gnn_amd.graph import GraphStructure
+    from stem_gnn_amd.model.encoder import aggregate
+    n, per, d = 1200, 65, 32
+    g = torch.Generator().manual_seed(11)
+    src = torch.arange(n).repeat_interleave(per)
+    dst = src + torch.arange(1, per + 1).repeat(n)   # node i -> i + 1 .. i + 65, where the target exists
+    ok = dst < n
+    ei = torch.stack([src[ok], dst[ok]])
+    ei = ei[:, torch.randperm(ei.size(1), generator=g)]
+    e = ei.size(1)
+    keep = torch.ones(e, dtype=torch.bool)
+    keep[torch.randperm(e, generator=g)[:e // 200]] = False  # a few drops; the bulk stays at degree 130
+    gs = GraphStructure(ei.to(dev), n)
+    aug = gs.dropout_undirected(0.2, keep=keep.to(dev))
+    assert aug.slot_capacity == 2 * e
+    ea = torch.randn(e, d, generator=g)
+    x, w = torch.randn(n, d, generator=g), torch.randn(n, d, generator=g)
+    ei_o, ea_o, _ = O.dropout_adj_undirected(ei, ea, keep)
+    deg = torch.bincount(ei_o[1], minlength=n)
+    heavy = deg > ops.SPLIT_HEAVY
+    assert int(heavy.sum()) > n // 2 and int(deg.max()) < 3 * ops.SPLIT_HEAVY
+    x_ref = x.clone().requires_grad_(True)
+    ref = O.sage_mean_aggregate(x_ref, ei_o, ea_o)
+    (ref * w).sum().backward()
+    xg = x.to(dev).requires_grad_(True)
+    out = aggregate(xg, aug, ea.to(dev))
+    (out * w.to(dev)).sum().backward()
+    plan = aug._plan_in
+    items, rows = plan.counts.tolist()
+    want_items = int(((deg[heavy] + ops.SPLIT_CHUNK - 1) // ops.SPLIT_CHUNK).sum())
+    assert rows == int(heavy.sum()) and items == want_items
+    assert items > 2 * (e // ops.SPLIT_CHUNK) + 2, "the case must exceed what a plan sized from E would hold"
+    assert items <= plan.cap_items and rows <= plan.cap_heavy
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(xg.grad.cpu(), x_ref.grad, rtol=1e-4, atol=1e-4 * x_ref.grad.abs().max().item())
+
+
 # ---------------------------------------------------------------------------- K4
 @pytest.mark.parametrize("n,d", [(2, 4), (37, 32), (1000, 128), (513, 768), (4096, 48)])
 @pytest.mark.parametrize("use_bn,act,p,slope", [(True, 1, 0.15, 0.0), (True, 0, 0.0, 0.0), (False, 1, 0.3, 0.01),
@@ -456,8 +500,9 @@ def test_neighbor_sampler_contract(dev, impl):
     draws min(deg, fanout) of its in-neighbours without replacement; every sampled edge is a real
     edge of the full graph with its edge type; seeds first; last-hop nodes have no in-edges."""
     from collections import Counter
-    from stem_gnn_amd.data.sampler import HipNeighborSampler, NeighborSampler
+    from stem_gnn_amd.data.sampler import HipNeighborSampler
     from stem_gnn_amd.data.synthetic import make_graph
+    from torch_sampler import NeighborSampler  # tests/torch_sampler.py: the torch-op restatement of the contract
     g = make_graph(5000, 60000, 16, 4, kind="Z", device=dev, graph_seed=3)
     cls = HipNeighborSampler if impl == "hip" else NeighborSampler
     fan = [5, 3]

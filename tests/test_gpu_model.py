@@ -40,47 +40,92 @@ def build_vq(N, D, H, K, Dc, ortho_max, ema, dev):
                           kmeans_init=False, ema_update=bool(ema)).to(dev)
 
 
+FLIPS = {}  # (fixture, gemm mode, phase) -> near-tie index flips seen, judged by test_golden_flip_budget below
+
+
+def _rows_equal(got, want, keep_rows, rtol, atol, what):
+    """assert_close on the rows flagged in keep_rows (all of them unless an index flipped)."""
+    assert int(keep_rows.sum()) >= 0.99 * keep_rows.numel(), f"{what}: more than 1 % of the rows carry a flipped index"
+    torch.testing.assert_close(got[keep_rows], want[keep_rows], rtol=rtol, atol=atol, msg=lambda m: f"{what}: {m}")
+
+
+@pytest.mark.parametrize("gemm_mode", [1, 0], ids=["bf16x3", "f32mfma"])
 @pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p) for p in FIXTURES])
-def test_vq_matches_reference_golden(dev, path):
+def test_vq_matches_reference_golden(dev, path, gemm_mode, record_property):
+    """Every value the reference produced for the fixture is compared on every row whose code indices agree -- a
+    near-tie flip (top-2 gap < 1e-5) removes only its own row from the row-wise comparisons, never the whole
+    fixture; sums over rows (loss, parameter gradients, EMA buffers) are compared exactly when no index flipped and
+    with the flipped rows' bounded contribution otherwise.  Both matrix-core paths (exact bf16 pieces / fp32 MFMA)
+    run every fixture."""
+    from stem_gnn_amd import ops
     fx = torch.load(path, weights_only=True)
     N, D, H, K, Dc, ortho_max, ema, seed = fx["meta"].tolist()
-    vq = build_vq(N, D, H, K, Dc, ortho_max, ema, dev)
-    state = {k[len("state0."):]: v for k, v in fx.items() if k.startswith("state0.")}
-    vq.load_state_dict(state)  # the reference's exact key / shape contract
-    vq.train()
-    z = fx["z"].to(dev).requires_grad_(True)
-    # replay the reference's randperm draw for the orthogonal loss
-    if K > ortho_max:
-        vq._rand_code_ids = lambda n, k, device: fx["ortho_ids"].to(device)
-    q, ind, loss, oq = vq(z)
-    assert ind.dtype == torch.int64 and tuple(ind.shape) == tuple(fx["train.embed_ind"].shape)
-    flips = assert_indices_match(ind.cpu(), fx["train.embed_ind"], fx["top2_gap"])
-    if flips == 0:
-        torch.testing.assert_close(oq.detach().cpu(), fx["train.orig_quantize"], rtol=1e-4, atol=1e-5)
-        torch.testing.assert_close(q.detach().cpu(), fx["train.quantize"], rtol=1e-4, atol=1e-5)
-        torch.testing.assert_close(loss.detach().cpu(), fx["train.loss"], rtol=1e-4, atol=1e-5)
+    prev = ops.linear_set_mode(gemm_mode)
+    try:
+        vq = build_vq(N, D, H, K, Dc, ortho_max, ema, dev)
+        state = {k[len("state0."):]: v for k, v in fx.items() if k.startswith("state0.")}
+        vq.load_state_dict(state)  # the reference's exact key / shape contract
+        vq.train()
+        z = fx["z"].to(dev).requires_grad_(True)
+        # replay the reference's randperm draw for the orthogonal loss
+        if K > ortho_max:
+            vq._rand_code_ids = lambda n, k, device: fx["ortho_ids"].to(device)
+        q, ind, loss, oq = vq(z)
+        assert ind.dtype == torch.int64 and tuple(ind.shape) == tuple(fx["train.embed_ind"].shape)
+        flips = assert_indices_match(ind.cpu(), fx["train.embed_ind"], fx["top2_gap"])
+        FLIPS[(os.path.basename(path), gemm_mode, "train")] = flips
+        record_property("train_index_flips", flips)
+        assert flips <= 0.01 * N * H, f"{flips} near-tie flips of {N * H} assignments"
+        same = (ind.cpu().reshape(N, -1) == fx["train.embed_ind"].reshape(N, -1))          # [N, H]
+        row_ok = same.all(dim=1)
+        head_ok = same.repeat_interleave(Dc, dim=1)                                          # [N, H*Dc]
+        got_oq, want_oq = oq.detach().cpu(), fx["train.orig_quantize"]
+        torch.testing.assert_close(torch.where(head_ok, got_oq, want_oq), want_oq, rtol=1e-4, atol=1e-5)
+        _rows_equal(q.detach().cpu(), fx["train.quantize"], row_ok, 1e-4, 1e-5, "quantize")
+        # commitment term: a flipped assignment moves one row-head's squared error by < 2 * gap (unit vectors)
+        slack = 10.0 * 2.0 * 1e-5 * flips / max(N * H * Dc, 1)
+        torch.testing.assert_close(loss.detach().cpu(), fx["train.loss"], rtol=1e-4, atol=1e-5 + slack)
         w = torch.linspace(-1.0, 1.0, q.numel()).view_as(q).to(dev)
         (loss.sum() + (q * w).sum()).backward()
-        torch.testing.assert_close(z.grad.cpu(), fx["train.grad_z"], rtol=1e-3, atol=1e-5)
-        for pn, p in vq.named_parameters():
-            key = "train.grad." + pn
-            if key in fx:
-                torch.testing.assert_close(p.grad.cpu(), fx[key], rtol=1e-3, atol=1e-5)
-        if ema:
-            for k, v in vq.state_dict().items():
-                if k.startswith("_codebook."):
-                    torch.testing.assert_close(v.cpu(), fx["post." + k], rtol=1e-4, atol=1e-5)
-    # eval mode on the initial state
-    vq2 = build_vq(N, D, H, K, Dc, ortho_max, ema, dev)
-    vq2.load_state_dict(state)
-    vq2.eval()
-    with torch.no_grad():
-        q2, ind2, loss2, oq2 = vq2(fx["z"].to(dev))
-    flips2 = assert_indices_match(ind2.cpu(), fx["eval.embed_ind"], fx["top2_gap"])
-    if flips2 == 0:
-        torch.testing.assert_close(q2.cpu(), fx["eval.quantize"], rtol=1e-4, atol=1e-5)
-        torch.testing.assert_close(oq2.cpu(), fx["eval.orig_quantize"], rtol=1e-4, atol=1e-5)
-    assert float(loss2) == 0.0
+        _rows_equal(z.grad.cpu(), fx["train.grad_z"], row_ok, 1e-3, 1e-5, "grad_z")
+        if flips == 0:  # sums over all rows: a flipped row swaps a whole code vector in them
+            for pn, p in vq.named_parameters():
+                key = "train.grad." + pn
+                if key in fx:
+                    torch.testing.assert_close(p.grad.cpu(), fx[key], rtol=1e-3, atol=1e-5)
+            if ema:
+                for k, v in vq.state_dict().items():
+                    if k.startswith("_codebook."):
+                        torch.testing.assert_close(v.cpu(), fx["post." + k], rtol=1e-4, atol=1e-5)
+        # eval mode on the initial state
+        vq2 = build_vq(N, D, H, K, Dc, ortho_max, ema, dev)
+        vq2.load_state_dict(state)
+        vq2.eval()
+        with torch.no_grad():
+            q2, ind2, loss2, oq2 = vq2(fx["z"].to(dev))
+        flips2 = assert_indices_match(ind2.cpu(), fx["eval.embed_ind"], fx["top2_gap"])
+        FLIPS[(os.path.basename(path), gemm_mode, "eval")] = flips2
+        record_property("eval_index_flips", flips2)
+        assert flips2 <= 0.01 * N * H
+        same2 = (ind2.cpu().reshape(N, -1) == fx["eval.embed_ind"].reshape(N, -1))
+        _rows_equal(q2.cpu(), fx["eval.quantize"], same2.all(dim=1), 1e-4, 1e-5, "eval quantize")
+        head_ok2 = same2.repeat_interleave(Dc, dim=1)
+        torch.testing.assert_close(torch.where(head_ok2, oq2.cpu(), fx["eval.orig_quantize"]), fx["eval.orig_quantize"],
+                                   rtol=1e-4, atol=1e-5)
+        assert float(loss2) == 0.0
+    finally:
+        ops.linear_set_mode(prev)
+
+
+def test_golden_flip_budget():
+    """The golden comparisons above are not vacuous: the row-sum quantities (parameter gradients, EMA buffers) are
+    only compared for fixtures without an index flip, so nearly all fixtures must be flip-free in each mode."""
+    assert FLIPS, "run together with test_vq_matches_reference_golden"
+    for mode in (0, 1):
+        train = {k: v for k, v in FLIPS.items() if k[1] == mode and k[2] == "train"}
+        flipped = {k[0]: v for k, v in train.items() if v}
+        print(f"gemm mode {mode}: {len(train)} fixtures, flips: {flipped or 'none'}")
+        assert len(flipped) <= max(1, len(train) // 6), flipped
 
 
 @pytest.mark.parametrize("N,D,H,K,Dc", [(1, 32, 2, 8, 16), (127, 32, 4, 33, 32), (129, 64, 4, 128, 64),
@@ -107,13 +152,15 @@ def test_vq_vs_oracle_sizes(dev, N, D, H, K, Dc):
         vq._rand_code_ids = lambda n, k, device: ids.to(device)
     qg, ig, lg, oqg = vq(zg)
     flips = assert_indices_match(ig.cpu(), ir, gap)
-    if flips == 0:
-        torch.testing.assert_close(qg.detach().cpu(), qr.detach(), rtol=1e-4, atol=1e-5)
-        torch.testing.assert_close(lg.detach().cpu(), lr.detach(), rtol=1e-4, atol=1e-5)
-        w = torch.randn(N, D)
-        (lr.sum() + (qr * w).sum()).backward()
-        (lg.sum() + (qg * w.to(dev)).sum()).backward()
-        torch.testing.assert_close(zg.grad.cpu(), zr.grad, rtol=1e-3, atol=1e-5)
+    assert flips <= max(1, 0.01 * N * H), flips
+    row_ok = (ig.cpu().reshape(N, -1) == ir.reshape(N, -1)).all(dim=1)
+    torch.testing.assert_close(qg.detach().cpu()[row_ok], qr.detach()[row_ok], rtol=1e-4, atol=1e-5)
+    slack = 10.0 * 2.0 * 1e-5 * flips / max(N * H * Dc, 1)
+    torch.testing.assert_close(lg.detach().cpu(), lr.detach(), rtol=1e-4, atol=1e-5 + slack)
+    w = torch.randn(N, D)
+    (lr.sum() + (qr * w).sum()).backward()
+    (lg.sum() + (qg * w.to(dev)).sum()).backward()
+    torch.testing.assert_close(zg.grad.cpu()[row_ok], zr.grad[row_ok], rtol=1e-3, atol=1e-5)
 
 
 def test_vq_tie_breaks_to_lowest_index(dev):
