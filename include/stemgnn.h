@@ -178,6 +178,14 @@ int stemgnn_sage_agg_bwd(const float* g_agg, const float* x, int64_t num_nodes, 
                          const float* edge_attr, const float* etab, const int32_t* etype_slot_t, int64_t num_types,
                          float* g_x, void* stream);
 
+/* The same, ADDING into g_x (which already holds lin_r's share of the gradient, encoder.py:83-87) instead of
+ * overwriting it: rows without out-edges are left untouched.  Replaces autograd's separate accumulation add. */
+int stemgnn_sage_agg_bwd_acc(const float* g_agg, const float* x, int64_t num_nodes, int64_t dim,
+                             const int32_t* rowptr_t, const int32_t* dst_t, const int32_t* eid_t,
+                             const float* inv_deg,
+                             const float* edge_attr, const float* etab, const int32_t* etype_slot_t, int64_t num_types,
+                             float* g_x, void* stream);
+
 int stemgnn_inv_degree(const int32_t* rowptr, int64_t num_nodes, float* inv_deg, void* stream);
 
 /* Plain mean aggregation agg[i] = mean_{slots of i} x[src] (no edge term, no relu) and its
@@ -274,9 +282,9 @@ int stemgnn_linear_set_mode(int mode);
 /* y [M, N] = x1 [M, K1] w1[N, K1]^T (+ x2 [M, K2] w2 [N, K2]^T when K2 > 0) + bias [N] (NULL: none).
  * stats_partial (may be NULL): receives per-row-block column sums / sums of squares of y,
  * [stemgnn_linear_stats_blocks(M, N)][2][N]; *stats_blocks_host (host pointer, may be NULL)
- * receives that block count.  x1_rows: rows >= x1_rows of x1 are KNOWN TO BE ZERO (the aggregate of a sampled
- * batch, whose edges all end in the leading, expanded nodes): row tiles past them skip the x1 half of the
- * contraction.  Pass -1 (or M) when no such promise holds. */
+ * receives that block count.  x1_rows: rows >= x1_rows of x1 COUNT AS ZERO and are never read (the aggregate of a
+ * sampled batch, whose edges all end in the leading, expanded nodes; x1 may be a [x1_rows, K1] buffer): row tiles
+ * past them skip the x1 half of the contraction.  Pass -1 (or M) when x1 has M meaningful rows. */
 size_t stemgnn_linear_stats_partial_bytes(int64_t num_rows, int64_t out_dim);
 int64_t stemgnn_linear_stats_blocks(int64_t num_rows, int64_t out_dim);
 int stemgnn_linear_fwd(const float* x1, const float* w1, int64_t k1, const float* x2, const float* w2, int64_t k2,
@@ -327,6 +335,33 @@ int stemgnn_vq_assign_bwd(const float* g_quant, const float* g_loss, float commi
                           const float* xp, const float* norm, const int64_t* ind, const float* embed,
                           int64_t num_rows, int64_t heads, int64_t code_dim, int64_t codebook_size,
                           float* g_xp, void* stream);
+
+/* The same assignment without any [N, H*Dc] output: ind, norm and the commitment sum only.  The squared error of a
+ * row follows from its arg-max, |q - xn|^2 = |q|^2 + |xn|^2 - 2 <q, xn>, with esq [H, K] = |embed|^2 per code
+ * (stemgnn_code_sqnorm).  For callers that consume project_out(codes) (stemgnn_codes_project) and not the codes. */
+int stemgnn_vq_assign_lean(const float* xp, int64_t num_rows, int64_t heads, int64_t code_dim, const float* embed,
+                           const float* esq, int64_t codebook_size, float* norm, int64_t* ind, float* sqerr,
+                           float sqerr_scale, void* workspace, size_t workspace_bytes, void* stream);
+int stemgnn_code_sqnorm(const float* embed, int64_t num_codes, int64_t code_dim, float* esq, void* stream);
+
+/* project_out of quantised rows (vq.py:1041) read off a table: out[n] = bias + sum_h table[h][ind[n][h]], table
+ * [H, K, D] = embed[h, k] W_out[:, h*Dc:(h+1)*Dc]^T (stemgnn_small_gemm), bias [D] or NULL. */
+int stemgnn_codes_project(const float* table, const int64_t* ind, const float* bias, int64_t num_rows, int64_t heads,
+                          int64_t codebook_size, int64_t dim, float* out, void* stream);
+
+/* sums[h*K + k][:] = sum of the rows g[m] (g [M, D]) whose code in head h is k (ind [M, H] int64): the one-hot^T g
+ * product on the matrix cores, with the one-hot operand built in registers.  Deterministic (row splits reduced in a
+ * fixed order).  db[d] = sum_k sums[k][d] over one head's K rows = the column sums of g (stemgnn_segment_colsum). */
+size_t stemgnn_code_segment_sums_workspace_bytes(int64_t num_rows, int64_t heads, int64_t codebook_size, int64_t dim);
+int stemgnn_code_segment_sums(const int64_t* ind, int64_t heads, int64_t codebook_size, const float* g, int64_t num_rows,
+                              int64_t dim, float* sums, void* workspace, size_t workspace_bytes, void* stream);
+int stemgnn_segment_colsum(const float* sums, int64_t codebook_size, int64_t dim, float* db, void* stream);
+
+/* c(m, n) = sum_k a(m, k) b(k, n) for small operands with arbitrary ELEMENT strides, `batches` independent products
+ * (pointer offsets *_batch per batch): plain fp32 FMA in a fixed order.  For codebook-sized products only. */
+int stemgnn_small_gemm(const float* a, int64_t a_m, int64_t a_k, int64_t a_batch, const float* b, int64_t b_k,
+                       int64_t b_n, int64_t b_batch, float* c, int64_t c_m, int64_t c_n, int64_t c_batch, int64_t M,
+                       int64_t N, int64_t K, int64_t batches, void* stream);
 
 /* K10: EMA statistics (vq.py:661-672): bins [H, K] = #rows per code, embed_sum [H, K, Dc]
  * = sum of the normalised rows xp/max(norm,1e-12) per code.  Deterministic (sorted segment sums). */
@@ -433,6 +468,109 @@ int stemgnn_adamw_step(float* const* params, const float* const* grads, float* c
                        float* const* exp_avg_sq, const int64_t* sizes, int32_t count, float lr, float beta1,
                        float beta2, float eps, float weight_decay, int64_t step, const float* grad_coef,
                        void* stream);
+
+/* ====================================================================================
+ * Phase entry points: one call enqueues a whole module forward (or its backward) of the pretraining path, so the
+ * host pays one crossing per module instead of one per kernel.  Same arithmetic as the single-op entry points
+ * above (they are what these functions launch); structs carry plain device pointers and sizes.
+ * ==================================================================================== */
+
+/* Both CSR views of one (sub)graph (stem_gnn_amd.graph.GraphStructure). */
+typedef struct stemgnn_graph_view {
+  int64_t num_nodes;
+  int64_t active_rows;               /* rows >= active_rows have no in-edges (sampled batch); num_nodes if no promise */
+  const int32_t* rowptr;             /* by target: forward aggregation */
+  const int32_t* src;
+  const int32_t* eid;
+  const int32_t* etype_slot;         /* NULL unless the edge attribute is (type table, type id) */
+  const int32_t* rowptr_t;           /* by source: backward (may be NULL for a forward-only call) */
+  const int32_t* dst_t;
+  const int32_t* eid_t;
+  const int32_t* etype_slot_t;
+  const float* inv_deg;              /* [num_nodes] 1 / max(in-degree, 1) (backward) */
+} stemgnn_graph_view;
+
+/* One MySAGEConv + BatchNorm1d layer of Encoder (model/encoder.py:72-97,173,313-317). */
+typedef struct stemgnn_sage_layer {
+  int64_t in_dim, out_dim;
+  const float* w_l;                  /* lin_l.weight [out, in] */
+  const float* b_l;                  /* lin_l.bias [out] or NULL */
+  const float* w_r;                  /* lin_r.weight [out, in] */
+  const float* bn_weight;            /* [out]; NULL with normalize == 'none' */
+  const float* bn_bias;
+  float* bn_running_mean;            /* NULL: statistics not tracked */
+  float* bn_running_var;
+  int64_t* bn_num_batches_tracked;
+  float bn_eps, bn_momentum;
+  uint64_t drop_seed, drop_offset;   /* Philox key of this layer's dropout */
+  float* g_w_l;                      /* gradients, backward only (NULL: not wanted) */
+  float* g_b_l;
+  float* g_w_r;
+  float* g_bn_weight;
+  float* g_bn_bias;
+} stemgnn_sage_layer;
+
+typedef struct stemgnn_encoder_cfg {
+  int32_t num_layers;
+  int32_t use_bn;                    /* normalize == 'batch' */
+  int32_t training;                  /* batch statistics + dropout; 0: running statistics, no dropout (forward only) */
+  int32_t act;                       /* 1: relu / leaky relu between layers */
+  float negative_slope;
+  float dropout_p;
+} stemgnn_encoder_cfg;
+
+/* Encoder.forward (model/encoder.py:279-323) for the 'sage' backbone without MoE layers: per layer K1 over the
+ * rows that can receive edges, lin_l(agg) + lin_r(h) with the BatchNorm statistics in its epilogue, statistics
+ * finalisation, normalise + activation + dropout (none after the last layer).  Exactly one of edge_attr (dense
+ * [E, D]) / etab ([T, D], with graph->etype_slot) may be given, or neither.  The graph must not need the heavy-row
+ * split (no row with more than 128 edges).  `save` keeps what the backward needs (stemgnn_encoder_save_bytes);
+ * z [N, out_dim of the last layer]. */
+size_t stemgnn_encoder_save_bytes(int64_t num_nodes, int64_t active_rows, const stemgnn_sage_layer* layers,
+                                  const stemgnn_encoder_cfg* cfg);
+int stemgnn_encoder_fwd(const stemgnn_graph_view* graph, const float* x, const float* edge_attr, const float* etab,
+                        int64_t num_types, const stemgnn_sage_layer* layers, const stemgnn_encoder_cfg* cfg, float* z,
+                        void* save, size_t save_bytes, void* stream);
+/* Its backward: g_z [N, out] -> parameter gradients (layer structs) and, when g_x != NULL, the input gradient.
+ * g_z is only read.  `scratch`: stemgnn_encoder_bwd_scratch_bytes. */
+size_t stemgnn_encoder_bwd_scratch_bytes(int64_t num_nodes, int64_t active_rows, const stemgnn_sage_layer* layers,
+                                         const stemgnn_encoder_cfg* cfg);
+int stemgnn_encoder_bwd(const stemgnn_graph_view* graph, const float* x, const float* edge_attr, const float* etab,
+                        int64_t num_types, const stemgnn_sage_layer* layers, const stemgnn_encoder_cfg* cfg,
+                        const float* g_z, float* g_x, const void* save, size_t save_bytes, void* scratch,
+                        size_t scratch_bytes, void* stream);
+
+/* VectorQuantize (model/vq.py:692-1064) with a cosine codebook per head and projections in / out. */
+typedef struct stemgnn_vq_params {
+  int64_t dim, heads, code_dim, codebook_size;
+  const float* w_in;                 /* project_in.weight [H*Dc, dim] */
+  const float* b_in;                 /* [H*Dc] or NULL */
+  const float* w_out;                /* project_out.weight [dim, H*Dc] */
+  const float* b_out;                /* [dim] or NULL */
+  const float* embed;                /* _codebook.embed [H, K, Dc] */
+  float commitment_weight;           /* 0: no commitment term */
+  float ortho_weight;                /* 0: no orthogonal regulariser */
+  const int64_t* ortho_ids;          /* code ids the regulariser runs on (distinct) */
+  int64_t num_ortho_ids;
+  float* g_w_in;                     /* gradients, backward only (NULL: not wanted) */
+  float* g_b_in;
+  float* g_w_out;
+  float* g_b_out;
+  float* g_embed;
+} stemgnn_vq_params;
+
+/* VectorQuantize.forward for callers that use (quantize, embed_ind, loss) and not the per-head codes (the pretraining
+ * step, pt_model.py:113): project_in -> fused cosine assignment -> loss terms -> project_out read off the projected
+ * code table.  quantize [N, dim], ind [N, H] int64, loss [1] = commitment_weight * mse + ortho_weight * ortho
+ * (zero in eval mode).  `save`: stemgnn_vq_save_bytes. */
+size_t stemgnn_vq_save_bytes(const stemgnn_vq_params* p, int64_t num_rows);
+int stemgnn_vq_fwd(const stemgnn_vq_params* p, const float* z, int64_t num_rows, int training, float* quantize,
+                   int64_t* ind, float* loss, void* save, size_t save_bytes, void* stream);
+/* Backward: g_quantize [N, dim] (NULL: zero), g_loss [1] device scalar (NULL: zero) -> g_z [N, dim] and the parameter
+ * gradients of the struct.  `scratch`: stemgnn_vq_bwd_scratch_bytes. */
+size_t stemgnn_vq_bwd_scratch_bytes(const stemgnn_vq_params* p, int64_t num_rows);
+int stemgnn_vq_bwd(const stemgnn_vq_params* p, const float* z, int64_t num_rows, const int64_t* ind,
+                   const float* g_quantize, const float* g_loss, float* g_z, const void* save, size_t save_bytes,
+                   void* scratch, size_t scratch_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -32,6 +32,34 @@ P = c_void_p
 I64 = c_int64
 I32 = ctypes.c_int32
 
+
+class GraphView(ctypes.Structure):
+    """stemgnn_graph_view (include/stemgnn.h)."""
+    _fields_ = [("num_nodes", I64), ("active_rows", I64), ("rowptr", P), ("src", P), ("eid", P), ("etype_slot", P),
+                ("rowptr_t", P), ("dst_t", P), ("eid_t", P), ("etype_slot_t", P), ("inv_deg", P)]
+
+
+class SageLayer(ctypes.Structure):
+    """stemgnn_sage_layer (include/stemgnn.h)."""
+    _fields_ = [("in_dim", I64), ("out_dim", I64), ("w_l", P), ("b_l", P), ("w_r", P), ("bn_weight", P), ("bn_bias", P),
+                ("bn_running_mean", P), ("bn_running_var", P), ("bn_num_batches_tracked", P), ("bn_eps", c_float),
+                ("bn_momentum", c_float), ("drop_seed", c_uint64), ("drop_offset", c_uint64), ("g_w_l", P), ("g_b_l", P),
+                ("g_w_r", P), ("g_bn_weight", P), ("g_bn_bias", P)]
+
+
+class VqParams(ctypes.Structure):
+    """stemgnn_vq_params (include/stemgnn.h)."""
+    _fields_ = [("dim", I64), ("heads", I64), ("code_dim", I64), ("codebook_size", I64), ("w_in", P), ("b_in", P),
+                ("w_out", P), ("b_out", P), ("embed", P), ("commitment_weight", c_float), ("ortho_weight", c_float),
+                ("ortho_ids", P), ("num_ortho_ids", I64), ("g_w_in", P), ("g_b_in", P), ("g_w_out", P), ("g_b_out", P),
+                ("g_embed", P)]
+
+
+class EncoderCfg(ctypes.Structure):
+    """stemgnn_encoder_cfg (include/stemgnn.h)."""
+    _fields_ = [("num_layers", I32), ("use_bn", I32), ("training", I32), ("act", I32), ("negative_slope", c_float),
+                ("dropout_p", c_float)]
+
 _SIGNATURES = {
     "stemgnn_abi_version": (c_int, []),
     "stemgnn_status_string": (c_char_p, [c_int]),
@@ -56,6 +84,22 @@ _SIGNATURES = {
     "stemgnn_group_by_key": (c_int, [P, I64, I64, P, P, P, c_size_t, P]),
     "stemgnn_sage_agg_fwd": (c_int, [P, I64, I64, P, P, P, P, P, P, I64, P, P]),
     "stemgnn_sage_agg_bwd": (c_int, [P, P, I64, I64, P, P, P, P, P, P, P, I64, P, P]),
+    "stemgnn_sage_agg_bwd_acc": (c_int, [P, P, I64, I64, P, P, P, P, P, P, P, I64, P, P]),
+    "stemgnn_vq_assign_lean": (c_int, [P, I64, I64, I64, P, P, I64, P, P, P, c_float, P, c_size_t, P]),
+    "stemgnn_code_sqnorm": (c_int, [P, I64, I64, P, P]),
+    "stemgnn_codes_project": (c_int, [P, P, P, I64, I64, I64, I64, P, P]),
+    "stemgnn_code_segment_sums_workspace_bytes": (c_size_t, [I64, I64, I64, I64]),
+    "stemgnn_code_segment_sums": (c_int, [P, I64, I64, P, I64, I64, P, P, c_size_t, P]),
+    "stemgnn_segment_colsum": (c_int, [P, I64, I64, P, P]),
+    "stemgnn_small_gemm": (c_int, [P, I64, I64, I64, P, I64, I64, I64, P, I64, I64, I64, I64, I64, I64, I64, P]),
+    "stemgnn_vq_save_bytes": (c_size_t, [P, I64]),
+    "stemgnn_vq_fwd": (c_int, [P, P, I64, c_int, P, P, P, P, c_size_t, P]),
+    "stemgnn_vq_bwd_scratch_bytes": (c_size_t, [P, I64]),
+    "stemgnn_vq_bwd": (c_int, [P, P, I64, P, P, P, P, P, c_size_t, P, c_size_t, P]),
+    "stemgnn_encoder_save_bytes": (c_size_t, [I64, I64, P, P]),
+    "stemgnn_encoder_fwd": (c_int, [P, P, P, P, I64, P, P, P, P, c_size_t, P]),
+    "stemgnn_encoder_bwd_scratch_bytes": (c_size_t, [I64, I64, P, P]),
+    "stemgnn_encoder_bwd": (c_int, [P, P, P, P, I64, P, P, P, P, P, c_size_t, P, c_size_t, P]),
     "stemgnn_sage_agg_fwd_split": (c_int, [P, I64, I64, I64, P, P, P, P, P, P, I64, P, I32, I32, I32, I32, I64, I64,
                                            P, P, P, P, P, P, P]),
     "stemgnn_sage_agg_bwd_split": (c_int, [P, P, I64, I64, I64, P, P, P, P, P, P, P, I64, P, I32, I32, I32, I32, I64,

@@ -86,7 +86,8 @@ k_linear_fwd(const float* __restrict__ x1, const float* __restrict__ w1, int K1,
       }
       if (t < FA) {
         const int64_t m = m0 + r;
-        ra[t] = (m < M && k < K) ? ld4(xs + m * K + k) : zero4();
+        // rows >= x1_rows of the first operand are zero by promise and are never read (the buffer may end there)
+        ra[t] = (m < (second ? M : x1_rows) && k < K) ? ld4(xs + m * K + k) : zero4();
       }
     }
   };
@@ -247,7 +248,8 @@ k_linear_fwd_x3(const float* __restrict__ x1, const float* __restrict__ w1, int 
       }
       if (t < FA) {
         const int64_t m = m0 + r;
-        ra[t] = (m < M && k < K) ? ld4(xs + m * K + k) : zero4();
+        // rows >= x1_rows of the first operand are zero by promise and are never read (the buffer may end there)
+        ra[t] = (m < (second ? M : x1_rows) && k < K) ? ld4(xs + m * K + k) : zero4();
       }
     }
   };
@@ -551,6 +553,163 @@ k_linear_bwd_weight_x3(const float* __restrict__ dy, const float* __restrict__ x
     st4(partial_db + static_cast<int64_t>(split) * N + n0 + 4 * cq, colsum);
 }
 
+// Segment sums by code on the matrix cores: S[h * K + k][d] = sum over rows m with ind[m][h] == k of g[m][d], i.e. the
+// weight-gradient product above with dY^T replaced by the ONE-HOT matrix of the code assignment.  A one-hot entry is
+// exact in a single bf16 piece, so the A operand is built in registers from `ind` (no [M, H*K] or [M, H*Dc] operand is
+// ever read) and a 16-row step takes three MFMAs (g's three pieces) instead of six.  Used for project_out's weight
+// gradient: quantize = sum_h embed[h, ind[:, h]] W_out_h^T, so dW_out_h = S_h^T embed_h (reference model/vq.py:1041).
+// Deterministic: row splits + the fixed-order slab reduction below.
+__global__ void __launch_bounds__(kBlock, 2)
+k_code_segment_sums(const int64_t* __restrict__ ind, int H, int K, const float* __restrict__ g, int64_t M, int D,
+                    int64_t rows_per_split, float* __restrict__ partial /*[S][H*K][D]*/) {
+  constexpr int PL = kBN * kLdP;
+  __shared__ __attribute__((aligned(16))) unsigned char sA[PL];      // one-hot^T plane [128 codes][32 m]
+  __shared__ __attribute__((aligned(16))) unsigned char sB[3 * PL];  // g^T planes   [128 d][32 m]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wi = wave >> 1, wj = wave & 1, hi = lane >> 5, lj = lane & 31;
+  const int split = blockIdx.x;
+  const int n0 = blockIdx.y * kBN, k0 = blockIdx.z * kBN;  // code tile, feature tile
+  const int NC = H * K;
+  const int64_t mbeg = split * rows_per_split;
+  const int64_t mend = min(M, mbeg + rows_per_split);
+  const int steps = static_cast<int>((mend - mbeg + kKC - 1) / kKC);
+  const int mq = tid & 7, cq = tid >> 3;
+  // the four code columns this thread stages: (head, code) of each
+  int ch[4], ck[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = n0 + 4 * cq + j;
+    ch[j] = n < NC ? n / K : -1;
+    ck[j] = n < NC ? n % K : -1;
+  }
+
+  int code[4][4];  // code[i][j]: assignment of row i in the head of column j
+  float4 rb[4];
+  auto fetch = [&](int step) {
+    const int64_t mm = mbeg + static_cast<int64_t>(step) * kKC + 4 * mq;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t m = mm + i;
+      rb[i] = (m < mend && k0 + 4 * cq < D) ? ld4(g + m * D + k0 + 4 * cq) : zero4();
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        code[i][j] = (m < mend && ch[j] >= 0) ? static_cast<int>(ind[m * H + ch[j]]) : -2;
+    }
+  };
+
+  floatx16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  if (steps > 0) fetch(0);
+  for (int step = 0; step < steps; ++step) {
+    stash_transposed(rb, sB, PL, tid);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t one = 0x3F80u;  // bf16 1.0
+      const uint32_t e0 = code[0][j] == ck[j] ? one : 0u, e1 = code[1][j] == ck[j] ? one : 0u;
+      const uint32_t e2 = code[2][j] == ck[j] ? one : 0u, e3 = code[3][j] == ck[j] ? one : 0u;
+      *reinterpret_cast<uint2*>(sA + (4 * cq + j) * kLdP + 8 * mq) = make_uint2(e0 | (e1 << 16), e2 | (e3 << 16));
+    }
+    __syncthreads();
+    if (step + 1 < steps) fetch(step + 1);
+#pragma unroll
+    for (int ks = 0; ks < kKC / 16; ++ks) {
+      const int ko = ks * 32 + hi * 16;
+      bf16x8 a[2], b[2][3];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        a[t] = *reinterpret_cast<const bf16x8*>(sA + (wi * 64 + t * 32 + lj) * kLdP + ko);
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          b[t][p] = *reinterpret_cast<const bf16x8*>(sB + p * PL + (wj * 64 + t * 32 + lj) * kLdP + ko);
+      }
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) {
+          floatx16 c = acc[ti][tj];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ti], b[tj][2], c, 0, 0, 0);  // small pieces first
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ti], b[tj][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ti], b[tj][0], c, 0, 0, 0);
+          acc[ti][tj] = c;
+        }
+    }
+    __syncthreads();
+  }
+
+  float* pw = partial + static_cast<int64_t>(split) * NC * D;
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj) {
+      const int k = k0 + wj * 64 + tj * 32 + lj;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wi * 64 + ti * 32 + acc_row(r, hi);
+        if (n < NC && k < D) pw[static_cast<int64_t>(n) * D + k] = acc[ti][tj][r];
+      }
+    }
+}
+
+// C(m, n) = sum_k A(m, k) B(k, n) for SMALL operands with arbitrary element strides (codebook-sized products: the
+// project_out table P_h = embed_h W_out_h^T and dW_out_h = S_h^T embed_h): plain fp32 FMA in a fixed k order --
+// exact fp32 arithmetic, bit-reproducible.  64 x 64 tile, 16-deep chunks, 4 x 4 outputs per thread; blockIdx.z = batch.
+struct SmallGemm {
+  const float* a; int64_t a_m, a_k, a_b;   // element strides of A along m, k and per batch
+  const float* b; int64_t b_k, b_n, b_b;
+  float* c; int64_t c_m, c_n, c_b;
+  int M, N, K;
+};
+__global__ void __launch_bounds__(kBlock) k_small_gemm(SmallGemm p) {
+  constexpr int T = 64, KC = 16;
+  __shared__ float sA[KC][T + 1], sB[KC][T + 1];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int m0 = blockIdx.x * T, n0 = blockIdx.y * T;
+  const float* A = p.a + blockIdx.z * p.a_b;
+  const float* B = p.b + blockIdx.z * p.b_b;
+  float* C = p.c + blockIdx.z * p.c_b;
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  for (int k0 = 0; k0 < p.K; k0 += KC) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int idx = t * kBlock + tid;  // 1024 elements of each 16 x 64 chunk
+      const int kk = idx >> 6, mm = idx & 63;
+      const int k = k0 + kk;
+      sA[kk][mm] = (k < p.K && m0 + mm < p.M) ? A[static_cast<int64_t>(m0 + mm) * p.a_m + k * p.a_k] : 0.f;
+      sB[kk][mm] = (k < p.K && n0 + mm < p.N) ? B[static_cast<int64_t>(k) * p.b_k + (n0 + mm) * p.b_n] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < KC; ++kk) {
+      float a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { a[i] = sA[kk][ty + 16 * i]; b[i] = sB[kk][tx + 16 * i]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = m0 + ty + 16 * i, n = n0 + tx + 16 * j;
+      if (m < p.M && n < p.N) C[static_cast<int64_t>(m) * p.c_m + static_cast<int64_t>(n) * p.c_n] = acc[i][j];
+    }
+}
+
 // out[i] = sum_s partial[s][i]: 16 float4 columns x 16 split-slices per block, fixed-order LDS
 // tree over the slices (deterministic).
 __global__ void __launch_bounds__(kBlock)
@@ -812,6 +971,52 @@ int stemgnn_linear_bwd_weight(const float* dy, const float* x, int64_t M, int64_
   const int blocks1 = static_cast<int>((nk / 4 + 15) / 16);
   const int blocks2 = db ? static_cast<int>((N / 4 + 15) / 16) : 0;
   k_reduce_splits<<<static_cast<unsigned>(blocks1 + blocks2), kBlock, 0, st>>>(pw, S, nk, dw, pb, N, db, blocks1);
+  STEMGNN_LAUNCH_CHECK();
+  return STEMGNN_OK;
+}
+
+size_t stemgnn_code_segment_sums_workspace_bytes(int64_t M, int64_t H, int64_t K, int64_t D) {
+  if (M < 0 || H <= 0 || K <= 0 || D <= 0 || D % 4 != 0) return 0;
+  return static_cast<size_t>(pick_splits(M, out_tiles(H * K, D))) * (H * K) * D * sizeof(float) + 512;
+}
+
+int stemgnn_code_segment_sums(const int64_t* ind, int64_t H, int64_t K, const float* g, int64_t M, int64_t D,
+                              float* sums, void* workspace, size_t workspace_bytes, void* stream_) {
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  if (M < 0 || H <= 0 || K <= 0 || D <= 0 || D % 4 != 0 || H * K > (1 << 24) || !sums) return STEMGNN_ERR_INVALID_ARG;
+  if (!fits_i32(M)) return STEMGNN_ERR_TOO_LARGE;
+  const int64_t NC = H * K;
+  if (M == 0) {
+    STEMGNN_HIP_TRY(hipMemsetAsync(sums, 0, sizeof(float) * NC * D, st));
+    return STEMGNN_OK;
+  }
+  if (!ind || !g || !workspace) return STEMGNN_ERR_INVALID_ARG;
+  if (workspace_bytes < stemgnn_code_segment_sums_workspace_bytes(M, H, K, D)) return STEMGNN_ERR_WORKSPACE;
+  const int S = pick_splits(M, out_tiles(NC, D));
+  int64_t rows = (M + S - 1) / S;
+  rows = (rows + kKC - 1) / kKC * kKC;
+  float* pw = reinterpret_cast<float*>(align_up(reinterpret_cast<uintptr_t>(workspace), 256));
+  dim3 grid(static_cast<unsigned>(S), static_cast<unsigned>((NC + kBN - 1) / kBN), static_cast<unsigned>((D + kBN - 1) / kBN));
+  k_code_segment_sums<<<grid, kBlock, 0, st>>>(ind, static_cast<int>(H), static_cast<int>(K), g, M, static_cast<int>(D),
+                                               rows, pw);
+  STEMGNN_LAUNCH_CHECK();
+  const int64_t nk = NC * D;
+  const int blocks1 = static_cast<int>((nk / 4 + 15) / 16);
+  k_reduce_splits<<<static_cast<unsigned>(blocks1), kBlock, 0, st>>>(pw, S, nk, sums, nullptr, 0, nullptr, blocks1);
+  STEMGNN_LAUNCH_CHECK();
+  return STEMGNN_OK;
+}
+
+int stemgnn_small_gemm(const float* a, int64_t a_m, int64_t a_k, int64_t a_batch, const float* b, int64_t b_k,
+                       int64_t b_n, int64_t b_batch, float* c, int64_t c_m, int64_t c_n, int64_t c_batch, int64_t M,
+                       int64_t N, int64_t K, int64_t batches, void* stream_) {
+  if (M <= 0 || N <= 0 || K <= 0 || batches <= 0 || batches > 65535 || M > (1 << 24) || N > (1 << 24) || K > (1 << 24) ||
+      !a || !b || !c)
+    return STEMGNN_ERR_INVALID_ARG;
+  SmallGemm p{a, a_m, a_k, a_batch, b, b_k, b_n, b_batch, c, c_m, c_n, c_batch, static_cast<int>(M),
+              static_cast<int>(N), static_cast<int>(K)};
+  dim3 grid(static_cast<unsigned>((M + 63) / 64), static_cast<unsigned>((N + 63) / 64), static_cast<unsigned>(batches));
+  k_small_gemm<<<grid, kBlock, 0, static_cast<hipStream_t>(stream_)>>>(p);
   STEMGNN_LAUNCH_CHECK();
   return STEMGNN_OK;
 }

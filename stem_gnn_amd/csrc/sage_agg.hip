@@ -298,6 +298,10 @@ k_sage_agg_bwd(const float* __restrict__ g_agg, const float* __restrict__ x, int
   const int64_t unit = static_cast<int64_t>(blockIdx.x) * kGroups + group;
   const int nvec = D / 4;
   constexpr int U = V <= 3 ? 4 : (V == 4 ? 2 : 1);
+  // bit 1 of `relu`: ACCUMULATE -- g_x already holds a gradient (lin_r's backward-data product) and this pass adds
+  // to it; rows without out-edges are then left alone instead of being zeroed.  Row mode only.
+  const bool accumulate = (relu & 2) != 0;
+  relu &= 1;
   // Same latency ordering as the forward: extent, first chunk of (target, weight, type), the source row and the
   // zero rows all go out before the table is staged; nobody returns above the barrier inside stage_table.
   int64_t row = 0;
@@ -339,11 +343,19 @@ k_sage_agg_bwd(const float* __restrict__ g_agg, const float* __restrict__ x, int
     const int c = lane + G * v;
     xs[v] = (live && c < nvec && beg < end) ? ld4(x + row * D + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  if (live && beg == end) {
+  float4 prior[V];
 #pragma unroll
-    for (int v = 0; v < V; ++v) {
-      const int c = lane + G * v;
-      if (c < nvec) st4(out + 4 * c, acc[v]);
+  for (int v = 0; v < V; ++v) {
+    const int c = lane + G * v;
+    prior[v] = (accumulate && live && c < nvec && beg < end) ? ld4(out + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (live && beg == end) {
+    if (!accumulate) {
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        const int c = lane + G * v;
+        if (c < nvec) st4(out + 4 * c, acc[v]);
+      }
     }
     live = false;
   }
@@ -400,7 +412,9 @@ k_sage_agg_bwd(const float* __restrict__ g_agg, const float* __restrict__ x, int
 #pragma unroll
   for (int v = 0; v < V; ++v) {
     const int c = lane + G * v;
-    if (c < nvec) st4(out + 4 * c, acc[v]);
+    if (c < nvec)
+      st4(out + 4 * c, make_float4(acc[v].x + prior[v].x, acc[v].y + prior[v].y, acc[v].z + prior[v].z,
+                                   acc[v].w + prior[v].w));
   }
 }
 
@@ -655,6 +669,13 @@ int stemgnn_sage_agg_bwd(const float* g_agg, const float* x, int64_t N, int64_t 
                          const int32_t* dst_t, const int32_t* eid_t, const float* inv_deg, const float* edge_attr,
                          const float* etab, const int32_t* etype_slot_t, int64_t T, float* g_x, void* stream_) {
   return sage_agg_bwd_impl(g_agg, x, N, D, rowptr_t, dst_t, eid_t, inv_deg, edge_attr, etab, etype_slot_t, T, g_x, 1,
+                           nullptr, 0, stream_);
+}
+
+int stemgnn_sage_agg_bwd_acc(const float* g_agg, const float* x, int64_t N, int64_t D, const int32_t* rowptr_t,
+                             const int32_t* dst_t, const int32_t* eid_t, const float* inv_deg, const float* edge_attr,
+                             const float* etab, const int32_t* etype_slot_t, int64_t T, float* g_x, void* stream_) {
+  return sage_agg_bwd_impl(g_agg, x, N, D, rowptr_t, dst_t, eid_t, inv_deg, edge_attr, etab, etype_slot_t, T, g_x, 1 | 2,
                            nullptr, 0, stream_);
 }
 

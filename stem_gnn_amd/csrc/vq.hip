@@ -42,7 +42,7 @@ template <int CG, bool X3>
 __global__ void __launch_bounds__(kBlock, 2)
 k_vq_assign(const float* __restrict__ xp, int64_t N, int H, int Dc, const float* __restrict__ embed, int K,
             int training, float* __restrict__ xn_out, float* __restrict__ norm_out, int64_t* __restrict__ ind_out,
-            float* __restrict__ quant, float* __restrict__ sq_partial) {
+            float* __restrict__ quant, float* __restrict__ sq_partial, const float* __restrict__ esq) {
   constexpr int PA = 32 * CG * kLdP, PB = kRowsPerBlock * kLdP;  // bytes of one bf16 plane (X3)
   constexpr int kBytesA = X3 ? 3 * PA : 32 * CG * kLd * 4;
   constexpr int kBytesB = X3 ? 3 * PB : kRowsPerBlock * kLd * 4;
@@ -51,6 +51,7 @@ k_vq_assign(const float* __restrict__ xp, int64_t N, int H, int Dc, const float*
   float* sA = reinterpret_cast<float*>(sA_raw);
   float* sB = reinterpret_cast<float*>(sB_raw);
   __shared__ float s_inv[kRowsPerBlock];
+  __shared__ float s_nrm[kRowsPerBlock];
   __shared__ float s_red[kBlock / kWave];
 
   const int tid = threadIdx.x;
@@ -207,6 +208,7 @@ k_vq_assign(const float* __restrict__ xp, int64_t N, int H, int Dc, const float*
       const int64_t row = row0 + r;
       const float nrm = sqrtf(v);
       s_inv[r] = row < N ? 1.0f / fmaxf(nrm, kNormEps) : 0.f;
+      s_nrm[r] = nrm;
       if (row < N) norm_out[row * H + h] = nrm;
     }
   }
@@ -222,10 +224,22 @@ k_vq_assign(const float* __restrict__ xp, int64_t N, int H, int Dc, const float*
     if (row < N) ind_out[row * H + h] = static_cast<int64_t>(best_idx);
   }
 
-  // ---- epilogue: gather the winning code rows, straight-through value, commitment partial
+  // ---- epilogue.  With `quant` the winning code rows are gathered and the straight-through value is written
+  // (callers that consume the per-head codes).  Without it nothing of size [N, H*Dc] is read again or written: the
+  // commitment term follows from the arg-max itself, |q - xn|^2 = |q|^2 + |xn|^2 - 2 <q, xn>, with <q, xn> =
+  // best_val / max(|x|, eps) from the fp32-accurate similarity product and |q|^2 from the per-code table `esq`.
+  float sq = 0.f;
+  if (quant == nullptr) {
+    if (hi == 0) {
+      const int r = wave * 32 + lj;
+      if (row0 + r < N) {
+        const float inv = s_inv[r], xn2 = s_nrm[r] * inv;  // |xn| (1 unless the row is below the eps clamp)
+        sq = esq[static_cast<int64_t>(h) * K + best_idx] + xn2 * xn2 - 2.0f * best_val * inv;
+      }
+    }
+  } else {
   // All loads of a batch are issued before its stores: vmcnt counts loads and stores in one
   // in-order queue, so a load placed behind a store would wait for that store to retire.
-  float sq = 0.f;
   constexpr int EB = 8;
   const int iters = (32 * nvec + 63) / 64;  // wave-uniform trip count: every lane takes part in the shuffles
   for (int it0 = 0; it0 < iters; it0 += EB) {
@@ -260,6 +274,7 @@ k_vq_assign(const float* __restrict__ xp, int64_t N, int H, int Dc, const float*
       }
     }
   }
+  }
   sq = wave_sum(sq);
   if (lane == 0) s_red[wave] = sq;
   __syncthreads();
@@ -268,6 +283,54 @@ k_vq_assign(const float* __restrict__ xp, int64_t N, int H, int Dc, const float*
     for (int w = 0; w < kBlock / kWave; ++w) t += s_red[w];
     sq_partial[static_cast<int64_t>(blockIdx.y) * gridDim.x + blockIdx.x] = t;
   }
+}
+
+// esq[c] = |embed[c]|^2, one wave per code row (the codebook drifts off the unit sphere under AdamW).
+__global__ void __launch_bounds__(kBlock) k_code_sqnorm(const float* __restrict__ embed, int64_t codes, int Dc,
+                                                        float* __restrict__ esq) {
+  const int lane = threadIdx.x & 63;
+  const int64_t c = static_cast<int64_t>(blockIdx.x) * (kBlock / kWave) + (threadIdx.x >> 6);
+  if (c >= codes) return;
+  float s = 0.f;
+  for (int i = lane; i < Dc / 4; i += 64) {
+    const float4 v = ld4(embed + c * Dc + 4 * i);
+    s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  s = wave_sum(s);
+  if (lane == 0) esq[c] = s;
+}
+
+// out[n] = bias + sum_h table[h][ind[n][h]]: project_out of the quantised heads (model/vq.py:1041) read off a
+// [H, K, D] table of projected code rows (the rows of a batch take only H*K distinct values per head).
+template <int G>
+__global__ void __launch_bounds__(kBlock)
+k_codes_project(const float* __restrict__ table, const int64_t* __restrict__ ind, const float* __restrict__ bias,
+                int64_t N, int H, int K, int D, float* __restrict__ out) {
+  const int lane = threadIdx.x % G;
+  const int64_t row = static_cast<int64_t>(blockIdx.x) * (kBlock / G) + threadIdx.x / G;
+  if (row >= N) return;
+  const int nvec = D / 4;
+  for (int c = lane; c < nvec; c += G) {
+    float4 a = bias ? ld4(bias + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int h = 0; h < H; ++h) {
+      int64_t code = ind[row * H + h];
+      if (code < 0 || code >= K) code = 0;
+      const float4 v = ld4(table + (static_cast<int64_t>(h) * K + code) * D + 4 * c);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    st4(out + row * D + 4 * c, a);
+  }
+}
+
+// db[d] = sum_k sums[k][d] over the K code rows of ONE head (every row of the batch belongs to exactly one code per
+// head, so any head's segment sums add up to the column sums of the gradient): project_out's bias gradient.
+__global__ void __launch_bounds__(kBlock) k_segment_colsum(const float* __restrict__ sums, int K, int D,
+                                                           float* __restrict__ db) {
+  const int d = blockIdx.x * kBlock + threadIdx.x;
+  if (d >= D) return;
+  float s = 0.f;
+  for (int k = 0; k < K; ++k) s += sums[static_cast<int64_t>(k) * D + d];
+  db[d] = s;
 }
 
 __global__ void __launch_bounds__(kBlock) k_sum_partials(const float* __restrict__ partial, int64_t n, double scale,
@@ -380,9 +443,61 @@ size_t stemgnn_vq_workspace_bytes(int64_t N, int64_t H, int64_t Dc, int64_t K) {
   return static_cast<size_t>(row_blocks(N < 1 ? 1 : N) * H) * sizeof(float) + 512;
 }
 
+static int vq_assign_impl(const float* xp, int64_t N, int64_t H, int64_t Dc, const float* embed, int64_t K,
+                          int training, float* xn, float* norm, int64_t* ind, float* quant, const float* esq,
+                          float* sqerr, float sqerr_scale, void* workspace, size_t workspace_bytes, void* stream_);
+
 int stemgnn_vq_assign_fwd(const float* xp, int64_t N, int64_t H, int64_t Dc, const float* embed, int64_t K,
                           int training, float* xn, float* norm, int64_t* ind, float* quant, float* sqerr,
                           float sqerr_scale, void* workspace, size_t workspace_bytes, void* stream_) {
+  if (!quant && N > 0) return STEMGNN_ERR_INVALID_ARG;
+  return vq_assign_impl(xp, N, H, Dc, embed, K, training, xn, norm, ind, quant, nullptr, sqerr, sqerr_scale, workspace,
+                        workspace_bytes, stream_);
+}
+
+int stemgnn_vq_assign_lean(const float* xp, int64_t N, int64_t H, int64_t Dc, const float* embed, const float* esq,
+                           int64_t K, float* norm, int64_t* ind, float* sqerr, float sqerr_scale, void* workspace,
+                           size_t workspace_bytes, void* stream_) {
+  if (!esq && N > 0) return STEMGNN_ERR_INVALID_ARG;
+  return vq_assign_impl(xp, N, H, Dc, embed, K, 1, nullptr, norm, ind, nullptr, esq, sqerr, sqerr_scale, workspace,
+                        workspace_bytes, stream_);
+}
+
+int stemgnn_code_sqnorm(const float* embed, int64_t codes, int64_t Dc, float* esq, void* stream_) {
+  if (codes < 0 || Dc <= 0 || Dc % 4 != 0) return STEMGNN_ERR_INVALID_ARG;
+  if (codes == 0) return STEMGNN_OK;
+  if (!embed || !esq) return STEMGNN_ERR_INVALID_ARG;
+  k_code_sqnorm<<<static_cast<unsigned>((codes + 3) / 4), kBlock, 0, static_cast<hipStream_t>(stream_)>>>(
+      embed, codes, static_cast<int>(Dc), esq);
+  STEMGNN_LAUNCH_CHECK();
+  return STEMGNN_OK;
+}
+
+int stemgnn_codes_project(const float* table, const int64_t* ind, const float* bias, int64_t N, int64_t H, int64_t K,
+                          int64_t D, float* out, void* stream_) {
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  if (N < 0 || H <= 0 || K <= 0 || D <= 0 || D % 4 != 0) return STEMGNN_ERR_INVALID_ARG;
+  if (N == 0) return STEMGNN_OK;
+  if (!table || !ind || !out) return STEMGNN_ERR_INVALID_ARG;
+  const int Hi = static_cast<int>(H), Ki = static_cast<int>(K), Di = static_cast<int>(D);
+  if (D / 4 <= 16) k_codes_project<16><<<static_cast<unsigned>((N + 15) / 16), kBlock, 0, st>>>(table, ind, bias, N, Hi, Ki, Di, out);
+  else if (D / 4 <= 32) k_codes_project<32><<<static_cast<unsigned>((N + 7) / 8), kBlock, 0, st>>>(table, ind, bias, N, Hi, Ki, Di, out);
+  else k_codes_project<64><<<static_cast<unsigned>((N + 3) / 4), kBlock, 0, st>>>(table, ind, bias, N, Hi, Ki, Di, out);
+  STEMGNN_LAUNCH_CHECK();
+  return STEMGNN_OK;
+}
+
+int stemgnn_segment_colsum(const float* sums, int64_t K, int64_t D, float* db, void* stream_) {
+  if (K <= 0 || D <= 0 || !sums || !db) return STEMGNN_ERR_INVALID_ARG;
+  k_segment_colsum<<<static_cast<unsigned>((D + kBlock - 1) / kBlock), kBlock, 0, static_cast<hipStream_t>(stream_)>>>(
+      sums, static_cast<int>(K), static_cast<int>(D), db);
+  STEMGNN_LAUNCH_CHECK();
+  return STEMGNN_OK;
+}
+
+static int vq_assign_impl(const float* xp, int64_t N, int64_t H, int64_t Dc, const float* embed, int64_t K,
+                          int training, float* xn, float* norm, int64_t* ind, float* quant, const float* esq,
+                          float* sqerr, float sqerr_scale, void* workspace, size_t workspace_bytes, void* stream_) {
   hipStream_t st = static_cast<hipStream_t>(stream_);
   if (!vq_dims_ok(N, H, Dc, K)) return STEMGNN_ERR_INVALID_ARG;
   if (!fits_i32(N) || !fits_i32(N * H)) return STEMGNN_ERR_TOO_LARGE;
@@ -391,7 +506,7 @@ int stemgnn_vq_assign_fwd(const float* xp, int64_t N, int64_t H, int64_t Dc, con
     STEMGNN_HIP_TRY(hipMemsetAsync(sqerr, 0, sizeof(float), st));
     return STEMGNN_OK;
   }
-  if (!xp || !embed || !norm || !ind || !quant || !workspace) return STEMGNN_ERR_INVALID_ARG;
+  if (!xp || !embed || !norm || !ind || (!quant && !esq) || !workspace) return STEMGNN_ERR_INVALID_ARG;
   if (workspace_bytes < stemgnn_vq_workspace_bytes(N, H, Dc, K)) return STEMGNN_ERR_WORKSPACE;
   float* partial = reinterpret_cast<float*>(align_up(reinterpret_cast<uintptr_t>(workspace), 256));
   const int64_t rb = row_blocks(N);
@@ -401,9 +516,9 @@ int stemgnn_vq_assign_fwd(const float* xp, int64_t N, int64_t H, int64_t Dc, con
 #define STEMGNN_VQ_LAUNCH(CG)                                                                                         \
   do {                                                                                                                \
     if (x3) k_vq_assign<CG, true><<<grid, kBlock, 0, st>>>(xp, N, Hi, Dci, embed, Ki, training, xn, norm, ind, quant, \
-                                                            partial);                                                 \
+                                                            partial, esq);                                            \
     else k_vq_assign<CG, false><<<grid, kBlock, 0, st>>>(xp, N, Hi, Dci, embed, Ki, training, xn, norm, ind, quant,   \
-                                                          partial);                                                   \
+                                                          partial, esq);                                              \
   } while (0)
   if (K <= 32) STEMGNN_VQ_LAUNCH(1);
   else if (K <= 64) STEMGNN_VQ_LAUNCH(2);

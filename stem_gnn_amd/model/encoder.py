@@ -326,15 +326,57 @@ class Encoder(nn.Module):
                                          self._slope, p, seed, offset, stats)
         return ops.BnActDropFn.apply(z, None, None, None, None, False, 0.0, 0.0, act, self._slope, p, seed, offset)
 
+    def _encode_phase(self, x, graph, dense, etab):
+        """The whole layer stack as one library call per direction (ops.EncoderFn, csrc/phases.hip), or None when the
+        configuration needs the per-layer path (MoE layers, cumulative-average BatchNorm, a graph with hub rows,
+        gradients wanted in eval mode)."""
+        if any(self.moe_layer_flags) or not ops.encoder_phase_ok(graph, x, dense, etab):
+            return None
+        use_bn = self.normalize != "none"
+        wants_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if use_bn and not self.training and wants_grad:
+            return None
+        per_layer, params = [], []
+        keys = []
+        for i, (conv, norm) in enumerate(zip(self.layers, self.norms)):
+            if conv.normalize or not conv.root_weight or conv.in_channels != x.size(1) and i == 0:
+                return None
+            if use_bn and (norm.momentum is None or not norm.affine or (not norm.track_running_stats and not self.training)):
+                return None
+            last = i == self.num_layers - 1
+            key = (0, 0)
+            if self.training and not last and self.dropout.p > 0:
+                key = ops.next_dropout_key()
+                keys.append(key)
+            track = use_bn and norm.track_running_stats
+            per_layer.append(dict(running_mean=norm.running_mean if track else None,
+                                  running_var=norm.running_var if track else None,
+                                  num_batches_tracked=norm.num_batches_tracked if (track and self.training) else None,
+                                  eps=float(norm.eps), momentum=float(norm.momentum or 0.0), drop_key=key))
+            params += [conv.lin_l.weight, conv.lin_l.bias, conv.lin_r.weight,
+                       norm.weight if use_bn else None, norm.bias if use_bn else None]
+        cfg = dict(use_bn=use_bn, training=self.training, act=self._act_code, slope=self._slope,
+                   p=float(self.dropout.p) if self.training else 0.0)
+        self.last_dropout_keys = keys
+        return ops.EncoderFn.apply(x, graph, dense, etab, (cfg, per_layer), *params)
+
     def encode(self, x, edge_index, edge_attr=None):
+        dense, etab, etype = _split_edge_attr(edge_attr)
+        graph = as_graph(edge_index, x.size(0), etype)  # one structure build shared by all layers
+        self._last_env_reg = None
+        self.last_dropout_keys = []
+        z = self._encode_phase(x, graph, dense, etab)
+        if z is not None:
+            self._last_env_reg = self._zero_reg(z.device)
+            return z
+        return self._encode_layers(x, graph, edge_attr)
+
+    def _encode_layers(self, x, graph, edge_attr):
+        """Layer by layer through the single-op autograd functions (every configuration)."""
         z = x
         env_idx = 0
         env_reg_total: Optional[Tensor] = None
         env_layers = 0
-        self._last_env_reg = None
-        self.last_dropout_keys = []
-        dense, etab, etype = _split_edge_attr(edge_attr)
-        graph = as_graph(edge_index, x.size(0), etype)  # one structure build shared by all layers
 
         for i in range(self.num_layers):
             layer = self.layers[i]

@@ -217,7 +217,14 @@ class PretrainModel(nn.Module):
 
     def quantize(self, x, edge_index, edge_attr=None):
         z = self.encoder(x, edge_index, edge_attr)
-        quantize, indices, commit_loss, _ = self.vq(z)
+        skip = getattr(self.vq, "skip_codes", None)
+        if skip is not None:
+            self.vq.skip_codes = True  # the fourth output (per-head codes) is discarded right here, pt_model.py:113
+        try:
+            quantize, indices, commit_loss, _ = self.vq(z)
+        finally:
+            if skip is not None:
+                self.vq.skip_codes = skip
         return z, quantize, indices, commit_loss
 
     def forward(self, aug_g, g, topo_recon_ratio=1.0, bs=None, no_codebook=False, draws=None):

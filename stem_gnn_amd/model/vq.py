@@ -179,6 +179,9 @@ class VectorQuantize(nn.Module):
             ema_update=ema_update)
         self.codebook_size = codebook_size
         self.last_ortho_ids: Optional[Tensor] = None  # the randperm ids of the last training forward
+        # Set by a caller that discards the fourth output (PretrainModel.quantize, pt_model.py:113): forward then
+        # returns None in its place and never materialises the [N, H*Dc] per-head codes.
+        self.skip_codes = False
 
     @property
     def codebook(self):
@@ -209,6 +212,31 @@ class VectorQuantize(nn.Module):
     def _project(lin, t):
         return ops.linear(t, lin) if isinstance(lin, nn.Linear) else lin(t)
 
+    def _forward_phase(self, x, only_one, lead):
+        """(quantize, embed_ind, loss, None) through ops.VqFn: the whole module as one library call per direction."""
+        cb = self._codebook
+        h = self.heads
+        ids = None
+        self.last_ortho_ids = None
+        ortho = self.orthogonal_reg_weight if (self.training and self.has_codebook_orthogonal_loss) else 0.0
+        if ortho:
+            num_codes = cb.embed.shape[-2]
+            if self.orthogonal_reg_max_codes is not None and num_codes > self.orthogonal_reg_max_codes:
+                ids = self._rand_code_ids(num_codes, self.orthogonal_reg_max_codes, x.device)
+                self.last_ortho_ids = ids
+            else:
+                ids = torch.arange(num_codes, device=x.device)
+        cfg = dict(training=self.training, commit=self.commitment_weight if self.training else 0.0, ortho=ortho,
+                   ortho_ids=ids)
+        quantize, embed_ind, loss = ops.VqFn.apply(x, cb.embed, self.project_in.weight, self.project_in.bias,
+                                                   self.project_out.weight, self.project_out.bias, cfg)
+        if h == 1:
+            embed_ind = embed_ind.view(x.size(0))
+        if not only_one:
+            quantize = quantize.reshape(*lead, -1)
+            embed_ind = embed_ind.reshape(*lead, -1) if h > 1 else embed_ind.reshape(*lead)
+        return quantize, embed_ind, loss, None
+
     def forward(self, x, indices=None, mask=None, sample_codebook_temp=None, freeze_codebook=False):
         if indices is not None or mask is not None:
             raise NotImplementedError("indices= / mask= are never passed by the reference's call sites")
@@ -219,6 +247,10 @@ class VectorQuantize(nn.Module):
         n = x.size(0)
         h, dc = self.heads, self.codebook_dim
         cb = self._codebook
+        phase = (self.skip_codes and cb._initted_host and self.has_projections and x.is_cuda
+                 and x.dtype == torch.float32 and not (self.training and cb.ema_update and not freeze_codebook))
+        if phase:
+            return self._forward_phase(x, only_one, None if only_one else lead)
         xp = self._project(self.project_in, x).float()  # vq.py:881; the codebook forces fp32 (vq.py:623,634)
         if not cb._initted_host:
             with torch.no_grad():

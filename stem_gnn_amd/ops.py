@@ -13,7 +13,7 @@ from typing import Optional, Tuple
 import torch
 from torch import Tensor
 
-from ._lib import check, lib
+from ._lib import EncoderCfg, GraphView, SageLayer, VqParams, check, lib
 
 
 _raw_stream = torch._C._cuda_getCurrentRawStream  # the hipStream_t of torch's current stream, without the Stream object
@@ -419,6 +419,111 @@ class MeanAggFn(torch.autograd.Function):
 
 
 # ----------------------------------------------------------------------------------------
+# Encoder phase: the whole layer stack in one call per direction (csrc/phases.hip)
+# ----------------------------------------------------------------------------------------
+def graph_view(graph, need_transpose: bool) -> GraphView:
+    """stemgnn_graph_view of a GraphStructure (pointers only; the structure owns the memory)."""
+    if need_transpose:
+        graph.ensure_transpose()
+    gv = GraphView()
+    gv.num_nodes = graph.num_nodes
+    gv.active_rows = graph.num_nodes if graph.active_rows is None else graph.active_rows
+    gv.rowptr, gv.src, gv.eid, gv.etype_slot = _p(graph.rowptr), _p(graph.src), _p(graph.eid), _p(graph.etype_slot)
+    gv.rowptr_t, gv.dst_t, gv.eid_t = _p(graph.rowptr_t), _p(graph.dst_t), _p(graph.eid_t)
+    gv.etype_slot_t, gv.inv_deg = _p(graph.etype_slot_t), _p(graph.inv_deg)
+    return gv
+
+
+def encoder_phase_ok(graph, x: Tensor, dense: Optional[Tensor], etab: Optional[Tensor]) -> bool:
+    """The fused phase covers what the pretraining path runs: fp32 CUDA rows, a graph without heavy rows (no split
+    plan on either side) and at most one edge-attribute form."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.size(1) % 4 == 0):
+        return False
+    if graph.num_nodes != x.size(0) or graph.num_nodes == 0:
+        return False
+    if dense is not None and (dense.requires_grad or tuple(dense.shape) != (graph.num_edges, x.size(1))):
+        return False
+    if etab is not None and (graph.etype_slot is None or etab.size(1) != x.size(1)):
+        return False
+    if dense is not None and etab is not None:
+        return False
+    return graph.split_plan("in") is None and graph.split_plan("out") is None
+
+
+class EncoderFn(torch.autograd.Function):
+    """Encoder.forward for the 'sage' backbone without MoE layers (reference model/encoder.py:279-323) as ONE library
+    call, and its backward as one more.  ``meta`` = (cfg dict, per-layer dicts with the BatchNorm buffers and the
+    dropout key); ``params`` = per layer (lin_l.weight, lin_l.bias or None, lin_r.weight, bn.weight or None,
+    bn.bias or None)."""
+
+    @staticmethod
+    def _layers(meta, params, grads=None):
+        cfg_d, per_layer = meta
+        L = len(per_layer)
+        arr = (SageLayer * L)()
+        for l, info in enumerate(per_layer):
+            w_l, b_l, w_r, bn_w, bn_b = params[5 * l:5 * l + 5]
+            y = arr[l]
+            y.out_dim, y.in_dim = w_l.shape
+            y.w_l, y.b_l, y.w_r, y.bn_weight, y.bn_bias = _p(w_l), _p(b_l), _p(w_r), _p(bn_w), _p(bn_b)
+            y.bn_running_mean, y.bn_running_var = _p(info["running_mean"]), _p(info["running_var"])
+            y.bn_num_batches_tracked = _p(info["num_batches_tracked"])
+            y.bn_eps, y.bn_momentum = info["eps"], info["momentum"]
+            y.drop_seed, y.drop_offset = info["drop_key"]
+            if grads is not None:
+                g = grads[5 * l:5 * l + 5]
+                y.g_w_l, y.g_b_l, y.g_w_r, y.g_bn_weight, y.g_bn_bias = (_p(t) for t in g)
+        cfg = EncoderCfg(L, int(cfg_d["use_bn"]), int(cfg_d["training"]), int(cfg_d["act"]), float(cfg_d["slope"]),
+                         float(cfg_d["p"]))
+        return arr, cfg
+
+    @staticmethod
+    def forward(ctx, x, graph, dense, etab, meta, *params):
+        x = x.contiguous()
+        for t in params:
+            if t is not None:
+                _req(t, torch.float32, "encoder parameter")
+        arr, cfg = EncoderFn._layers(meta, params)
+        need_bwd = any(t is not None and t.requires_grad for t in params) or x.requires_grad
+        gv = graph_view(graph, need_bwd)
+        N, A = gv.num_nodes, gv.active_rows
+        nbytes = lib.stemgnn_encoder_save_bytes(N, A, arr, ctypes.byref(cfg))
+        if nbytes == 0:
+            raise RuntimeError("encoder phase: unsupported layer configuration")
+        save = _workspace(nbytes, x.device)
+        z = torch.empty(N, arr[len(arr) - 1].out_dim, dtype=torch.float32, device=x.device)
+        T = 0 if etab is None else etab.size(0)
+        check(lib.stemgnn_encoder_fwd(ctypes.byref(gv), _p(x), _p(dense), _p(etab), T, arr, ctypes.byref(cfg), _p(z),
+                                      _p(save), save.numel(), _stream()), "encoder_fwd")
+        ctx.graph, ctx.meta = graph, meta
+        ctx.save_for_backward(x, dense, etab, save, z, *params)
+        return z
+
+    @staticmethod
+    def backward(ctx, g_z):
+        x, dense, etab, save, z, *params = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        grads = [torch.empty_like(t) if (t is not None and need[5 + i]) else None for i, t in enumerate(params)]
+        # a weight gradient is produced together with its layer's bias gradient: give lin_r's product a target
+        # whenever either is wanted (see stemgnn_encoder_bwd)
+        for l in range(len(params) // 5):
+            if grads[5 * l + 1] is not None and grads[5 * l + 2] is None:
+                grads[5 * l + 2] = torch.empty_like(params[5 * l + 2])
+        arr, cfg = EncoderFn._layers(ctx.meta, params, grads)
+        gv = graph_view(ctx.graph, True)
+        N, A = gv.num_nodes, gv.active_rows
+        g_x = torch.empty_like(x) if need[0] else None
+        scratch = _workspace(lib.stemgnn_encoder_bwd_scratch_bytes(N, A, arr, ctypes.byref(cfg)), x.device)
+        g_work = g_z.contiguous()
+        T = 0 if etab is None else etab.size(0)
+        check(lib.stemgnn_encoder_bwd(ctypes.byref(gv), _p(x), _p(dense), _p(etab), T, arr, ctypes.byref(cfg),
+                                      _p(g_work), _p(g_x), _p(save), save.numel(), _p(scratch), scratch.numel(),
+                                      _stream()), "encoder_bwd")
+        out = [g if need[5 + i] else None for i, g in enumerate(grads)]
+        return (g_x, None, None, None, None, *out)
+
+
+# ----------------------------------------------------------------------------------------
 # K4
 # ----------------------------------------------------------------------------------------
 def bn_stats(y: Tensor, eps: float, running_mean: Optional[Tensor], running_var: Optional[Tensor],
@@ -708,6 +813,73 @@ class VqAssignFn(torch.autograd.Function):
         check(lib.stemgnn_vq_assign_bwd(_p(g_quant), _p(g_loss), ctx.loss_weight, _p(xp), _p(norm), _p(ind), _p(embed), N,
                                         H, Dc, K, _p(g_xp), _stream()), "vq_assign_bwd")
         return g_xp, None, None, None, None, None
+
+
+class VqFn(torch.autograd.Function):
+    """VectorQuantize.forward (reference model/vq.py:849-1064) for callers that use (quantize, embed_ind, loss) and
+    not the per-head codes, as ONE library call per direction (csrc/phases.hip: stemgnn_vq_fwd / _bwd): project_in,
+    fused cosine assignment, commitment + orthogonal terms, and project_out read off the table of projected code
+    rows; in the backward project_out's weight gradient comes from per-code segment sums.  The codebook receives the
+    orthogonal term's gradient only (the quantised rows are detached in the reference, vq.py:931-937)."""
+
+    @staticmethod
+    def _params(z, embed, w_in, b_in, w_out, b_out, cfg, grads=None):
+        H, K, Dc = embed.shape
+        p = VqParams()
+        p.dim, p.heads, p.code_dim, p.codebook_size = z.size(1), H, Dc, K
+        p.w_in, p.b_in, p.w_out, p.b_out, p.embed = _p(w_in), _p(b_in), _p(w_out), _p(b_out), _p(embed)
+        p.commitment_weight, p.ortho_weight = float(cfg["commit"]), float(cfg["ortho"])
+        ids = cfg["ortho_ids"]
+        p.ortho_ids, p.num_ortho_ids = _p(ids), 0 if ids is None else ids.numel()
+        if grads is not None:
+            p.g_w_in, p.g_b_in, p.g_w_out, p.g_b_out, p.g_embed = (_p(t) for t in grads)
+        return p
+
+    @staticmethod
+    def forward(ctx, z, embed, w_in, b_in, w_out, b_out, cfg):
+        z = z.contiguous()
+        tensors = [embed, w_in, b_in, w_out, b_out]
+        for t in (z, *tensors):
+            if t is not None:
+                _req(t.detach(), torch.float32, "vq operand")
+        if embed.dim() != 3 or tuple(w_in.shape) != (embed.size(0) * embed.size(2), z.size(1)) or \
+                tuple(w_out.shape) != (z.size(1), embed.size(0) * embed.size(2)):
+            raise RuntimeError("vq phase: projection / codebook shapes do not match")
+        if cfg["ortho_ids"] is not None:
+            _req(cfg["ortho_ids"], torch.int64, "ortho_ids", 1)
+        p = VqFn._params(z, embed, w_in, b_in, w_out, b_out, cfg)
+        N, H = z.size(0), embed.size(0)
+        save = _workspace(lib.stemgnn_vq_save_bytes(ctypes.byref(p), N), z.device)
+        quantize = torch.empty_like(z)
+        ind = torch.empty(N, H, dtype=torch.int64, device=z.device)
+        loss = torch.empty(1, dtype=torch.float32, device=z.device)
+        check(lib.stemgnn_vq_fwd(ctypes.byref(p), _p(z), N, int(bool(cfg["training"])), _p(quantize), _p(ind), _p(loss),
+                                 _p(save), save.numel(), _stream()), "vq_fwd")
+        ctx.cfg = cfg
+        ctx.save_for_backward(z, ind, save, embed, w_in, b_in, w_out, b_out)
+        ctx.mark_non_differentiable(ind)
+        return quantize, ind, loss
+
+    @staticmethod
+    def backward(ctx, g_quantize, _g_ind, g_loss):
+        z, ind, save, embed, w_in, b_in, w_out, b_out = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        tensors = [w_in, b_in, w_out, b_out, embed]
+        wanted = [need[2], need[3], need[4], need[5], need[1]]
+        if wanted[1] and not wanted[0]:
+            wanted[0] = True  # project_in's bias gradient is produced with its weight gradient
+        grads = [torch.empty_like(t) if (t is not None and w) else None for t, w in zip(tensors, wanted)]
+        p = VqFn._params(z, embed, w_in, b_in, w_out, b_out, ctx.cfg, grads)
+        N = z.size(0)
+        g_z = torch.empty_like(z) if need[0] else None
+        scratch = _workspace(lib.stemgnn_vq_bwd_scratch_bytes(ctypes.byref(p), N), z.device)
+        gq = None if g_quantize is None else g_quantize.contiguous()
+        gl = None if g_loss is None else g_loss.reshape(1).contiguous().float()
+        check(lib.stemgnn_vq_bwd(ctypes.byref(p), _p(z), N, _p(ind), _p(gq), _p(gl), _p(g_z), _p(save), save.numel(),
+                                 _p(scratch), scratch.numel(), _stream()), "vq_bwd")
+        g_w_in, g_b_in, g_w_out, g_b_out, g_embed = grads
+        return (g_z, g_embed if need[1] else None, g_w_in if need[2] else None, g_b_in if need[3] else None,
+                g_w_out if need[4] else None, g_b_out if need[5] else None, None)
 
 
 def vq_ema_stats(xp: Tensor, norm: Tensor, ind: Tensor, codebook_size: int) -> Tuple[Tensor, Tensor]:
