@@ -96,6 +96,15 @@ __device__ __forceinline__ void split3(float4 a, uint2& h, uint2& m, uint2& l) {
   m = make_uint2(pack_hi(mb[0], mb[1]), pack_hi(mb[2], mb[3]));
   l = make_uint2(pack_hi(lb[0], lb[1]), pack_hi(lb[2], lb[3]));
 }
+// 8 consecutive values -> 16 bytes of each plane
+__device__ __forceinline__ void split8(float4 a, float4 b, uint4& h, uint4& m, uint4& l) {
+  uint2 h0, m0, l0, h1, m1, l1;
+  split3(a, h0, m0, l0);
+  split3(b, h1, m1, l1);
+  h = make_uint4(h0.x, h0.y, h1.x, h1.y);
+  m = make_uint4(m0.x, m0.y, m1.x, m1.y);
+  l = make_uint4(l0.x, l0.y, l1.x, l1.y);
+}
 // q[i] = columns c .. c+3 of contraction row 4 (tid & 7) + i (c = 4 (tid >> 3)): split every element and store column j
 // as the 4 consecutive contraction steps of plane row c + j, i.e. the transposed image [column][32 k] the fragment
 // reads want, for an operand whose contraction index is its SLOW dimension.
@@ -134,6 +143,12 @@ __device__ __forceinline__ floatx16 mfma_x3(const bf16x8 (&a)[3], const bf16x8 (
   c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
   return c;
 }
+
+// csrc/linear.hip: row-split count of a weight-gradient product and the fixed-order reduction of its partial slabs
+// (out[i] = sum_s partial[s][i]; the second family, e.g. the bias gradient, is optional), shared with csrc/pgemm.hip
+int plane_split_count(int64_t M, int64_t out_tiles);
+int reduce_splits_launch(const float* partial, int splits, int64_t n, float* out, const float* partial2, int64_t n2,
+                         float* out2, hipStream_t st);
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }

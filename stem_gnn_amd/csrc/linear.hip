@@ -216,8 +216,10 @@ k_linear_fwd_x3(const float* __restrict__ x1, const float* __restrict__ w1, int 
   constexpr int TN = kBN / (32 * WN);
   constexpr int FA = BM * 8 / kBlock;  // float4 of an activation chunk per thread
   constexpr int PA = BM * kLdP, PB = kBN * kLdP;  // bytes of one bf16 plane
-  __shared__ __attribute__((aligned(16))) unsigned char sA[3 * PA];  // planes h, m, l of the activation chunk
-  __shared__ __attribute__((aligned(16))) unsigned char sB[3 * PB];  // planes h, m, l of the weight chunk
+  // planes h, m, l of the activation chunk, then of the weight chunk; the epilogue reuses the memory as an fp32 tile
+  __shared__ __attribute__((aligned(16))) unsigned char smem[3 * PA + 3 * PB];
+  unsigned char* const sA = smem;
+  unsigned char* const sB = smem + 3 * PA;
   __shared__ float s_stats[WM][2][kBN];  // [wave_m][sum|sumsq][n]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -319,6 +321,63 @@ k_linear_fwd_x3(const float* __restrict__ x1, const float* __restrict__ w1, int 
     __syncthreads();
   }
 
+  // ---- epilogue (128-row tiles): the accumulators hold one column and 16 scattered rows per lane, which as direct
+  // stores is 64 four-byte store instructions per lane; measured on the plane-operand twin of this tile
+  // (tools/pgemm_ablate.py) those stores cost more than the tile's matrix work.  The tile goes through LDS instead,
+  // 64 rows at a time, and leaves as 16-byte stores of whole 512-byte rows (8 per thread).
+  if (BM == 128) {
+    constexpr int kLdT = kBN + 4;  // fp32 row stride of the staging tile (64 x 132 x 4 B = 33 KB of the 60 KB)
+    float* tile = reinterpret_cast<float*>(smem);
+    float s1[TN], s2[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) s1[tn] = s2[tn] = 0.f;
+    for (int half = 0; half < 2; ++half) {
+      if (wm == half) {
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          const int nl = wn * 32 * TN + tn * 32 + lj;
+          const bool col_ok = n0 + nl < N;
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int rl = tm * 32 + 4 * hi + (r & 3) + 8 * (r >> 2);
+              const float v = acc[tm][tn][r] + bias_v[tn];
+              tile[rl * kLdT + nl] = v;
+              if (STATS && col_ok && m0 + half * 64 + rl < M) { s1[tn] += v; s2[tn] += v * v; }
+            }
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int rl = (tid >> 5) + 8 * i, c4 = tid & 31;
+        const int64_t m = m0 + half * 64 + rl;
+        if (m < M && n0 + 4 * c4 < N) st4(y + m * N + n0 + 4 * c4, ld4(tile + rl * kLdT + 4 * c4));
+      }
+      __syncthreads();
+    }
+    if (STATS) {
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const int nl = wn * 32 * TN + tn * 32 + lj;
+        float a = s1[tn], b = s2[tn];
+        a += __shfl_xor(a, 32, 64);
+        b += __shfl_xor(b, 32, 64);
+        if (hi == 0) { s_stats[wm][0][nl] = a; s_stats[wm][1][nl] = b; }
+      }
+      __syncthreads();
+      if (tid < kBN && n0 + tid < N) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) { t1 += s_stats[w][0][tid]; t2 += s_stats[w][1][tid]; }
+        float* p = stats_partial + (stats_block0 + blockIdx.x) * 2 * N;
+        p[n0 + tid] = t1;
+        p[N + n0 + tid] = t2;
+      }
+    }
+    return;
+  }
   // ---- epilogue: bias, store (two 128-byte row segments per store instruction), column stats.
   // The bias was loaded before the main loop: the epilogue issues stores only, so no
   // s_waitcnt vmcnt(0) ever serialises them (vmcnt counts stores too).
@@ -659,52 +718,64 @@ k_code_segment_sums(const int64_t* __restrict__ ind, int H, int K, const float* 
 
 // C(m, n) = sum_k A(m, k) B(k, n) for SMALL operands with arbitrary element strides (codebook-sized products: the
 // project_out table P_h = embed_h W_out_h^T and dW_out_h = S_h^T embed_h): plain fp32 FMA in a fixed k order --
-// exact fp32 arithmetic, bit-reproducible.  64 x 64 tile, 16-deep chunks, 4 x 4 outputs per thread; blockIdx.z = batch.
+// exact fp32 arithmetic, bit-reproducible.  blockIdx.z = batch.
 struct SmallGemm {
   const float* a; int64_t a_m, a_k, a_b;   // element strides of A along m, k and per batch
   const float* b; int64_t b_k, b_n, b_b;
   float* c; int64_t c_m, c_n, c_b;
   int M, N, K;
 };
+template <int T>  // T x T output tile per block: 32 (many small blocks: codebook-sized problems are latency bound) or 64
 __global__ void __launch_bounds__(kBlock) k_small_gemm(SmallGemm p) {
-  constexpr int T = 64, KC = 16;
+  constexpr int KC = 32, R = T / 16, PER = T * KC / kBlock;  // outputs per thread R x R, staged elements per thread
   __shared__ float sA[KC][T + 1], sB[KC][T + 1];
   const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
   const int m0 = blockIdx.x * T, n0 = blockIdx.y * T;
   const float* A = p.a + blockIdx.z * p.a_b;
   const float* B = p.b + blockIdx.z * p.b_b;
   float* C = p.c + blockIdx.z * p.c_b;
-  float acc[4][4];
+  float acc[R][R];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < R; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    for (int j = 0; j < R; ++j) acc[i][j] = 0.f;
+  float ra[PER], rb[PER];
+  auto fetch = [&](int k0) {  // the next chunk travels in registers while the current one is multiplied
+#pragma unroll
+    for (int t = 0; t < PER; ++t) {
+      const int idx = t * kBlock + tid;
+      const int kk = idx / T, mm = idx % T;
+      const int k = k0 + kk;
+      ra[t] = (k < p.K && m0 + mm < p.M) ? A[static_cast<int64_t>(m0 + mm) * p.a_m + k * p.a_k] : 0.f;
+      rb[t] = (k < p.K && n0 + mm < p.N) ? B[static_cast<int64_t>(k) * p.b_k + (n0 + mm) * p.b_n] : 0.f;
+    }
+  };
+  fetch(0);
   for (int k0 = 0; k0 < p.K; k0 += KC) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int idx = t * kBlock + tid;  // 1024 elements of each 16 x 64 chunk
-      const int kk = idx >> 6, mm = idx & 63;
-      const int k = k0 + kk;
-      sA[kk][mm] = (k < p.K && m0 + mm < p.M) ? A[static_cast<int64_t>(m0 + mm) * p.a_m + k * p.a_k] : 0.f;
-      sB[kk][mm] = (k < p.K && n0 + mm < p.N) ? B[static_cast<int64_t>(k) * p.b_k + (n0 + mm) * p.b_n] : 0.f;
+    for (int t = 0; t < PER; ++t) {
+      const int idx = t * kBlock + tid;
+      sA[idx / T][idx % T] = ra[t];
+      sB[idx / T][idx % T] = rb[t];
     }
     __syncthreads();
+    if (k0 + KC < p.K) fetch(k0 + KC);
 #pragma unroll
     for (int kk = 0; kk < KC; ++kk) {
-      float a[4], b[4];
+      float a[R], b[R];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { a[i] = sA[kk][ty + 16 * i]; b[i] = sB[kk][tx + 16 * i]; }
+      for (int i = 0; i < R; ++i) { a[i] = sA[kk][ty + 16 * i]; b[i] = sB[kk][tx + 16 * i]; }
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < R; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+        for (int j = 0; j < R; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
     }
     __syncthreads();
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < R; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < R; ++j) {
       const int m = m0 + ty + 16 * i, n = n0 + tx + 16 * j;
       if (m < p.M && n < p.N) C[static_cast<int64_t>(m) * p.c_m + static_cast<int64_t>(n) * p.c_n] = acc[i][j];
     }
@@ -838,6 +909,19 @@ inline int pick_splits(int64_t M, int64_t tiles) {
 inline int64_t out_tiles(int64_t N, int64_t K) { return ((N + kBN - 1) / kBN) * ((K + kBN - 1) / kBN); }
 
 }  // namespace
+}  // namespace stemgnn
+
+namespace stemgnn {
+int plane_split_count(int64_t M, int64_t tiles) { return pick_splits(M, tiles); }
+int reduce_splits_launch(const float* partial, int splits, int64_t n, float* out, const float* partial2, int64_t n2,
+                         float* out2, hipStream_t st) {
+  const int blocks1 = static_cast<int>((n / 4 + 15) / 16);
+  const int blocks2 = (partial2 && out2) ? static_cast<int>((n2 / 4 + 15) / 16) : 0;
+  k_reduce_splits<<<static_cast<unsigned>(blocks1 + blocks2), kBlock, 0, st>>>(partial, splits, n, out, partial2, n2,
+                                                                              out2, blocks1);
+  STEMGNN_LAUNCH_CHECK();
+  return STEMGNN_OK;
+}
 }  // namespace stemgnn
 
 using namespace stemgnn;
@@ -1015,8 +1099,14 @@ int stemgnn_small_gemm(const float* a, int64_t a_m, int64_t a_k, int64_t a_batch
     return STEMGNN_ERR_INVALID_ARG;
   SmallGemm p{a, a_m, a_k, a_batch, b, b_k, b_n, b_batch, c, c_m, c_n, c_batch, static_cast<int>(M),
               static_cast<int>(N), static_cast<int>(K)};
-  dim3 grid(static_cast<unsigned>((M + 63) / 64), static_cast<unsigned>((N + 63) / 64), static_cast<unsigned>(batches));
-  k_small_gemm<<<grid, kBlock, 0, static_cast<hipStream_t>(stream_)>>>(p);
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  if (((M + 63) / 64) * ((N + 63) / 64) * batches >= 512) {
+    dim3 grid(static_cast<unsigned>((M + 63) / 64), static_cast<unsigned>((N + 63) / 64), static_cast<unsigned>(batches));
+    k_small_gemm<64><<<grid, kBlock, 0, st>>>(p);
+  } else {
+    dim3 grid(static_cast<unsigned>((M + 31) / 32), static_cast<unsigned>((N + 31) / 32), static_cast<unsigned>(batches));
+    k_small_gemm<32><<<grid, kBlock, 0, st>>>(p);
+  }
   STEMGNN_LAUNCH_CHECK();
   return STEMGNN_OK;
 }

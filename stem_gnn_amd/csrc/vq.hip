@@ -326,11 +326,16 @@ k_codes_project(const float* __restrict__ table, const int64_t* __restrict__ ind
 // head, so any head's segment sums add up to the column sums of the gradient): project_out's bias gradient.
 __global__ void __launch_bounds__(kBlock) k_segment_colsum(const float* __restrict__ sums, int K, int D,
                                                            float* __restrict__ db) {
-  const int d = blockIdx.x * kBlock + threadIdx.x;
-  if (d >= D) return;
-  float s = 0.f;
-  for (int k = 0; k < K; ++k) s += sums[static_cast<int64_t>(k) * D + d];
-  db[d] = s;
+  // 64 columns x 4 row slices per block; slices added in index order (reproducible)
+  __shared__ float red[4][64];
+  const int c = threadIdx.x & 63, s = threadIdx.x >> 6;
+  const int d = blockIdx.x * 64 + c;
+  float a = 0.f;
+  if (d < D)
+    for (int k = s; k < K; k += 4) a += sums[static_cast<int64_t>(k) * D + d];
+  red[s][c] = a;
+  __syncthreads();
+  if (s == 0 && d < D) db[d] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
 }
 
 __global__ void __launch_bounds__(kBlock) k_sum_partials(const float* __restrict__ partial, int64_t n, double scale,
@@ -489,7 +494,7 @@ int stemgnn_codes_project(const float* table, const int64_t* ind, const float* b
 
 int stemgnn_segment_colsum(const float* sums, int64_t K, int64_t D, float* db, void* stream_) {
   if (K <= 0 || D <= 0 || !sums || !db) return STEMGNN_ERR_INVALID_ARG;
-  k_segment_colsum<<<static_cast<unsigned>((D + kBlock - 1) / kBlock), kBlock, 0, static_cast<hipStream_t>(stream_)>>>(
+  k_segment_colsum<<<static_cast<unsigned>((D + 63) / 64), kBlock, 0, static_cast<hipStream_t>(stream_)>>>(
       sums, static_cast<int>(K), static_cast<int>(D), db);
   STEMGNN_LAUNCH_CHECK();
   return STEMGNN_OK;
