@@ -291,6 +291,13 @@ int stemgnn_linear_fwd(const float* x1, const float* w1, int64_t k1, const float
                        const float* bias, int64_t num_rows, int64_t out_dim, float* y, float* stats_partial,
                        int64_t* stats_blocks_host, int64_t x1_rows, void* stream);
 
+/* The same with a row limit on the OUTPUT: rows >= store_rows of y are computed (they count in stats_partial) but
+ * not written -- a BatchNorm layer whose caller reads only its leading rows (the EMA teacher's last layer,
+ * pt_model.py:93-97: statistics over all rows, values of the seed rows).  y may be a [store_rows, N] buffer. */
+int stemgnn_linear_fwd_rows(const float* x1, const float* w1, int64_t k1, const float* x2, const float* w2, int64_t k2,
+                            const float* bias, int64_t num_rows, int64_t out_dim, float* y, float* stats_partial,
+                            int64_t* stats_blocks_host, int64_t x1_rows, int64_t store_rows, void* stream);
+
 /* Backward w.r.t. the input of y = x w^T: dx[M, K] = dy[M, N] w[N, K] (autograd of nn.Linear, reference
  * model/encoder.py:83-87, model/vq.py:881,1041).  The weight is read as stored; no transposed copy is made.
  * N, K multiples of 4. */
@@ -362,6 +369,14 @@ int stemgnn_segment_colsum(const float* sums, int64_t codebook_size, int64_t dim
 int stemgnn_small_gemm(const float* a, int64_t a_m, int64_t a_k, int64_t a_batch, const float* b, int64_t b_k,
                        int64_t b_n, int64_t b_batch, float* c, int64_t c_m, int64_t c_n, int64_t c_batch, int64_t M,
                        int64_t N, int64_t K, int64_t batches, void* stream);
+
+/* stemgnn_vq_assign_bwd with project_out's backward-data product inside (code_dim <= 128, default matrix-core
+ * mode): g_out [N, D] is the gradient of project_out's OUTPUT, w_out [D, H*Dc] its weight as stored; the
+ * [N, H*Dc] gradient of the quantised rows (g_out w_out) lives only in the kernel's accumulators. */
+int stemgnn_vq_assign_bwd_fused(const float* g_out, int64_t dim, const float* w_out, const float* g_loss,
+                                float commit_weight, const float* xp, const float* norm, const int64_t* ind,
+                                const float* embed, int64_t num_rows, int64_t heads, int64_t code_dim,
+                                int64_t codebook_size, float* g_xp, void* stream);
 
 /* K10: EMA statistics (vq.py:661-672): bins [H, K] = #rows per code, embed_sum [H, K, Dc]
  * = sum of the normalised rows xp/max(norm,1e-12) per code.  Deterministic (sorted segment sums). */
@@ -545,6 +560,9 @@ typedef struct stemgnn_encoder_cfg {
   int32_t act;                       /* 1: relu / leaky relu between layers */
   float negative_slope;
   float dropout_p;
+  int64_t out_rows;                  /* forward only: z holds rows [0, out_rows) of the output (the last layer's
+                                        product and normalisation are not written past them; its BatchNorm statistics
+                                        still run over every row).  <= 0 or >= N: all rows */
 } stemgnn_encoder_cfg;
 
 /* Encoder.forward (model/encoder.py:279-323) for the 'sage' backbone without MoE layers: per layer K1 over the
@@ -552,7 +570,7 @@ typedef struct stemgnn_encoder_cfg {
  * finalisation, normalise + activation + dropout (none after the last layer).  Exactly one of edge_attr (dense
  * [E, D]) / etab ([T, D], with graph->etype_slot) may be given, or neither.  The graph must not need the heavy-row
  * split (no row with more than 128 edges).  `save` keeps what the backward needs (stemgnn_encoder_save_bytes);
- * z [N, out_dim of the last layer]. */
+ * z [N (or cfg->out_rows), out_dim of the last layer]. */
 size_t stemgnn_encoder_save_bytes(int64_t num_nodes, int64_t active_rows, const stemgnn_sage_layer* layers,
                                   const stemgnn_encoder_cfg* cfg);
 int stemgnn_encoder_fwd(const stemgnn_graph_view* graph, const float* x, const float* edge_attr, const float* etab,
@@ -599,6 +617,50 @@ size_t stemgnn_vq_bwd_scratch_bytes(const stemgnn_vq_params* p, int64_t num_rows
 int stemgnn_vq_bwd(const stemgnn_vq_params* p, const float* z, int64_t num_rows, const int64_t* ind,
                    const float* g_quantize, const float* g_loss, float* g_z, const void* save, size_t save_bytes,
                    void* scratch, size_t scratch_bytes, void* stream);
+
+/* The decoders that read the decoder query in PretrainModel.forward (model/pt_model.py:39-102,128-131). */
+typedef struct stemgnn_heads_params {
+  int64_t dim;                       /* hidden width D of the query */
+  int64_t in_dim;                    /* out_features of feat_recon_decoder (= feature width of x) */
+  const float* w_feat;               /* feat_recon_decoder [in_dim, D] */
+  const float* b_feat;
+  const float* w_topo;               /* topo_recon_decoder.lin [D, D] (InnerProductDecoder, encoder.py:353-366) */
+  const float* b_topo;
+  const float* w_ts;                 /* topo_sem_recon_decoder [D, 2D] */
+  const float* b_ts;
+  const float* w_sem;                /* sem_projector [D, D] */
+  const float* b_sem;
+  float* g_w_feat;                   /* gradients (backward only) */
+  float* g_b_feat;
+  float* g_w_topo;
+  float* g_b_topo;
+  float* g_w_ts;
+  float* g_b_ts;
+  float* g_w_sem;
+  float* g_b_sem;
+} stemgnn_heads_params;
+
+/* The four reconstruction losses of one step, losses[4] = (feat_recon, topo_recon, topo_sem_recon, sem_recon), each
+ * UNWEIGHTED (the caller applies the lambdas).  k = number of sampled edges (max(int(E * ratio), 1)); the draws are
+ * keyed by (seed, off_*) like stemgnn_sample_edges / stemgnn_negative_sample and returned for replay: topo_perm [k],
+ * topo_edges int64 [2, 2k] (columns [0, k) the sampled positives, [k, 2k) the negatives), ts_perm [k], ts_edges
+ * [2, k], ts_type [k].  edge_index int64 [2, E] / edge_type int64 [E] are the batch graph's COO; `graph` its
+ * by-target CSR (negative sampling looks positives up through it).  x_feat [N, in_dim], z_teacher [>= bs, D].
+ * Everything is enqueued on `stream` (with STEMGNN_HEADS_LANES=1 the three heads' chains run on internal side
+ * streams forked from and joined to it). */
+size_t stemgnn_heads_save_bytes(const stemgnn_heads_params* p, int64_t num_nodes, int64_t num_edges, int64_t bs, int64_t k);
+int stemgnn_heads_fwd(const stemgnn_heads_params* p, const stemgnn_graph_view* graph, const int64_t* edge_index,
+                      const int64_t* edge_type, int64_t num_edges, const float* etab, int64_t num_types, const float* q,
+                      const float* x_feat, const float* z_teacher, int64_t bs, int64_t k, uint64_t seed,
+                      uint64_t off_topo, uint64_t off_neg, uint64_t off_ts, int64_t* topo_perm, int64_t* topo_edges,
+                      int64_t* ts_perm, int64_t* ts_edges, int64_t* ts_type, float* losses, void* save,
+                      size_t save_bytes, void* stream);
+/* Backward: g_losses [4] device scalars -> g_q [N, D] (overwritten) and the parameter gradients of the struct. */
+size_t stemgnn_heads_bwd_scratch_bytes(const stemgnn_heads_params* p, int64_t num_nodes, int64_t bs, int64_t k);
+int stemgnn_heads_bwd(const stemgnn_heads_params* p, int64_t num_nodes, const float* q, const float* x_feat,
+                      const float* z_teacher, int64_t bs, int64_t k, const int64_t* topo_edges, const int64_t* ts_edges,
+                      const float* g_losses, float* g_q, const void* save, size_t save_bytes, int64_t num_edges,
+                      void* scratch, size_t scratch_bytes, void* stream);
 
 #ifdef __cplusplus
 }

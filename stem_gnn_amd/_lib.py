@@ -55,10 +55,17 @@ class VqParams(ctypes.Structure):
                 ("g_embed", P)]
 
 
+class HeadsParams(ctypes.Structure):
+    """stemgnn_heads_params (include/stemgnn.h)."""
+    _fields_ = [("dim", I64), ("in_dim", I64), ("w_feat", P), ("b_feat", P), ("w_topo", P), ("b_topo", P), ("w_ts", P),
+                ("b_ts", P), ("w_sem", P), ("b_sem", P), ("g_w_feat", P), ("g_b_feat", P), ("g_w_topo", P),
+                ("g_b_topo", P), ("g_w_ts", P), ("g_b_ts", P), ("g_w_sem", P), ("g_b_sem", P)]
+
+
 class EncoderCfg(ctypes.Structure):
     """stemgnn_encoder_cfg (include/stemgnn.h)."""
     _fields_ = [("num_layers", I32), ("use_bn", I32), ("training", I32), ("act", I32), ("negative_slope", c_float),
-                ("dropout_p", c_float)]
+                ("dropout_p", c_float), ("out_rows", I64)]
 
 _SIGNATURES = {
     "stemgnn_abi_version": (c_int, []),
@@ -85,6 +92,7 @@ _SIGNATURES = {
     "stemgnn_sage_agg_fwd": (c_int, [P, I64, I64, P, P, P, P, P, P, I64, P, P]),
     "stemgnn_sage_agg_bwd": (c_int, [P, P, I64, I64, P, P, P, P, P, P, P, I64, P, P]),
     "stemgnn_sage_agg_bwd_acc": (c_int, [P, P, I64, I64, P, P, P, P, P, P, P, I64, P, P]),
+    "stemgnn_vq_assign_bwd_fused": (c_int, [P, I64, P, P, c_float, P, P, P, P, I64, I64, I64, I64, P, P]),
     "stemgnn_vq_assign_lean": (c_int, [P, I64, I64, I64, P, P, I64, P, P, P, c_float, P, c_size_t, P]),
     "stemgnn_code_sqnorm": (c_int, [P, I64, I64, P, P]),
     "stemgnn_codes_project": (c_int, [P, P, P, I64, I64, I64, I64, P, P]),
@@ -103,6 +111,11 @@ _SIGNATURES = {
     "stemgnn_pgemm_fwd": (c_int, [P, I64, I64, I64, P, P, I64, I64, P, P, I64, I64, P, P, P]),
     "stemgnn_pgemm_dw_workspace_bytes": (c_size_t, [I64, I64, I64]),
     "stemgnn_pgemm_dw": (c_int, [P, I64, P, I64, I64, I64, I64, P, P, P, c_size_t, P]),
+    "stemgnn_heads_save_bytes": (c_size_t, [P, I64, I64, I64, I64]),
+    "stemgnn_heads_fwd": (c_int, [P, P, P, P, I64, P, I64, P, P, P, I64, I64, c_uint64, c_uint64, c_uint64, c_uint64,
+                                  P, P, P, P, P, P, P, c_size_t, P]),
+    "stemgnn_heads_bwd_scratch_bytes": (c_size_t, [P, I64, I64, I64]),
+    "stemgnn_heads_bwd": (c_int, [P, I64, P, P, P, I64, I64, P, P, P, P, P, c_size_t, I64, P, c_size_t, P]),
     "stemgnn_encoder_save_bytes": (c_size_t, [I64, I64, P, P]),
     "stemgnn_encoder_fwd": (c_int, [P, P, P, P, I64, P, P, P, P, c_size_t, P]),
     "stemgnn_encoder_bwd_scratch_bytes": (c_size_t, [I64, I64, P, P]),
@@ -131,6 +144,7 @@ _SIGNATURES = {
     "stemgnn_linear_set_mode": (c_int, [c_int]),
     "stemgnn_linear_bwd_data": (c_int, [P, P, I64, I64, I64, P, P]),
     "stemgnn_linear_fwd": (c_int, [P, P, I64, P, P, I64, P, I64, I64, P, P, P, I64, P]),
+    "stemgnn_linear_fwd_rows": (c_int, [P, P, I64, P, P, I64, P, I64, I64, P, P, P, I64, I64, P]),
     "stemgnn_linear_bwd_weight_workspace_bytes": (c_size_t, [I64, I64, I64]),
     "stemgnn_linear_bwd_weight": (c_int, [P, P, I64, I64, I64, P, P, P, c_size_t, P]),
     "stemgnn_transpose": (c_int, [P, I64, I64, P, P]),

@@ -47,7 +47,7 @@ __global__ void __launch_bounds__(kBlock, 2)
 k_linear_fwd(const float* __restrict__ x1, const float* __restrict__ w1, int K1, const float* __restrict__ x2,
              const float* __restrict__ w2, int K2, const float* __restrict__ bias, int64_t M, int N,
              float* __restrict__ y, float* __restrict__ stats_partial /*[blocks][2][N]*/, int64_t row_base,
-             int64_t stats_block0, int64_t x1_rows) {
+             int64_t stats_block0, int64_t x1_rows, int64_t store_rows) {
   // BM = 128: waves 2(m) x 2(n), 64x64 per wave.  BM = 32 (tail tiles): waves 1 x 4, 32x32 per wave.
   constexpr int WM = BM == 128 ? 2 : 1;
   constexpr int WN = 4 / WM;
@@ -170,7 +170,7 @@ k_linear_fwd(const float* __restrict__ x1, const float* __restrict__ w1, int K1,
         const int64_t m = mrow0 + (r & 3) + 8 * (r >> 2);
         const float v = acc[tm][tn][r] + bv;
         if (interior || (m < M && n < N)) {
-          y[m * N + n] = v;
+          if (m < store_rows) y[m * N + n] = v;  // rows past store_rows only feed the column statistics
           if (STATS) { s1 += v; s2 += v * v; }
         }
       }
@@ -208,7 +208,7 @@ __global__ void __launch_bounds__(kBlock, 2)
 k_linear_fwd_x3(const float* __restrict__ x1, const float* __restrict__ w1, int K1, const float* __restrict__ x2,
              const float* __restrict__ w2, int K2, const float* __restrict__ bias, int64_t M, int N,
              float* __restrict__ y, float* __restrict__ stats_partial /*[blocks][2][N]*/, int64_t row_base,
-             int64_t stats_block0, int64_t x1_rows) {
+             int64_t stats_block0, int64_t x1_rows, int64_t store_rows) {
   // BM = 128: waves 2(m) x 2(n), 64x64 per wave.  BM = 32 (tail tiles): waves 1 x 4, 32x32 per wave.
   constexpr int WM = BM == 128 ? 2 : 1;
   constexpr int WN = 4 / WM;
@@ -331,7 +331,9 @@ k_linear_fwd_x3(const float* __restrict__ x1, const float* __restrict__ w1, int 
     float s1[TN], s2[TN];
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) s1[tn] = s2[tn] = 0.f;
+    const int64_t row_end = store_rows < M ? store_rows : M;  // rows past it only feed the column statistics
     for (int half = 0; half < 2; ++half) {
+      const bool stored = m0 + half * 64 < row_end;  // block-uniform
       if (wm == half) {
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
@@ -343,17 +345,18 @@ k_linear_fwd_x3(const float* __restrict__ x1, const float* __restrict__ w1, int 
             for (int r = 0; r < 16; ++r) {
               const int rl = tm * 32 + 4 * hi + (r & 3) + 8 * (r >> 2);
               const float v = acc[tm][tn][r] + bias_v[tn];
-              tile[rl * kLdT + nl] = v;
+              if (stored) tile[rl * kLdT + nl] = v;
               if (STATS && col_ok && m0 + half * 64 + rl < M) { s1[tn] += v; s2[tn] += v * v; }
             }
         }
       }
+      if (!stored) continue;
       __syncthreads();
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int rl = (tid >> 5) + 8 * i, c4 = tid & 31;
         const int64_t m = m0 + half * 64 + rl;
-        if (m < M && n0 + 4 * c4 < N) st4(y + m * N + n0 + 4 * c4, ld4(tile + rl * kLdT + 4 * c4));
+        if (m < row_end && n0 + 4 * c4 < N) st4(y + m * N + n0 + 4 * c4, ld4(tile + rl * kLdT + 4 * c4));
       }
       __syncthreads();
     }
@@ -396,7 +399,7 @@ k_linear_fwd_x3(const float* __restrict__ x1, const float* __restrict__ w1, int 
         const int64_t m = mrow0 + (r & 3) + 8 * (r >> 2);
         const float v = acc[tm][tn][r] + bv;
         if (interior || (m < M && n < N)) {
-          y[m * N + n] = v;
+          if (m < store_rows) y[m * N + n] = v;  // rows past store_rows only feed the column statistics
           if (STATS) { s1 += v; s2 += v * v; }
         }
       }
@@ -948,7 +951,15 @@ int64_t stemgnn_linear_stats_blocks(int64_t M, int64_t N) {
 int stemgnn_linear_fwd(const float* x1, const float* w1, int64_t K1, const float* x2, const float* w2, int64_t K2,
                        const float* bias, int64_t M, int64_t N, float* y, float* stats_partial,
                        int64_t* stats_blocks_host, int64_t x1_rows, void* stream_) {
+  return stemgnn_linear_fwd_rows(x1, w1, K1, x2, w2, K2, bias, M, N, y, stats_partial, stats_blocks_host, x1_rows, M,
+                                 stream_);
+}
+
+int stemgnn_linear_fwd_rows(const float* x1, const float* w1, int64_t K1, const float* x2, const float* w2, int64_t K2,
+                            const float* bias, int64_t M, int64_t N, float* y, float* stats_partial,
+                            int64_t* stats_blocks_host, int64_t x1_rows, int64_t store_rows, void* stream_) {
   hipStream_t st = static_cast<hipStream_t>(stream_);
+  const int64_t sr = (store_rows < 0 || store_rows > M) ? M : store_rows;
   if (!lin_dims_ok(M, N, K1) || K2 < 0 || K2 % 4 != 0) return STEMGNN_ERR_INVALID_ARG;
   const int64_t x1r = (x1_rows < 0 || x1_rows > M) ? M : x1_rows;
   if (!fits_i32(M)) return STEMGNN_ERR_TOO_LARGE;
@@ -963,11 +974,11 @@ int stemgnn_linear_fwd(const float* x1, const float* w1, int64_t K1, const float
   if (plan.main_tiles > 0) {
     dim3 grid(static_cast<unsigned>(plan.main_tiles), static_cast<unsigned>(gy));
     if (stats_partial) {
-      if (x3) k_linear_fwd_x3<128, true><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, stats_partial, 0, 0, x1r);
-      else k_linear_fwd<128, true><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, stats_partial, 0, 0, x1r);
+      if (x3) k_linear_fwd_x3<128, true><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, stats_partial, 0, 0, x1r, sr);
+      else k_linear_fwd<128, true><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, stats_partial, 0, 0, x1r, sr);
     } else {
-      if (x3) k_linear_fwd_x3<128, false><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, nullptr, 0, 0, x1r);
-      else k_linear_fwd<128, false><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, nullptr, 0, 0, x1r);
+      if (x3) k_linear_fwd_x3<128, false><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, nullptr, 0, 0, x1r, sr);
+      else k_linear_fwd<128, false><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, nullptr, 0, 0, x1r, sr);
     }
     STEMGNN_LAUNCH_CHECK();
   }
@@ -978,14 +989,14 @@ int stemgnn_linear_fwd(const float* x1, const float* w1, int64_t K1, const float
     const int64_t row_base = plan.main_tiles * kBM;
     if (stats_partial) {
       if (x3) k_linear_fwd_x3<32, true><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, stats_partial,
-                                                                 row_base, plan.main_tiles, x1r);
+                                                                 row_base, plan.main_tiles, x1r, sr);
       else k_linear_fwd<32, true><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, stats_partial,
-                                                           row_base, plan.main_tiles, x1r);
+                                                           row_base, plan.main_tiles, x1r, sr);
     } else {
       if (x3) k_linear_fwd_x3<32, false><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, nullptr,
-                                                                  row_base, plan.main_tiles, x1r);
+                                                                  row_base, plan.main_tiles, x1r, sr);
       else k_linear_fwd<32, false><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, nullptr,
-                                                            row_base, plan.main_tiles, x1r);
+                                                            row_base, plan.main_tiles, x1r, sr);
     }
     STEMGNN_LAUNCH_CHECK();
   }
@@ -1007,15 +1018,15 @@ int stemgnn_linear_bwd_data(const float* dy, const float* w, int64_t M, int64_t 
   const bool x3 = gemm_x3();
   if (plan.main_tiles > 0) {
     dim3 grid(static_cast<unsigned>(plan.main_tiles), static_cast<unsigned>(gy));
-    if (x3) k_linear_fwd_x3<128, false, true><<<grid, kBlock, 0, st>>>(dy, w, kc, nullptr, nullptr, 0, nullptr, M, n, dx, nullptr, 0, 0, M);
-    else k_linear_fwd<128, false, true><<<grid, kBlock, 0, st>>>(dy, w, kc, nullptr, nullptr, 0, nullptr, M, n, dx, nullptr, 0, 0, M);
+    if (x3) k_linear_fwd_x3<128, false, true><<<grid, kBlock, 0, st>>>(dy, w, kc, nullptr, nullptr, 0, nullptr, M, n, dx, nullptr, 0, 0, M, M);
+    else k_linear_fwd<128, false, true><<<grid, kBlock, 0, st>>>(dy, w, kc, nullptr, nullptr, 0, nullptr, M, n, dx, nullptr, 0, 0, M, M);
     STEMGNN_LAUNCH_CHECK();
   }
   if (plan.tail_tiles > 0) {
     dim3 grid(static_cast<unsigned>(plan.tail_tiles), static_cast<unsigned>(gy));
     const int64_t row_base = plan.main_tiles * kBM;
-    if (x3) k_linear_fwd_x3<32, false, true><<<grid, kBlock, 0, st>>>(dy, w, kc, nullptr, nullptr, 0, nullptr, M, n, dx, nullptr, row_base, 0, M);
-    else k_linear_fwd<32, false, true><<<grid, kBlock, 0, st>>>(dy, w, kc, nullptr, nullptr, 0, nullptr, M, n, dx, nullptr, row_base, 0, M);
+    if (x3) k_linear_fwd_x3<32, false, true><<<grid, kBlock, 0, st>>>(dy, w, kc, nullptr, nullptr, 0, nullptr, M, n, dx, nullptr, row_base, 0, M, M);
+    else k_linear_fwd<32, false, true><<<grid, kBlock, 0, st>>>(dy, w, kc, nullptr, nullptr, 0, nullptr, M, n, dx, nullptr, row_base, 0, M, M);
     STEMGNN_LAUNCH_CHECK();
   }
   return STEMGNN_OK;

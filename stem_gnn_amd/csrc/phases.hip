@@ -32,7 +32,7 @@ struct LayerSave {
 };
 
 struct EncoderPlan {
-  int64_t N, A;
+  int64_t N, A, R;           // rows, rows that receive edges, rows of the output the caller wants
   bool tail_identity;        // last layer without BatchNorm: its product IS z
   std::vector<LayerSave> layers;
   float* stats_partial;      // forward scratch (column partials of the widest layer)
@@ -58,6 +58,7 @@ inline EncoderPlan plan_encoder(const void* save, int64_t N, int64_t A, const st
   EncoderPlan p;
   p.N = N;
   p.A = A;
+  p.R = (cfg->out_rows > 0 && cfg->out_rows < N) ? cfg->out_rows : N;
   const int L = cfg->num_layers;
   p.tail_identity = !cfg->use_bn;
   Carver c(save);
@@ -70,7 +71,7 @@ inline EncoderPlan plan_encoder(const void* save, int64_t N, int64_t A, const st
     if (last && p.tail_identity) {
       s.y = z;  // no normalisation, activation or dropout after the last layer: the product is the output
     } else {
-      s.y = c.take<float>(static_cast<size_t>(std::max<int64_t>(N, 1)) * y.out_dim);
+      s.y = c.take<float>(static_cast<size_t>(std::max<int64_t>(last ? p.R : N, 1)) * y.out_dim);
     }
     s.h = last ? z : c.take<float>(static_cast<size_t>(std::max<int64_t>(N, 1)) * y.out_dim);
     if (cfg->use_bn) {
@@ -172,8 +173,9 @@ int stemgnn_encoder_fwd(const stemgnn_graph_view* g, const float* x, const float
       STEMGNN_TRY(stemgnn_sage_agg_fwd(h, A, y.in_dim, g->rowptr, g->src, g->eid, edge_attr, etab, g->etype_slot, T,
                                        s.agg, stream));
     const bool batch_stats = cfg->use_bn && cfg->training;
-    STEMGNN_TRY(stemgnn_linear_fwd(s.agg, y.w_l, y.in_dim, h, y.w_r, y.in_dim, y.b_l, N, y.out_dim, s.y,
-                                   batch_stats ? p.stats_partial : nullptr, nullptr, A, stream));
+    const int64_t rows_out = last ? p.R : N;  // the last layer's values are wanted for the leading rows only
+    STEMGNN_TRY(stemgnn_linear_fwd_rows(s.agg, y.w_l, y.in_dim, h, y.w_r, y.in_dim, y.b_l, N, y.out_dim, s.y,
+                                        batch_stats ? p.stats_partial : nullptr, nullptr, A, rows_out, stream));
     if (last && p.tail_identity) break;
     const float *mean = nullptr, *rstd = nullptr;
     if (batch_stats) {
@@ -192,7 +194,7 @@ int stemgnn_encoder_fwd(const stemgnn_graph_view* g, const float* x, const float
     }
     const int act = last ? 0 : cfg->act;
     const float pdrop = (last || !cfg->training) ? 0.f : cfg->dropout_p;
-    STEMGNN_TRY(stemgnn_bn_act_drop_fwd(s.y, N, y.out_dim, mean, rstd, cfg->use_bn ? y.bn_weight : nullptr,
+    STEMGNN_TRY(stemgnn_bn_act_drop_fwd(s.y, rows_out, y.out_dim, mean, rstd, cfg->use_bn ? y.bn_weight : nullptr,
                                         cfg->use_bn ? y.bn_bias : nullptr, act, cfg->negative_slope, pdrop, y.drop_seed,
                                         y.drop_offset, s.h, stream));
     h = s.h;
@@ -224,6 +226,7 @@ int stemgnn_encoder_bwd(const stemgnn_graph_view* g, const float* x, const float
   const int64_t A = (g->active_rows < 0 || g->active_rows > N) ? N : g->active_rows;
   if (N <= 0) return N == 0 ? STEMGNN_OK : STEMGNN_ERR_INVALID_ARG;
   if (!cfg->training && cfg->use_bn) return STEMGNN_ERR_INVALID_ARG;  // running-statistics backward: single-op path
+  if (cfg->out_rows > 0 && cfg->out_rows < N) return STEMGNN_ERR_INVALID_ARG;  // a truncated forward has no backward
   if (!x || !g_z || !save || !scratch || !g->rowptr_t || !g->inv_deg) return STEMGNN_ERR_INVALID_ARG;
   if (save_bytes < stemgnn_encoder_save_bytes(N, A, layers, cfg) ||
       scratch_bytes < stemgnn_encoder_bwd_scratch_bytes(N, A, layers, cfg))
@@ -365,9 +368,12 @@ int stemgnn_vq_bwd(const stemgnn_vq_params* p, const float* z, int64_t N, const 
   const size_t dw_ws_bytes = stemgnn_linear_bwd_weight_workspace_bytes(N, HD, D);
   void* dw_ws = c.take<unsigned char>(dw_ws_bytes);
 
+  // one head per 128-column tile and the exact-bf16 matrix-core mode: project_out's backward-data product runs inside
+  // the assignment's backward and the [N, H*Dc] gradient of the quantised rows never reaches memory
+  const bool fuse = g_quantize && Dc <= 128 && stemgnn_linear_set_mode(-1) == 1;
   if (g_quantize) {
     // straight-through (vq.py:937): the gradient of project_out's input reaches the normalised rows unchanged
-    STEMGNN_TRY(stemgnn_linear_bwd_data(g_quantize, p->w_out, N, D, HD, g_q, stream));
+    if (!fuse) STEMGNN_TRY(stemgnn_linear_bwd_data(g_quantize, p->w_out, N, D, HD, g_q, stream));
     // project_out's parameters: its input rows are code rows, so dW_out_h = (segment sums of g by code)^T embed_h
     if (p->g_w_out || p->g_b_out) {
       STEMGNN_TRY(stemgnn_code_segment_sums(ind, H, K, g_quantize, N, D, sums, seg_ws, seg_ws_bytes, stream));
@@ -381,8 +387,13 @@ int stemgnn_vq_bwd(const stemgnn_vq_params* p, const float* z, int64_t N, const 
     if (p->g_b_out) STEMGNN_HIP_TRY(hipMemsetAsync(p->g_b_out, 0, sizeof(float) * D, st));
   }
   // through the commitment term and the l2 normalisation
-  STEMGNN_TRY(stemgnn_vq_assign_bwd(g_q, p->commitment_weight > 0.f ? g_loss : nullptr, p->commitment_weight, s.xp, s.norm,
-                                    ind, p->embed, N, H, Dc, K, g_xp, stream));
+  const float* gl = p->commitment_weight > 0.f ? g_loss : nullptr;
+  if (fuse) {
+    STEMGNN_TRY(stemgnn_vq_assign_bwd_fused(g_quantize, D, p->w_out, gl, p->commitment_weight, s.xp, s.norm, ind, p->embed,
+                                            N, H, Dc, K, g_xp, stream));
+  } else {
+    STEMGNN_TRY(stemgnn_vq_assign_bwd(g_q, gl, p->commitment_weight, s.xp, s.norm, ind, p->embed, N, H, Dc, K, g_xp, stream));
+  }
   if (g_z) STEMGNN_TRY(stemgnn_linear_bwd_data(g_xp, p->w_in, N, HD, D, g_z, stream));
   if (p->g_w_in || p->g_b_in) {
     if (!p->g_w_in) return STEMGNN_ERR_INVALID_ARG;

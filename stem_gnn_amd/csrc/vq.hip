@@ -394,6 +394,170 @@ k_vq_assign_bwd(const float* __restrict__ g_quant, const float* __restrict__ g_l
   }
 }
 
+// staging row of float4 slot idx (8 slots per row): the rows of every group of eight in the order 0 4 1 5 2 6 3 7, so
+// that the two rows one ds_write_b64 group covers share no LDS bank (as in csrc/linear.hip)
+__device__ __forceinline__ int stage_row8(int idx) {
+  const int r = idx >> 3;
+  return (r & ~7) | ((r & 1) << 2) | ((r >> 1) & 3);
+}
+
+// Backward with project_out's backward-data product inside: g_q = g_out W_out[:, h-block] is formed in the matrix
+// cores (the tile of csrc/linear.hip's backward-data product: exact bf16 pieces, weight read as stored and transposed
+// while staged) and consumed from LDS by the row-wise arithmetic of k_vq_assign_bwd -- the [N, H*Dc] gradient of the
+// quantised rows (vq.py:937,1041: straight-through + project_out) is never written to or read from HBM.
+// grid (row tiles, heads); one head's Dc <= 128 columns are one tile.
+__global__ void __launch_bounds__(kBlock, 2)
+k_vq_assign_bwd_fused(const float* __restrict__ g_out, int D, const float* __restrict__ w_out /*[D][H*Dc]*/,
+                      const float* __restrict__ g_loss, float coef, const float* __restrict__ xp,
+                      const float* __restrict__ norm, const int64_t* __restrict__ ind, const float* __restrict__ embed,
+                      int64_t N, int H, int Dc, int K, float* __restrict__ g_xp) {
+  constexpr int BM = 128, BN = 128;
+  constexpr int PA = BM * kLdP, PB = BN * kLdP;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[3 * PA + 3 * PB];
+  unsigned char* const sA = smem;
+  unsigned char* const sB = smem + 3 * PA;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, hi = lane >> 5, lj = lane & 31;
+  const int h = blockIdx.y;
+  const int64_t m0 = static_cast<int64_t>(blockIdx.x) * BM;
+  const int64_t HD = static_cast<int64_t>(H) * Dc;
+  const float* wh = w_out + static_cast<int64_t>(h) * Dc;  // column block of the head; row stride HD
+  const int steps = (D + kKC - 1) / kKC;
+
+  float4 ra[4], rb[4];
+  auto fetch = [&](int step) {
+    const int k0 = step * kKC;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int idx = t * kBlock + tid;
+      const int r = stage_row8(idx), k = k0 + 4 * (idx & 7);
+      const int64_t m = m0 + r;
+      ra[t] = (m < N && k < D) ? ld4(g_out + m * D + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+      // weight rows k0 + 4 (tid & 7) + t (contraction index d), columns 4 (tid >> 3) .. + 3 of the head
+      const int kk = k0 + 4 * (tid & 7) + t, nn = 4 * (tid >> 3);
+      rb[t] = (kk < D && nn < Dc) ? ld4(wh + static_cast<int64_t>(kk) * HD + nn) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto stash = [&]() {
+    stash_transposed(rb, sB, PB, tid);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int idx = t * kBlock + tid;
+      const int off = stage_row8(idx) * kLdP + 8 * (idx & 7);
+      uint2 ph, pm, pl;
+      split3(ra[t], ph, pm, pl);
+      *reinterpret_cast<uint2*>(sA + off) = ph;
+      *reinterpret_cast<uint2*>(sA + PA + off) = pm;
+      *reinterpret_cast<uint2*>(sA + 2 * PA + off) = pl;
+    }
+  };
+
+  floatx16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  fetch(0);
+  for (int step = 0; step < steps; ++step) {
+    stash();
+    __syncthreads();
+    if (step + 1 < steps) fetch(step + 1);
+#pragma unroll
+    for (int ks = 0; ks < kKC / 16; ++ks) {
+      const int ko = ks * 32 + hi * 16;
+      bf16x8 a[2][3], b[2][3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          a[t][p] = *reinterpret_cast<const bf16x8*>(sA + p * PA + (wm * 64 + t * 32 + lj) * kLdP + ko);
+          b[t][p] = *reinterpret_cast<const bf16x8*>(sB + p * PB + (wn * 64 + t * 32 + lj) * kLdP + ko);
+        }
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) acc[tm][tn] = mfma_x3(a[tm], b[tn], acc[tm][tn]);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: the tile through LDS, 64 rows at a time; then one 32-lane group per row does what
+  // k_vq_assign_bwd does with a row of g_quant.  A group serves 16 rows of the tile (8 per half); everything it needs
+  // from memory is requested up front -- codes and norms of all 16 rows at once, then per half the 8 xp rows and the 8
+  // code rows together -- so a block pays a handful of memory round trips, not one per row.
+  constexpr int kLdT = BN + 4;
+  float* tile = reinterpret_cast<float*>(smem);
+  const float s = g_loss ? g_loss[0] * coef : 0.f;
+  const int l32 = tid & 31, grp = tid >> 5;  // 8 groups of 32 lanes
+  const bool col_ok = 4 * l32 < Dc;
+  int64_t code[16];
+  float nrm[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int64_t m = m0 + (i >> 3) * 64 + (i & 7) * 8 + grp;
+    code[i] = 0;
+    nrm[i] = 1.f;
+    if (m < N) {
+      code[i] = ind[m * H + h];
+      nrm[i] = norm[m * H + h];
+    }
+  }
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    float4 xv[8], qv[8];
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+      const int64_t m = m0 + half * 64 + pass * 8 + grp;
+      int64_t c = code[half * 8 + pass];
+      if (c < 0 || c >= K) c = 0;
+      xv[pass] = qv[pass] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < N && col_ok) {
+        xv[pass] = ld4(xp + m * HD + static_cast<int64_t>(h) * Dc + 4 * l32);
+        qv[pass] = ld4(embed + (static_cast<int64_t>(h) * K + c) * Dc + 4 * l32);
+      }
+    }
+    if (wm == half) {
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            tile[(tm * 32 + 4 * hi + (r & 3) + 8 * (r >> 2)) * kLdT + wn * 64 + tn * 32 + lj] = acc[tm][tn][r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+      const int rl = pass * 8 + grp;
+      const int64_t m = m0 + half * 64 + rl;
+      const bool live = m < N;  // uniform within the 32-lane group
+      const float nr = nrm[half * 8 + pass];
+      const bool clamped = nr < kNormEps;
+      const float inv = 1.0f / fmaxf(nr, kNormEps);
+      float4 gx = make_float4(0.f, 0.f, 0.f, 0.f), n = gx;
+      float dot = 0.f;
+      if (live && col_ok) {
+        const float4 gq = ld4(tile + rl * kLdT + 4 * l32);
+        n = make_float4(xv[pass].x * inv, xv[pass].y * inv, xv[pass].z * inv, xv[pass].w * inv);
+        gx = make_float4(gq.x + s * (n.x - qv[pass].x), gq.y + s * (n.y - qv[pass].y), gq.z + s * (n.z - qv[pass].z),
+                         gq.w + s * (n.w - qv[pass].w));
+        dot = gx.x * n.x + gx.y * n.y + gx.z * n.z + gx.w * n.w;
+      }
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 32);
+      if (clamped) dot = 0.f;
+      if (live && col_ok)
+        st4(g_xp + m * HD + static_cast<int64_t>(h) * Dc + 4 * l32,
+            make_float4((gx.x - n.x * dot) * inv, (gx.y - n.y * dot) * inv, (gx.z - n.z * dot) * inv,
+                        (gx.w - n.w * dot) * inv));
+    }
+    __syncthreads();
+  }
+}
+
 // ---- K10 helpers -----------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock) k_code_keys(const int64_t* __restrict__ ind, int64_t NH, int H, int K,
                                                       int32_t* __restrict__ keys) {
@@ -557,6 +721,23 @@ int stemgnn_vq_assign_bwd(const float* g_quant, const float* g_loss, float commi
         g_quant, g_loss, coef, xp, norm, ind, embed, N, static_cast<int>(H), static_cast<int>(Dc),
         static_cast<int>(K), g_xp);
   }
+  STEMGNN_LAUNCH_CHECK();
+  return STEMGNN_OK;
+}
+
+int stemgnn_vq_assign_bwd_fused(const float* g_out, int64_t D, const float* w_out, const float* g_loss,
+                                float commit_weight, const float* xp, const float* norm, const int64_t* ind,
+                                const float* embed, int64_t N, int64_t H, int64_t Dc, int64_t K, float* g_xp,
+                                void* stream_) {
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  if (!vq_dims_ok(N, H, Dc, K) || Dc > 128 || D <= 0 || D % 4 != 0 || D > 65536) return STEMGNN_ERR_INVALID_ARG;
+  if (!fits_i32(N * H)) return STEMGNN_ERR_TOO_LARGE;
+  if (N == 0) return STEMGNN_OK;
+  if (!g_out || !w_out || !xp || !norm || !ind || !embed || !g_xp) return STEMGNN_ERR_INVALID_ARG;
+  const float coef = commit_weight * 2.0f / static_cast<float>(static_cast<double>(N) * H * Dc);
+  dim3 grid(static_cast<unsigned>(row_blocks(N)), static_cast<unsigned>(H));
+  k_vq_assign_bwd_fused<<<grid, kBlock, 0, st>>>(g_out, static_cast<int>(D), w_out, g_loss, coef, xp, norm, ind, embed, N,
+                                                 static_cast<int>(H), static_cast<int>(Dc), static_cast<int>(K), g_xp);
   STEMGNN_LAUNCH_CHECK();
   return STEMGNN_OK;
 }

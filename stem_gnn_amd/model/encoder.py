@@ -326,7 +326,7 @@ class Encoder(nn.Module):
                                          self._slope, p, seed, offset, stats)
         return ops.BnActDropFn.apply(z, None, None, None, None, False, 0.0, 0.0, act, self._slope, p, seed, offset)
 
-    def _encode_phase(self, x, graph, dense, etab):
+    def _encode_phase(self, x, graph, dense, etab, out_rows=None):
         """The whole layer stack as one library call per direction (ops.EncoderFn, csrc/phases.hip), or None when the
         configuration needs the per-layer path (MoE layers, cumulative-average BatchNorm, a graph with hub rows,
         gradients wanted in eval mode)."""
@@ -356,20 +356,25 @@ class Encoder(nn.Module):
             params += [conv.lin_l.weight, conv.lin_l.bias, conv.lin_r.weight,
                        norm.weight if use_bn else None, norm.bias if use_bn else None]
         cfg = dict(use_bn=use_bn, training=self.training, act=self._act_code, slope=self._slope,
-                   p=float(self.dropout.p) if self.training else 0.0)
+                   p=float(self.dropout.p) if self.training else 0.0,
+                   out_rows=out_rows if (out_rows and not wants_grad) else 0, wants_grad=wants_grad)
         self.last_dropout_keys = keys
         return ops.EncoderFn.apply(x, graph, dense, etab, (cfg, per_layer), *params)
 
-    def encode(self, x, edge_index, edge_attr=None):
+    def encode(self, x, edge_index, edge_attr=None, out_rows=None):
+        """``out_rows`` (not part of the reference signature): a no-grad caller that reads only the leading rows of the
+        output may say so -- the last layer's statistics still run over every row, its values are produced for those
+        rows only, and the result has ``out_rows`` rows."""
         dense, etab, etype = _split_edge_attr(edge_attr)
         graph = as_graph(edge_index, x.size(0), etype)  # one structure build shared by all layers
         self._last_env_reg = None
         self.last_dropout_keys = []
-        z = self._encode_phase(x, graph, dense, etab)
+        z = self._encode_phase(x, graph, dense, etab, out_rows)
         if z is not None:
             self._last_env_reg = self._zero_reg(z.device)
             return z
-        return self._encode_layers(x, graph, edge_attr)
+        z = self._encode_layers(x, graph, edge_attr)
+        return z if out_rows is None else z[:out_rows]
 
     def _encode_layers(self, x, graph, edge_attr):
         """Layer by layer through the single-op autograd functions (every configuration)."""

@@ -165,12 +165,14 @@ class PretrainModel(nn.Module):
         zz = ops.EdgeConcatFn.apply(z, edge_index.contiguous())  # cat([z[u], z[v]]), pt_model.py:80
         return F.mse_loss(self._lin(self.topo_sem_recon_decoder, zz), target)
 
-    def _teacher_forward(self, g):
-        """sem_encoder(orig graph).detach() (pt_model.py:93).  Independent of the student until the
-        cosine term, so it is issued on a side HIP stream and overlaps the student / VQ kernels."""
+    def _teacher_forward(self, g, rows=None):
+        """sem_encoder(orig graph).detach() (pt_model.py:93); only its rows [:bs] are ever read (:96-97), which
+        ``rows`` tells the encoder.  Optionally issued on a side HIP stream (measured: no gain)."""
         orig_x, orig_edge_index, orig_edge_attr = g[0], g[1], g[2]
         if not (self.teacher_side_stream and orig_x.is_cuda):
             with torch.no_grad():
+                if rows is not None and hasattr(self.sem_encoder, "_encode_phase"):
+                    return self.sem_encoder.encode(orig_x, orig_edge_index, orig_edge_attr, out_rows=rows), None
                 return self.sem_encoder(orig_x, orig_edge_index, orig_edge_attr), None
         if self._side_stream is None:
             self._side_stream = torch.cuda.Stream(device=orig_x.device)
@@ -182,7 +184,7 @@ class PretrainModel(nn.Module):
 
     def sem_recon_loss(self, g, quantize, eta=1.0, bs=None, teacher=None):
         if teacher is None:
-            teacher = self._teacher_forward(g)
+            teacher = self._teacher_forward(g, rows=None if bs is None else int(bs))
         z, side = teacher
         if side is not None:
             torch.cuda.current_stream(z.device).wait_stream(side)
@@ -227,6 +229,44 @@ class PretrainModel(nn.Module):
                 self.vq.skip_codes = skip
         return z, quantize, indices, commit_loss
 
+    def _heads_phase(self, query, g, ratio, bs, draws, teacher):
+        """The four heads as one library call per direction (ops.HeadsFn), or None when the call is not the standard
+        pretraining configuration (pretrain.py:91-130: Linear decoders, InnerProductDecoder with its projection, edge
+        attributes as (type table, int64 type ids), a sampling ratio in (0, 1), no injected draws)."""
+        orig_x, orig_edge_index, orig_edge_attr = g[0], g[1], g[2]
+        dec = self.topo_recon_decoder
+        if not (query.is_cuda and query.dtype == torch.float32 and 0.0 < ratio < 1.0 and bs is not None and not draws
+                and isinstance(orig_edge_attr, EdgeTypeAttr) and orig_edge_attr.etype is not None
+                and orig_edge_attr.etype.dtype == torch.int64
+                and isinstance(self.feat_recon_decoder, nn.Linear) and isinstance(self.topo_sem_recon_decoder, nn.Linear)
+                and isinstance(dec, InnerProductDecoder) and dec.proj_z and query.size(0) >= 2
+                and 0 < bs <= query.size(0) and orig_x.dtype == torch.float32 and orig_x.size(1) % 4 == 0):
+            return None
+        d = query.size(1)
+        if (tuple(self.topo_sem_recon_decoder.weight.shape) != (d, 2 * d) or tuple(dec.lin.weight.shape) != (d, d)
+                or tuple(self.feat_recon_decoder.weight.shape) != (orig_x.size(1), d)
+                or tuple(self.sem_projector.weight.shape) != (d, d) or orig_edge_attr.table.size(1) != d):
+            return None
+        graph = orig_edge_index if isinstance(orig_edge_index, GraphStructure) else as_graph(orig_edge_index, query.size(0))
+        num_edges = graph.edge_index.size(1)
+        if num_edges == 0:
+            return None
+        if teacher is None:
+            teacher = self._teacher_forward(g, rows=int(bs))
+        z_t, side = teacher
+        if side is not None:
+            torch.cuda.current_stream(z_t.device).wait_stream(side)
+            z_t.record_stream(torch.cuda.current_stream(z_t.device))
+        k = max(int(num_edges * ratio), 1)
+        seed, o1 = ops.next_dropout_key()
+        _, o2 = ops.next_dropout_key()
+        _, o3 = ops.next_dropout_key()
+        lins = (self.feat_recon_decoder, dec.lin, self.topo_sem_recon_decoder, self.sem_projector)
+        params = [t for lin in lins for t in (lin.weight, lin.bias)]
+        return ops.HeadsFn.apply(query, graph, orig_edge_attr.table, orig_edge_attr.etype.contiguous(),
+                                 orig_x.contiguous(), z_t.contiguous(), int(bs), k, (seed, (o1, o2, o3)),
+                                 self.last_draws, *params)
+
     def forward(self, aug_g, g, topo_recon_ratio=1.0, bs=None, no_codebook=False, draws=None):
         x, edge_index, edge_attr = aug_g[0], aug_g[1], aug_g[2]
         orig_x, orig_edge_index, orig_edge_attr = g[0], g[1], g[2]
@@ -239,7 +279,10 @@ class PretrainModel(nn.Module):
             commit_loss = torch.tensor(0.0, device=z.device)
         else:
             query = quantize
-        if topo_recon_ratio not in (0.0, 1.0) and query.is_cuda:
+        fused = self._heads_phase(query, g, topo_recon_ratio, bs, draws, teacher)
+        if fused is not None:
+            feat_recon_loss, topo_recon_loss, topo_sem_recon_loss, sem_recon_loss = fused
+        elif topo_recon_ratio not in (0.0, 1.0) and query.is_cuda:
             # fused fan-out of the query: one dense gradient buffer for its three consumers
             full_ei = _edge_index_of(orig_edge_index)
             typed = isinstance(orig_edge_attr, EdgeTypeAttr)

@@ -13,7 +13,7 @@ from typing import Optional, Tuple
 import torch
 from torch import Tensor
 
-from ._lib import EncoderCfg, GraphView, SageLayer, VqParams, check, lib
+from ._lib import EncoderCfg, GraphView, HeadsParams, SageLayer, VqParams, check, lib
 
 
 _raw_stream = torch._C._cuda_getCurrentRawStream  # the hipStream_t of torch's current stream, without the Stream object
@@ -474,7 +474,7 @@ class EncoderFn(torch.autograd.Function):
                 g = grads[5 * l:5 * l + 5]
                 y.g_w_l, y.g_b_l, y.g_w_r, y.g_bn_weight, y.g_bn_bias = (_p(t) for t in g)
         cfg = EncoderCfg(L, int(cfg_d["use_bn"]), int(cfg_d["training"]), int(cfg_d["act"]), float(cfg_d["slope"]),
-                         float(cfg_d["p"]))
+                         float(cfg_d["p"]), int(cfg_d.get("out_rows") or 0))
         return arr, cfg
 
     @staticmethod
@@ -484,14 +484,17 @@ class EncoderFn(torch.autograd.Function):
             if t is not None:
                 _req(t, torch.float32, "encoder parameter")
         arr, cfg = EncoderFn._layers(meta, params)
-        need_bwd = any(t is not None and t.requires_grad for t in params) or x.requires_grad
+        need_bwd = bool(meta[0].get("wants_grad", True))  # grad mode is off inside forward: the caller decides
         gv = graph_view(graph, need_bwd)
         N, A = gv.num_nodes, gv.active_rows
         nbytes = lib.stemgnn_encoder_save_bytes(N, A, arr, ctypes.byref(cfg))
         if nbytes == 0:
             raise RuntimeError("encoder phase: unsupported layer configuration")
         save = _workspace(nbytes, x.device)
-        z = torch.empty(N, arr[len(arr) - 1].out_dim, dtype=torch.float32, device=x.device)
+        rows = cfg.out_rows if 0 < cfg.out_rows < N else N
+        if rows < N and need_bwd:
+            raise RuntimeError("encoder phase: out_rows is a forward-only option (no_grad callers)")
+        z = torch.empty(rows, arr[len(arr) - 1].out_dim, dtype=torch.float32, device=x.device)
         T = 0 if etab is None else etab.size(0)
         check(lib.stemgnn_encoder_fwd(ctypes.byref(gv), _p(x), _p(dense), _p(etab), T, arr, ctypes.byref(cfg), _p(z),
                                       _p(save), save.numel(), _stream()), "encoder_fwd")
@@ -1155,6 +1158,84 @@ class QueryFanOutFn(torch.autograd.Function):
         return g, None, None
 
 
+class HeadsFn(torch.autograd.Function):
+    """The four reconstruction heads that read the decoder query in PretrainModel.forward (reference
+    model/pt_model.py:39-102,128-131) as ONE library call per direction (csrc/heads.hip): edge sampling, negative
+    sampling, the decoders' products and the four losses; backward: every head's gradient folded into one dense
+    [N, D] buffer plus the decoder parameter gradients.  Returns (losses [4] = feat, topo, topo_sem, sem -- unweighted,
+    draws dict).  ``params`` = (w_feat, b_feat, w_topo, b_topo, w_ts, b_ts, w_sem, b_sem)."""
+
+    @staticmethod
+    def _struct(q, x_feat, params, grads=None):
+        p = HeadsParams()
+        p.dim, p.in_dim = q.size(1), x_feat.size(1)
+        (p.w_feat, p.b_feat, p.w_topo, p.b_topo, p.w_ts, p.b_ts, p.w_sem, p.b_sem) = (_p(t) for t in params)
+        if grads is not None:
+            (p.g_w_feat, p.g_b_feat, p.g_w_topo, p.g_b_topo, p.g_w_ts, p.g_b_ts, p.g_w_sem, p.g_b_sem) = \
+                (_p(t) for t in grads)
+        return p
+
+    @staticmethod
+    def forward(ctx, q, graph, etab, etype, x_feat, z_teacher, bs, k, keys, out, *params):
+        q = q.contiguous()
+        _req(q, torch.float32, "query", 2)
+        _req(x_feat, torch.float32, "x", 2)
+        _req(z_teacher, torch.float32, "teacher", 2)
+        _req(etab, torch.float32, "edge_type_table", 2)
+        _req(etype, torch.int64, "edge_type", 1)
+        ei = _req(graph.edge_index, torch.int64, "edge_index", 2)
+        N, D = q.shape
+        E = ei.size(1)
+        if x_feat.size(0) < bs or z_teacher.size(0) < bs or z_teacher.size(1) != D or etab.size(1) != D:
+            raise RuntimeError("heads phase: operand shapes do not match the query")
+        W = (params[0], params[2], params[4], params[6])
+        want = ((x_feat.size(1), D), (D, D), (D, 2 * D), (D, D))
+        if any(tuple(w.shape) != s for w, s in zip(W, want)):
+            raise RuntimeError("heads phase: decoder shapes do not match (feat [in, D], topo [D, D], topo_sem [D, 2D], sem [D, D])")
+        p = HeadsFn._struct(q, x_feat, params)
+        gv = graph_view(graph, False)
+        dev = q.device
+        i64 = dict(dtype=torch.int64, device=dev)
+        topo_perm, topo_edges = torch.empty(k, **i64), torch.empty(2, 2 * k, **i64)
+        ts_perm, ts_edges, ts_type = torch.empty(k, **i64), torch.empty(2, k, **i64), torch.empty(k, **i64)
+        losses = torch.empty(4, dtype=torch.float32, device=dev)
+        save = _workspace(lib.stemgnn_heads_save_bytes(ctypes.byref(p), N, E, bs, k), dev)
+        seed, (o1, o2, o3) = keys
+        check(lib.stemgnn_heads_fwd(ctypes.byref(p), ctypes.byref(gv), _p(ei), _p(etype), E, _p(etab), etab.size(0), _p(q),
+                                    _p(x_feat), _p(z_teacher), bs, k, seed, o1, o2, o3, _p(topo_perm), _p(topo_edges),
+                                    _p(ts_perm), _p(ts_edges), _p(ts_type), _p(losses), _p(save), save.numel(), _stream()),
+              "heads_fwd")
+        out["topo_perm"], out["neg_edge_index"], out["topo_sem_perm"] = topo_perm, topo_edges[:, k:], ts_perm
+        ctx.meta = (bs, k, E)
+        ctx.save_for_backward(q, x_feat, z_teacher, topo_edges, ts_edges, save, *params)
+        # four outputs of this node (not select views of one output: their backward would be four zero fills, four
+        # copies and three adds)
+        return losses[0], losses[1], losses[2], losses[3]
+
+    @staticmethod
+    def backward(ctx, *g4):
+        q, x_feat, z_teacher, topo_edges, ts_edges, save, *params = ctx.saved_tensors
+        dev = q.device
+        g4 = [torch.zeros((), device=dev) if g is None else g for g in g4]
+        base = g4[0].data_ptr()
+        if all(g.dtype == torch.float32 and g.is_cuda and g.data_ptr() == base + 4 * i for i, g in enumerate(g4)):
+            g_losses = g4[0]   # consecutive elements of one buffer (what the weighted total's backward hands out)
+        else:
+            g_losses = torch.stack([g.reshape(()).float() for g in g4])
+        bs, k, E = ctx.meta
+        grads = [None if t is None else torch.empty_like(t) for t in params]
+        p = HeadsFn._struct(q, x_feat, params, grads)
+        N = q.size(0)
+        g_q = torch.empty_like(q)
+        scratch = _workspace(lib.stemgnn_heads_bwd_scratch_bytes(ctypes.byref(p), N, bs, k), q.device)
+        check(lib.stemgnn_heads_bwd(ctypes.byref(p), N, _p(q), _p(x_feat), _p(z_teacher), bs, k, _p(topo_edges),
+                                    _p(ts_edges), _p(g_losses), _p(g_q), _p(save), save.numel(), E, _p(scratch),
+                                    scratch.numel(), _stream()), "heads_bwd")
+        need = ctx.needs_input_grad
+        return (g_q if need[0] else None, None, None, None, None, None, None, None, None, None,
+                *[g if need[10 + i] else None for i, g in enumerate(grads)])
+
+
 _CLIP_MAX = int(lib.stemgnn_clip_grad_max_tensors())
 
 
@@ -1188,8 +1269,9 @@ class WeightedSumFn(torch.autograd.Function):
     def forward(ctx, weights, *terms):
         n = len(terms)
         ts = [t.reshape(1).contiguous() for t in terms]
-        for t in ts:
-            _req(t, torch.float32, "loss term", 1)
+        for t in ts:  # scalars: any 4-byte aligned device float will do (e.g. one element of a [4] loss vector)
+            if not (t.is_cuda and t.dtype == torch.float32):
+                raise RuntimeError("loss term: expected a CUDA float32 scalar")
         out = torch.empty(1, dtype=torch.float32, device=ts[0].device)
         ctx.w = (ctypes.c_float * n)(*[float(w) for w in weights])
         ctx.n = n
