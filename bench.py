@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--e2e-steps", type=int, default=40, help="extra steps timed with the loader inside the loop (0: skip)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the K1 legs at C2 / C3 size and the dense-product leg")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
     return ap.parse_args()
 
@@ -101,6 +102,39 @@ def cpu_baseline(params, batch_cpu, bs, budget_s):
                       f"{dt:.1f} s, torch {torch.__version__} fp32, {cores} threads"}
 
 
+def step_algorithmic_bytes(N, A, E, E_aug, k, bs, D, HD, in_dim, T):
+    """Algorithmic HBM bytes of one pretraining step as this library runs it (DESIGN.md section 5 lists the same table):
+    what every kernel must read and write once, fp32 activations, int32 structure.  SURVEY.md section 8d's form is
+    2 B_K1(E) + 2 B_K1(E_aug) + B_K2 + decoders + c N D 4; the entries below are that sum with c spelled out."""
+    ND, AD, NH = N * D * 4, A * D * 4, N * HD * 4
+
+    def b_k1(e):  # type-indexed edge attribute, rows = the A rows that can receive edges
+        return e * D * 4 + (4 * e + T * D * 4) + 4 * e + 4 * (A + 1) + AD
+
+    t = {
+        "augment: mask_feature (read x, write x_aug) + dropout_adj on the CSR": 2 * ND + 32 * E,
+        "student K1 x2 (augmented graph)": 2 * b_k1(E_aug),
+        "teacher K1 x2 (batch graph)": 2 * b_k1(E),
+        "student layer products x2 (read h + agg, write y)": 2 * (2 * ND + AD),
+        "student BatchNorm/act/dropout x2 (read y, write h)": 2 * 2 * ND,
+        "teacher layer 1 product + normalise": (2 * ND + AD) + 2 * ND,
+        "teacher layer 2 product (statistics over all rows, seed rows written)": ND + AD + 3 * bs * D * 4,
+        "VQ project_in (read z, write xp)": ND + NH,
+        "VQ assignment (read xp; ind, norm)": NH + 12 * N * (HD // D),
+        "VQ project_out off the code table (write quantize)": ND + 8 * N * (HD // D),
+        "heads forward: lin(q) for the topology head, gathers of 3k edge endpoints": 2 * ND + 8 * k * D * 4,
+        "heads backward: zero + scatter + lin backward-data + weight gradient": ND + 2 * ND + 2 * ND + 10 * k * D * 4,
+        "seed-row heads (feat, sem) forward + backward": 12 * bs * max(D, in_dim) * 4,
+        "VQ backward: code segment sums (read g_quantize)": ND + 8 * N * (HD // D),
+        "VQ backward: assignment + project_out backward-data, fused (read g, xp; write g_xp)": ND + 2 * NH,
+        "VQ backward: project_in backward-data (read g_xp, write g_z)": NH + ND,
+        "VQ backward: project_in weight gradient (read g_xp, z)": NH + ND,
+        "encoder backward layer 2: BatchNorm sums, apply, 2 weight gradients, 2 backward-data, K2": 2 * ND + 3 * ND + 2 * ND + 2 * AD + 2 * ND + 2 * AD + (E_aug * D * 4 + 3 * ND),
+        "encoder backward layer 1: BatchNorm sums, apply, 2 weight gradients": 2 * ND + 3 * ND + 2 * ND + 2 * AD,
+    }
+    return t
+
+
 def spawn_ranks(args) -> int:
     """`python bench.py --gpus N` as a plain command: start N rank processes through torch.distributed.run (the
     launch line the driver itself uses) from THIS process, which has made no HIP call (device_count() does not
@@ -121,6 +155,35 @@ def spawn_ranks(args) -> int:
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd, env=env)
+
+
+def k1_at_full_graph_sizes(dev):
+    """K1 forward at the full-batch sizes of BASELINE configs 2 and 3 (working sets beyond the Infinity Cache), timed
+    with the library's per-launch HIP events; reported beside the C4 batch launches of `roofline`."""
+    from stem_gnn_amd import ops
+    from stem_gnn_amd.data.synthetic import make_graph
+    from stem_gnn_amd.graph import EdgeTypeAttr, GraphStructure
+    out = {}
+    for name, (n, e, d, t) in {"c2 (100k nodes, 1M edges, D=128)": (100_000, 1_000_000, 128, 4),
+                               "c3 stand-in (169,343 nodes, 2,315,598 edges, D=768)": (169_343, 2_315_598, 768, 1)}.items():
+        g = make_graph(n, e, d, t, kind="U", device=dev, graph_seed=1234, feat_seed=0)
+        x = g.node_text_feat if g.node_text_feat.size(0) == n else g.node_text_feat[g.x]
+        gs = GraphStructure(g.edge_index, n, g.xe, validate=True)
+        for _ in range(3):
+            ops.sage_agg_fwd(x, gs, None, g.edge_text_feat)
+        ops.k1_timer.reset(True)
+        for _ in range(10):
+            ops.sage_agg_fwd(x, gs, None, g.edge_text_feat)
+        torch.cuda.synchronize()
+        ms, launches, by = ops.k1_timer.collect()
+        ops.k1_timer.reset(False)
+        gbs = by / (ms * 1e-3) / 1e9
+        out[name] = {"kernel": "k_sage_agg_fwd", "avg_launch_us": ms * 1e3 / launches,
+                     "algorithmic_bytes_per_launch": by / launches, "achieved": gbs, "peak": 8000.0, "unit": "GB/s",
+                     "frac": gbs / 8000.0}
+        del g, x, gs
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -226,7 +289,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     gc.enable()
-    k1_ms, k1_launches, k1_bytes = ops.k1_timer.collect()
+    k1_rows = ops.k1_timer.collect_each()
     ops.k1_timer.reset(False)
 
     from stem_gnn_amd.parallel import reduce_bench_stats
@@ -263,14 +326,41 @@ def main():
         e2e_ms = (time.perf_counter() - t1) / max(done, 1) * 1e3
 
     if rank == 0:
-        achieved = k1_bytes / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
         peak = 8000.0  # MI355X HBM3E spec, GB/s (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+
+        def k1_class(rows):
+            ms, by, n = sum(r["ms"] for r in rows), sum(r["bytes"] for r in rows), len(rows)
+            if n == 0 or ms <= 0:
+                return None
+            gbs = by / (ms * 1e-3) / 1e9
+            return {"launches": n, "avg_launch_us": ms * 1e3 / n, "algorithmic_bytes_per_launch": by / n,
+                    "rows_per_launch": sum(r["rows"] for r in rows) / n, "edges_per_launch": sum(r["edges"] for r in rows) / n,
+                    "achieved": gbs, "frac": gbs / peak}
+
+        k1_batch = k1_class([r for r in k1_rows if not r["augmented"]])
+        k1_aug = k1_class([r for r in k1_rows if r["augmented"]])
         nb = batches[args.warmup]
-        traffic = None  # HBM bytes per K1 launch from a separate rocprofv3 --pmc pass on this workload (profiles/)
-        tpath = os.path.join(ROOT, "profiles", "k1_traffic.json")
+        # HBM bytes from the PMC counters are collected by separate rocprofv3 --pmc passes on this workload
+        # (tools/prof_pmc.sh -> profiles/step_traffic.json), NOT in this run: the file's numbers are quoted here
+        tinfo = {}
+        tpath = os.path.join(ROOT, "profiles", "step_traffic.json")
         if args.workload == "c4" and args.batch_size == 1024 and os.path.exists(tpath):
             with open(tpath) as fh:
-                traffic = json.load(fh).get("traffic_bytes_per_launch")
+                tinfo = json.load(fh)
+        head = k1_batch or k1_aug or {"achieved": 0.0, "frac": 0.0}
+        roofline = {"bound": "hbm", "kernel": "k_sage_agg_fwd (K1, type-indexed edge attr), launches on the batch graph "
+                                              "(the teacher's two per step; rows = the nodes that can receive edges)",
+                    "achieved": head["achieved"], "peak": peak, "unit": "GB/s", "frac": head["frac"],
+                    "traffic": tinfo.get("k1_batch_traffic_bytes_per_launch"),
+                    "traffic_source": "profiles/step_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                                      "of this workload; not measured in this run)",
+                    "launches": head.get("launches"), "avg_launch_us": head.get("avg_launch_us"),
+                    "algorithmic_bytes_per_launch": head.get("algorithmic_bytes_per_launch"),
+                    "rows_per_launch": head.get("rows_per_launch"), "edges_per_launch": head.get("edges_per_launch"),
+                    "augmented_graph_launches": None if k1_aug is None else dict(
+                        k1_aug, traffic=tinfo.get("k1_augmented_traffic_bytes_per_launch"),
+                        note="dropout_adj(force_undirected) keeps src <= dst edges only: ~1e4 edges survive on a "
+                             "sampled batch; the launch is at the launch floor")}
         out = {
             "metric": "pretrain edges/sec (fwd+bwd) on 1M-node/20M-edge synthetic graph, 1/2/4/8 GPUs",
             "value": edges / dt, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -283,38 +373,54 @@ def main():
                        "parallelism": f"dp{world}", "edge_attr": "type-indexed (4E + T*D*4 bytes)",
                        "loader_ms_per_batch_outside_timed_region": round(sampler_ms, 3),
                        "ms_per_step_with_loader_in_loop": None if e2e_ms is None else round(e2e_ms, 3)},
-            "roofline": {"bound": "hbm", "kernel": "k_sage_agg_fwd (K1, type-indexed edge attr)",
-                         "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
-                         "traffic": traffic, "launches": k1_launches,
-                         "avg_launch_us": (k1_ms * 1e3 / k1_launches) if k1_launches else None,
-                         "algorithmic_bytes_per_launch": (k1_bytes / k1_launches) if k1_launches else None},
+            "roofline": roofline,
         }
-        # The dense products are the largest share of the step: the layer product lin_l(agg) + lin_r(x)
-        # at this batch's row count, timed back to back.  Executed matrix-core work is six bf16 MFMA products per
-        # fp32 product (csrc/linear.hip), priced against the dense bf16 peak; informational, not the judged roofline.
-        xb = batches[args.warmup][0]
-        Mb = int(xb.size(0))
-        wl_, wr_ = model.encoder.layers[0].lin_l.weight.detach(), model.encoder.layers[0].lin_r.weight.detach()
-        bl_ = model.encoder.layers[0].lin_l.bias.detach()
-        agg_ = torch.randn_like(xb)
-        for _ in range(3):
-            ops.linear_fwd(agg_, wl_, xb, wr_, bl_, False)
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = 30
-        ev0.record()
-        for _ in range(reps):
-            ops.linear_fwd(agg_, wl_, xb, wr_, bl_, False)
-        ev1.record()
-        torch.cuda.synchronize()
-        us = ev0.elapsed_time(ev1) / reps * 1e3
-        flop = 2.0 * Mb * (2 * D) * D
-        x3 = ops.linear_set_mode(-1) == 1
-        out["roofline_dense"] = {
-            "bound": "mfma", "kernel": "k_linear_fwd_x3 (lin_l(agg) + lin_r(x), one launch)" if x3 else "k_linear_fwd",
-            "rows": Mb, "us_per_launch": us, "fp32_equivalent_tflops": flop / us / 1e6,
-            "achieved": (6.0 if x3 else 1.0) * flop / us / 1e6, "peak": 2500.0 if x3 else 157.0, "unit": "TFLOP/s",
-            "frac": (6.0 if x3 else 1.0) * flop / us / 1e6 / (2500.0 if x3 else 157.0),
-            "hbm_floor_us": (3.0 * Mb * D * 4) / 6.3e12 * 1e6}
+        # Step-level roofline: the algorithmic bytes of ONE step of this batch shape over the step time
+        gs = nb[1]
+        E_b = int(gs.num_edges)
+        A_b = int(gs.active_rows if gs.active_rows is not None else gs.num_nodes)
+        aug_edges = [r["edges"] for r in k1_rows if r["augmented"]]
+        E_a = int(sum(aug_edges) / len(aug_edges)) if aug_edges else E_b
+        k_s = max(int(E_b * params["topo_recon_ratio"]), 1)
+        table = step_algorithmic_bytes(int(nb[0].size(0)), A_b, E_b, E_a, k_s, int(nb[3]), D,
+                                       params["codebook_head"] * params["code_dim"], D, wl["types"])
+        alg = float(sum(table.values()))
+        step_s = dt / args.steps
+        out["roofline_step"] = {"bound": "hbm", "algorithmic_bytes": alg, "peak": peak, "unit": "GB/s",
+                                "achieved": alg / step_s / 1e9, "frac": alg / step_s / 1e9 / peak,
+                                "floor_ms_at_peak": alg / (peak * 1e9) * 1e3,
+                                "traffic": tinfo.get("traffic_bytes_per_step"),
+                                "traffic_source": roofline["traffic_source"],
+                                "c_node_level_passes": (alg - sum(v for k, v in table.items() if " K1 " in k)) / (nb[0].size(0) * D * 4),
+                                "breakdown_MB": {k: round(v / 1e6, 1) for k, v in table.items()}}
+        if not args.no_extra:
+            # The dense products are the largest share of the step: the layer product
+            # lin_l(agg) + lin_r(x) at this batch's row count, timed back to back.  Executed matrix-core work is six
+            # bf16 MFMA products per fp32 product (csrc/linear.hip), priced against the dense bf16 peak; informational.
+            xb = batches[args.warmup][0]
+            Mb = int(xb.size(0))
+            lay = model.encoder.layers[0]
+            wl_, wr_, bl_ = lay.lin_l.weight.detach(), lay.lin_r.weight.detach(), lay.lin_l.bias.detach()
+            agg_ = torch.randn(A_b, D, device=dev)
+            for _ in range(3):
+                ops.linear_fwd(agg_, wl_, xb, wr_, bl_, True, A_b)
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 30
+            ev0.record()
+            for _ in range(reps):
+                ops.linear_fwd(agg_, wl_, xb, wr_, bl_, True, A_b)
+            ev1.record()
+            torch.cuda.synchronize()
+            us = ev0.elapsed_time(ev1) / reps * 1e3
+            flop = 2.0 * (Mb + A_b) * D * D
+            x3 = ops.linear_set_mode(-1) == 1
+            out["roofline_dense"] = {
+                "bound": "hbm", "kernel": "k_linear_fwd_x3<128, true> (lin_l(agg[:A]) + lin_r(x) + BatchNorm statistics, one launch)",
+                "rows": Mb, "aggregate_rows": A_b, "us_per_launch": us, "fp32_equivalent_tflops": flop / us / 1e6,
+                "mfma_frac_of_bf16_peak": (6.0 if x3 else 1.0) * flop / us / 1e6 / (2500.0 if x3 else 157.0),
+                "algorithmic_bytes": (2.0 * Mb + A_b) * D * 4, "achieved": (2.0 * Mb + A_b) * D * 4 / us / 1e3,
+                "peak": peak, "unit": "GB/s", "frac": (2.0 * Mb + A_b) * D * 4 / us / 1e3 / peak}
+            out["configs_extra"] = k1_at_full_graph_sizes(dev)
         if world == 1 and not args.no_cpu_baseline:
             x, ei, xe, bs = batches[args.warmup]
             out["cpu_baseline"] = cpu_baseline(params, (x.cpu(), ei.edge_index.cpu(), g.edge_text_feat.cpu(), xe.cpu()), bs,

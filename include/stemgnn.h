@@ -165,6 +165,8 @@ int stemgnn_sage_agg_fwd(const float* x, int64_t num_nodes, int64_t dim,
  * and returns the summed kernel time in ms and the launch count through HOST pointers. */
 int stemgnn_profile_k1(int enable);
 int stemgnn_profile_k1_collect(double* total_ms_host, int64_t* launches_host);
+/* The same per launch, in launch order: ms_host [capacity] (HOST array), *launches_host = launches recorded. */
+int stemgnn_profile_k1_collect_each(float* ms_host, int64_t capacity, int64_t* launches_host);
 
 /*
  * K2: backward of K1 w.r.t. x (PyG autograd: index_select backward = index_add,

@@ -128,6 +128,7 @@ _SIGNATURES = {
     "stemgnn_mean_agg_bwd": (c_int, [P, I64, I64, P, P, P, P, P]),
     "stemgnn_profile_k1": (c_int, [c_int]),
     "stemgnn_profile_k1_collect": (c_int, [P, P]),
+    "stemgnn_profile_k1_collect_each": (c_int, [P, I64, P]),
     "stemgnn_inv_degree": (c_int, [P, I64, P, P]),
     "stemgnn_bn_workspace_bytes": (c_size_t, [I64, I64]),
     "stemgnn_bn_stats": (c_int, [P, I64, I64, c_float, P, P, P, P, c_float, P, c_size_t, P]),

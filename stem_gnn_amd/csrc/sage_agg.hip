@@ -14,6 +14,8 @@
 //   A = E*D*4 + 4E (dense edge_attr rows + edge ids)  |  4E + T*D*4 (edge-type ids + table)
 #include "common.h"
 
+#include <cstdlib>
+
 #include <hip/hip_ext.h>
 #include <mutex>
 #include <utility>
@@ -105,7 +107,7 @@ __device__ __forceinline__ void plan_append(const SplitArgs& sp, int row, int be
 // ---------------------------------------------------------------------------------------
 // Forward.  G lanes per destination row, each lane owns V float4 columns (col = lane + G*v).
 // ---------------------------------------------------------------------------------------
-template <int G, int V, int MODE, int R>
+template <int G, int V, int MODE, int R, int UU = 0>
 __global__ void __launch_bounds__(kBlock)
 k_sage_agg_fwd(const float* __restrict__ x, int64_t N, int D, const int32_t* __restrict__ rowptr,
                const int32_t* __restrict__ src, const int32_t* __restrict__ aux,  // eid (dense) or etype per slot
@@ -113,7 +115,9 @@ k_sage_agg_fwd(const float* __restrict__ x, int64_t N, int D, const int32_t* __r
                float* __restrict__ agg, int relu, SplitArgs sp) {
   extern __shared__ __attribute__((aligned(16))) float lds_tab[];
   constexpr int kGroups = kBlock / G;
-  constexpr int U = V <= 3 ? 4 : (V == 4 ? 2 : 1);  // neighbour rows in flight per group (8 measured slower)
+  // neighbour rows in flight per group: 4 on full graphs (8 measured slower there); UU overrides it for launches over
+  // the ~1e4 active rows of a sampled batch, which are a chain of round trips and want a whole row's edges in flight
+  constexpr int U = UU ? UU : (V <= 3 ? 4 : (V == 4 ? 2 : 1));
   const int lane = threadIdx.x % G;
   const int group = threadIdx.x / G;
   const int nvec = D / 4;
@@ -437,7 +441,7 @@ inline bool pick_geometry(int64_t D, Geometry* g) {
   return true;
 }
 
-template <int G, int V, int MODE, int R>
+template <int G, int V, int MODE, int R, int UU = 0>
 int launch_fwd_r(size_t lds, dim3 grid, hipStream_t st, const float* x, int64_t N, int D, const int32_t* rowptr,
                  const int32_t* src, const int32_t* aux, const float* ea, const float* etab, int64_t T, float* agg,
                  int relu, SplitArgs sp) {
@@ -453,10 +457,10 @@ int launch_fwd_r(size_t lds, dim3 grid, hipStream_t st, const float* x, int64_t 
     }
   }
   if (ev0) {
-    hipExtLaunchKernelGGL((k_sage_agg_fwd<G, V, MODE, R>), grid, dim3(kBlock), lds, st, ev0, ev1, 0, x, N, D, rowptr,
+    hipExtLaunchKernelGGL((k_sage_agg_fwd<G, V, MODE, R, UU>), grid, dim3(kBlock), lds, st, ev0, ev1, 0, x, N, D, rowptr,
                           src, aux, ea, etab, T, agg, relu, sp);
   } else {
-    k_sage_agg_fwd<G, V, MODE, R><<<grid, kBlock, lds, st>>>(x, N, D, rowptr, src, aux, ea, etab, T, agg, relu, sp);
+    k_sage_agg_fwd<G, V, MODE, R, UU><<<grid, kBlock, lds, st>>>(x, N, D, rowptr, src, aux, ea, etab, T, agg, relu, sp);
   }
   STEMGNN_LAUNCH_CHECK();
   return STEMGNN_OK;
@@ -466,11 +470,17 @@ template <int G, int V, int MODE>
 int launch_fwd_one(size_t lds, dim3 units, hipStream_t st, const float* x, int64_t N, int D, const int32_t* rowptr,
                    const int32_t* src, const int32_t* aux, const float* ea, const float* etab, int64_t T,
                    float* agg, int relu, SplitArgs sp) {
-  // Two rows per group on small launches without a split plan (sampler batches): measured on C4 batches 22.3 -> 20.1
-  // us (batch graph) and 10.9 -> 10.5 us (augmented graph); neutral at 100k rows / 1M edges (78.0 vs 78.5 us),
-  // slower with a split plan on a skewed graph (95 -> 110 us) and at 4 rows per group (22.8 us).
+  // Launch shape by row count (no split plan, D <= 256).  Measured on C4 batches (tools/k1_batch_probe.py):
+  //  * launches over ALL rows of a sampled batch (1e5 rows, 89 % of them empty): two rows per group, 22.3 -> 20.1 us;
+  //  * launches over the ~1.1e4 rows that can receive edges (what the encoder phase issues; every row has ~10 edges):
+  //    one row per group, four source rows in flight -- 14.1 -> 12.9 us on the batch graph, 6.8 -> 5.2 us on the
+  //    augmented graph (eight or twelve rows in flight and two rows per group were all slower);
+  //  * 1e5 rows / 1e6 edges and beyond: one row per group (78.0 vs 78.5 us), also with a split plan (95 vs 110 us).
   const bool small = V == 1 && sp.counts == nullptr && N <= (1 << 18);
-  if (small) return launch_fwd_r<G, V, MODE, (V == 1 ? 2 : 1)>(lds, units, st, x, N, D, rowptr, src, aux, ea, etab, T, agg, relu, sp);
+  static const int variant = [] { const char* e = getenv("STEMGNN_K1_VARIANT"); return e ? atoi(e) : 0; }();
+  if (small && variant == 2) return launch_fwd_r<G, V, MODE, 1, (V == 1 ? 8 : 0)>(lds, units, st, x, N, D, rowptr, src, aux, ea, etab, T, agg, relu, sp);
+  if (small && variant == 3) return launch_fwd_r<G, V, MODE, (V == 1 ? 2 : 1), (V == 1 ? 8 : 0)>(lds, units, st, x, N, D, rowptr, src, aux, ea, etab, T, agg, relu, sp);
+  if (small && (N > 32768 || variant == 9)) return launch_fwd_r<G, V, MODE, (V == 1 ? 2 : 1)>(lds, units, st, x, N, D, rowptr, src, aux, ea, etab, T, agg, relu, sp);
   return launch_fwd_r<G, V, MODE, 1>(lds, units, st, x, N, D, rowptr, src, aux, ea, etab, T, agg, relu, sp);
 }
 
@@ -620,6 +630,26 @@ int stemgnn_mean_agg_fwd(const float* x, int64_t N, int64_t D, const int32_t* ro
 int stemgnn_profile_k1(int enable) {
   std::lock_guard<std::mutex> lock(g_k1_profile.mu);
   g_k1_profile.enabled = enable != 0;
+  return STEMGNN_OK;
+}
+
+int stemgnn_profile_k1_collect_each(float* ms_host, int64_t capacity, int64_t* launches_host) {
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;
+  {
+    std::lock_guard<std::mutex> lock(g_k1_profile.mu);
+    evs.swap(g_k1_profile.events);
+  }
+  int64_t i = 0;
+  for (auto& pr : evs) {
+    STEMGNN_HIP_TRY(hipEventSynchronize(pr.second));
+    float ms = 0.f;
+    STEMGNN_HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
+    if (ms_host && i < capacity) ms_host[i] = ms;
+    ++i;
+    (void)hipEventDestroy(pr.first);
+    (void)hipEventDestroy(pr.second);
+  }
+  if (launches_host) *launches_host = i;
   return STEMGNN_OK;
 }
 

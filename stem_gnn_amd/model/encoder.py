@@ -202,6 +202,8 @@ class Encoder(nn.Module):
         self._router_cache: Optional[list] = None
         self._cache_router = False
         self.last_dropout_keys: List[Tuple[int, int]] = []  # (seed, offset) per fused dropout of the last call
+        self.gumbel_noise: Optional[list] = None    # injected Gumbel(0, 1) draws, one [N, experts] tensor per MoE layer
+        self.last_gumbel_noise: List[Tensor] = []   # the draws the last training forward used
 
         self.moe_layer_flags = self._build_moe_layer_flags()
         dims = [input_dim] + [hidden_dim] * num_layers
@@ -215,25 +217,21 @@ class Encoder(nn.Module):
         self.reset_parameters()
 
     def _build_moe_layer_flags(self):
-        if not self.moe:
-            return [False] * self.num_layers
-        if self.moe_layers == "all":
-            return [True] * self.num_layers
-        if self.moe_layers == "last":
-            flags = [False] * self.num_layers
-            if self.num_layers > 0:
-                flags[-1] = True
-            return flags
-        if self.moe_layers == "none":
-            return [False] * self.num_layers
-        raise ValueError(f"Unsupported moe_layers setting: {self.moe_layers}")
+        """Which layers are mixture layers: every one ('all'), the last one ('last') or none (encoder.py:139-156)."""
+        n = self.num_layers
+        if not self.moe or self.moe_layers == "none":
+            return [False] * n
+        if self.moe_layers not in ("all", "last"):
+            raise ValueError(f"Unsupported moe_layers setting: {self.moe_layers}")
+        return [self.moe_layers == "all" or i == n - 1 for i in range(n)]
 
     def _build_conv(self, in_dim, out_dim):
         return MySAGEConv(in_dim, out_dim, aggr="mean", normalize=False, root_weight=True)
 
     def _reg_loss(self, weights, logits):
-        log_pi = logits - torch.logsumexp(logits, dim=-1, keepdim=True)
-        return torch.mean(torch.sum(weights * log_pi, dim=-1))
+        """E_nodes[sum_k w_k log softmax(logits)_k]: the routing weights' cross entropy against the router's own
+        distribution, sign as in the reference (encoder.py:202-204)."""
+        return (weights * F.log_softmax(logits, dim=-1)).sum(dim=-1).mean()
 
     def reset_parameters(self):
         for layer in self.layers:
@@ -245,45 +243,43 @@ class Encoder(nn.Module):
         self._last_env_reg = None
         self._moe_usage = None
 
-    # -- router bookkeeping (encoder.py:219-277) ------------------------------------------
+    # -- router bookkeeping ------------------------------------------------------------------
+    # Interface kept from the reference (encoder.py:219-277): enable_router_cache / get_router_cache hand back the
+    # routing weights of every MoE layer seen since the last reset; get_moe_usage reports, per MoE layer, the mean
+    # routing probability and the share of nodes whose top expert it was.
     def enable_router_cache(self, flag: bool = True):
-        self._cache_router = flag
+        self._cache_router = bool(flag)
         self._router_cache = [] if flag else None
 
     def get_router_cache(self, reset: bool = True):
-        out = self._router_cache or []
+        cached = list(self._router_cache or ())
         if reset:
-            self._router_cache = [] if self._cache_router else None
-        return out
+            self.enable_router_cache(self._cache_router)
+        return cached
 
     def _update_moe_usage(self, env_idx, weights):
-        weights = weights.detach()
+        """Accumulate [sum of probabilities | top-1 counts] per expert and the node count, on the device."""
+        w = weights.detach()
         if self._moe_usage is None:
-            self._moe_usage = [{"sum_prob": torch.zeros(self.num_experts, device=weights.device, dtype=weights.dtype),
-                                "sum_top1": torch.zeros(self.num_experts, device=weights.device, dtype=weights.dtype),
-                                "count": 0} for f in self.moe_layer_flags if f]
-        stats = self._moe_usage[env_idx]
-        stats["sum_prob"] += weights.sum(dim=0)
-        top1 = F.one_hot(weights.argmax(dim=-1), num_classes=self.num_experts).type_as(weights)
-        stats["sum_top1"] += top1.sum(dim=0)
-        stats["count"] += weights.size(0)
+            self._moe_usage = [None] * sum(self.moe_layer_flags)
+        top1 = torch.zeros_like(w).scatter_(1, w.argmax(dim=-1, keepdim=True), 1.0)
+        tally = torch.stack([w.sum(dim=0), top1.sum(dim=0)])           # [2, experts]
+        prev = self._moe_usage[env_idx]
+        self._moe_usage[env_idx] = (tally, w.size(0)) if prev is None else (prev[0] + tally, prev[1] + w.size(0))
 
     def get_moe_usage(self, reset=True):
-        if not self.moe or self._moe_usage is None:
-            return []
-        usage, env_idx = [], 0
-        for layer_idx, flag in enumerate(self.moe_layer_flags):
-            if not flag:
-                continue
-            stats = self._moe_usage[env_idx]
-            denom = max(stats["count"], 1)
-            usage.append({"layer": layer_idx,
-                          "avg_prob": (stats["sum_prob"] / denom).detach().cpu().tolist(),
-                          "top1_frac": (stats["sum_top1"] / denom).detach().cpu().tolist()})
-            env_idx += 1
-        if reset:
-            self._moe_usage = None
-        return usage
+        report = []
+        if self.moe and self._moe_usage is not None:
+            moe_layers = [i for i, flag in enumerate(self.moe_layer_flags) if flag]
+            for layer_idx, entry in zip(moe_layers, self._moe_usage):
+                if entry is None:
+                    continue
+                tally, nodes = entry
+                mean = (tally / max(nodes, 1)).cpu().tolist()
+                report.append({"layer": layer_idx, "avg_prob": mean[0], "top1_frac": mean[1]})
+            if reset:
+                self._moe_usage = None
+        return report
 
     # -- forward --------------------------------------------------------------------------
     def forward(self, x, edge_index, edge_attr=None):
@@ -382,13 +378,22 @@ class Encoder(nn.Module):
         env_idx = 0
         env_reg_total: Optional[Tensor] = None
         env_layers = 0
+        self.last_gumbel_noise = []
 
         for i in range(self.num_layers):
             layer = self.layers[i]
             if isinstance(layer, MixtureSageLayer):
                 logits = self.env_encoders[env_idx](z)
                 if self.training:
-                    weights = F.gumbel_softmax(logits, tau=self.tau, dim=-1)
+                    # F.gumbel_softmax(logits, tau) (encoder.py:294) = softmax((logits + G) / tau), G ~ Gumbel(0, 1);
+                    # the draw is kept (last_gumbel_noise) and can be injected (gumbel_noise) so that a parity test
+                    # replays the same routing through the oracle
+                    if self.gumbel_noise is not None:
+                        gumbel = self.gumbel_noise[env_idx].to(logits)
+                    else:
+                        gumbel = -torch.empty_like(logits).exponential_().log()
+                    self.last_gumbel_noise.append(gumbel)
+                    weights = F.softmax((logits + gumbel) / self.tau, dim=-1)
                     reg = self._reg_loss(weights, logits)
                     env_reg_total = reg if env_reg_total is None else env_reg_total + reg
                     env_layers += 1

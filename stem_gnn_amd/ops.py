@@ -241,7 +241,8 @@ def inv_degree(rowptr: Tensor) -> Tensor:
 class KernelTimer:
     """In-situ timing of every K1-forward launch (bench.py's roofline leg).  The library stamps
     each launch with its own begin/end HIP events (hipExtLaunchKernelGGL), so the time is the
-    kernel's, not the gap-inclusive span between marker packets."""
+    kernel's, not the gap-inclusive span between marker packets.  ``bytes`` lists, in launch order, what each launch
+    worked on: (rows computed, graph, D, edge mode, T)."""
 
     def __init__(self):
         self.enabled = False
@@ -254,10 +255,21 @@ class KernelTimer:
 
     def collect(self):
         """-> (total kernel ms, launches, total algorithmic bytes)"""
-        ms, n = ctypes.c_double(0.0), ctypes.c_int64(0)
-        check(lib.stemgnn_profile_k1_collect(ctypes.byref(ms), ctypes.byref(n)), "profile_k1_collect")
-        total = sum(k1_algorithmic_bytes(N, g.live_edges_host(), D, mode, T) for (N, g, D, mode, T) in self.bytes)
-        return ms.value, n.value, float(total)
+        rows = self.collect_each()
+        return sum(r["ms"] for r in rows), len(rows), float(sum(r["bytes"] for r in rows))
+
+    def collect_each(self):
+        """-> one dict per launch, in launch order: ms, algorithmic bytes, rows, live edges, augmented (bool)."""
+        cap = max(len(self.bytes), 1) + 64
+        ms = (ctypes.c_float * cap)()
+        n = ctypes.c_int64(0)
+        check(lib.stemgnn_profile_k1_collect_each(ms, cap, ctypes.byref(n)), "profile_k1_collect_each")
+        out = []
+        for i, (N, g, D, mode, T) in enumerate(self.bytes[:n.value]):
+            E = g.live_edges_host()
+            out.append(dict(ms=float(ms[i]), bytes=k1_algorithmic_bytes(N, E, D, mode, T), rows=N, edges=E,
+                            augmented=g._edge_index is None))
+        return out
 
 
 k1_timer = KernelTimer()
@@ -265,7 +277,8 @@ k1_timer = KernelTimer()
 
 def k1_algorithmic_bytes(N: int, E: int, D: int, mode: str, T: int = 0) -> int:
     """SURVEY.md §8d: E*D*4 (source rows) + A + 4E (src ids) + 4(N+1) (rowptr) + N*D*4 (output);
-    A = E*D*4 + 4E (dense rows + edge ids) | 4E + T*D*4 (type ids + table) | 0."""
+    A = E*D*4 + 4E (dense rows + edge ids) | 4E + T*D*4 (type ids + table) | 0.  N = the rows the launch computes
+    and writes (a sampled batch: only the rows that can receive edges)."""
     a = {"dense": E * D * 4 + 4 * E, "table": 4 * E + T * D * 4, "none": 0}[mode]
     return E * D * 4 + a + 4 * E + 4 * (N + 1) + N * D * 4
 
@@ -498,6 +511,10 @@ class EncoderFn(torch.autograd.Function):
         T = 0 if etab is None else etab.size(0)
         check(lib.stemgnn_encoder_fwd(ctypes.byref(gv), _p(x), _p(dense), _p(etab), T, arr, ctypes.byref(cfg), _p(z),
                                       _p(save), save.numel(), _stream()), "encoder_fwd")
+        if k1_timer.enabled and A > 0:  # one K1 launch per layer, over the rows that can receive edges
+            mode = "dense" if dense is not None else ("table" if etab is not None else "none")
+            for l in range(len(arr)):
+                k1_timer.bytes.append((A, graph, int(arr[l].in_dim), mode, T))
         ctx.graph, ctx.meta = graph, meta
         ctx.save_for_backward(x, dense, etab, save, z, *params)
         return z
@@ -628,7 +645,9 @@ def linear_fwd(x1: Tensor, w1: Tensor, x2: Optional[Tensor], w2: Optional[Tensor
         _req(x2, torch.float32, "x2", 2)
         _req(w2, torch.float32, "w2", 2)
         K2 = x2.size(1)
-        if x2.size(0) != M or tuple(w2.shape) != (N, K2):
+        if 0 <= x1_rows <= x1.size(0) and x1.size(0) < x2.size(0):
+            M = x2.size(0)  # x1 holds its x1_rows meaningful rows only (rows past them count as zero, never read)
+        if x2.size(0) != M or tuple(w2.shape) != (N, K2) or (x1.size(0) != M and x1.size(0) < x1_rows):
             raise RuntimeError("linear: second operand pair has inconsistent shapes")
     if bias is not None:
         _req(bias, torch.float32, "bias", 1)

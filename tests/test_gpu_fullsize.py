@@ -109,6 +109,56 @@ def test_sampler_contract_on_the_20m_edge_graph(dev, c4_graph):
     assert int((s.local_of != -2 ** 31).sum()) == 0
 
 
+def test_pretrain_step_on_a_real_c4_batch_matches_oracle(dev, c4_graph):
+    """The benchmark's own step shape against the CPU oracle: one neighbour-sampled batch of the 1M-node / 20M-edge
+    graph (1 024 seeds, fan-out [10, 10], D = 128, H = 4, K = 128: ~1e5 nodes, ~1.1e5 edges), the HIP run's draws
+    replayed.  Every loss term to 1e-4 (north_star), two optimiser steps, parameters compared after them."""
+    import torch.nn as nn
+    from oracle import stem_oracle as O  # checker only
+    from stem_gnn_amd import ops
+    from stem_gnn_amd.data.sampler import HipNeighborSampler
+    from stem_gnn_amd.graph import EdgeTypeAttr
+    from stem_gnn_amd.model.encoder import Encoder, InnerProductDecoder
+    from stem_gnn_amd.model.pt_model import PretrainModel
+    from stem_gnn_amd.model.vq import VectorQuantize
+    from stem_gnn_amd.pretrain import default_params, pretrain_step
+    g = c4_graph
+    D, L, H, K, bs = 128, 2, 4, 128, 1024
+    s = HipNeighborSampler(g.edge_index, g.xe, g.num_nodes, g.x, g.node_text_feat, g.edge_text_feat, [10, 10], seed=9)
+    b = s.sample(torch.randperm(g.num_nodes, device=dev)[:bs])
+    gs = b.graph
+    n, e = b.n_id.numel(), b.edge_index.size(1)
+    assert n > 90_000 and e > 100_000 and gs.active_rows is not None and gs.active_rows < n // 5
+    torch.manual_seed(0)
+    om = O.build_oracle_model(D, L, H, K, D, dropout=0.15)
+    enc = Encoder(D, D, nn.ReLU, L, backbone="sage", normalize="batch", dropout=0.15)
+    vq = VectorQuantize(dim=D, codebook_size=K, codebook_dim=D, heads=H, separate_codebook_per_head=True, decay=0.8,
+                        commitment_weight=10, use_cosine_sim=True, orthogonal_reg_weight=1, orthogonal_reg_max_codes=32,
+                        kmeans_init=False, ema_update=False)
+    gm = PretrainModel(enc, vq, nn.Linear(D, D), InnerProductDecoder(D, D), nn.Linear(2 * D, D))
+    gm.load_state_dict(om.state_dict())
+    gm = gm.to(dev)
+    params = default_params()
+    x = ops.gather_rows(g.node_text_feat, b.x.contiguous())
+    opt_o = torch.optim.AdamW(om.parameters(), lr=1e-4, weight_decay=1e-5)
+    opt_g = torch.optim.AdamW(gm.parameters(), lr=1e-4, weight_decay=1e-5)
+    ops.manual_seed(31)
+    x_cpu, ei_cpu, ea_cpu = x.cpu(), b.edge_index.cpu(), g.edge_text_feat[b.xe].cpu()
+    torch.set_num_threads(max(torch.get_num_threads(), 8))
+    for step in range(2):
+        loss_g, losses_g, draws = pretrain_step(gm, opt_g, None, params, x, gs, EdgeTypeAttr(g.edge_text_feat, b.xe), bs)
+        cpu_draws = {k: ([m.cpu() for m in v] if isinstance(v, list) else v.cpu()) for k, v in draws.items()}
+        loss_o, losses_o, _ = O.pretrain_step(om, opt_o, None, params, x_cpu, ei_cpu, ea_cpu, bs, cpu_draws)
+        for k in losses_o:
+            torch.testing.assert_close(losses_g[k].cpu().reshape(-1), losses_o[k].reshape(-1), rtol=1e-4, atol=1e-5,
+                                       msg=lambda m: f"step {step} {k}: {m}")
+        torch.testing.assert_close(loss_g.cpu().reshape(-1), loss_o.reshape(-1), rtol=1e-4, atol=1e-5)
+    for (n1, p1), (n2, p2) in zip(om.named_parameters(), gm.named_parameters()):
+        if "lin_l.bias" in n1 or n1.startswith("sem_encoder"):
+            continue  # exactly-zero true gradient in front of BatchNorm (rounding noise through Adam); teacher: EMA
+        torch.testing.assert_close(p2.detach().cpu(), p1.detach(), rtol=1e-3, atol=3e-4, msg=lambda m: f"{n1}: {m}")
+
+
 def test_c3_sized_full_batch_step_runs_and_learns(dev):
     """BASELINE config 3 stand-in (169,343 nodes, 2,315,598 directed entries, D = 768, K = 512, full batch): too big
     for the CPU oracle, so the step is checked through properties: finite decreasing loss, in-range codes, a used

@@ -464,3 +464,165 @@ def test_pretrain_step_on_sampler_batch_matches_oracle(dev):
         if "lin_l.bias" in n1 or n1.startswith("sem_encoder"):
             continue
         torch.testing.assert_close(p2.detach().cpu(), p1.detach(), rtol=1e-3, atol=3e-4, msg=lambda m: f"{n1}: {m}")
+
+
+def test_moe_encoder_train_mode_matches_oracle(dev):
+    """--moe in TRAINING mode (reference encoder.py:292-309, 202-204): Gumbel-softmax routing and the environment
+    regulariser.  The HIP run's Gumbel draws are recorded (Encoder.last_gumbel_noise) and replayed through the oracle;
+    then the oracle's path is checked the other way round with injected noise.  env_reg_loss is non-zero and matches,
+    and so do the output and every gradient."""
+    from stem_gnn_amd.model.encoder import Encoder
+    N, E, D = 300, 2500, 32
+    torch.manual_seed(4)
+    oe = O.OracleEncoder(D, D, 2, normalize="batch", dropout=0.0, moe=True, num_experts=3, moe_layers="all", tau=0.7)
+    ge = Encoder(D, D, nn.ReLU, 2, normalize="batch", dropout=0.0, moe=True, num_experts=3, tau=0.7, moe_layers="all")
+    ge.load_state_dict(oe.state_dict())
+    ge = ge.to(dev)
+    x = torch.randn(N, D)
+    ei = torch.randint(0, N, (2, E))
+    w = torch.randn(N, D)
+    oe.train(); ge.train()
+    for inject in (False, True):
+        noise = [-torch.empty(N, 3).exponential_().log() for _ in range(2)] if inject else None
+        ge.gumbel_noise = None if noise is None else [t.to(dev) for t in noise]
+        ge.zero_grad(); oe.zero_grad()
+        zg = ge(x.to(dev), ei.to(dev))
+        reg_g = ge.get_env_reg()
+        used = [t.cpu() for t in ge.last_gumbel_noise]
+        assert len(used) == 2 and all(tuple(t.shape) == (N, 3) for t in used)
+        if inject:
+            assert all(torch.equal(a, b) for a, b in zip(used, noise))
+        zo = oe(x, ei, gumbel_noise=used)
+        reg_o = oe.get_env_reg()
+        assert abs(float(reg_o)) > 1e-3  # the regulariser is live in this mode
+        torch.testing.assert_close(reg_g.cpu().reshape(-1), reg_o.reshape(-1), rtol=1e-4, atol=1e-6)
+        torch.testing.assert_close(zg.detach().cpu(), zo.detach(), rtol=1e-4, atol=1e-4)
+        ((zg * w.to(dev)).sum() + 3.0 * reg_g.sum()).backward()
+        ((zo * w).sum() + 3.0 * reg_o.sum()).backward()
+        for (n1, p1), (n2, p2) in zip(oe.named_parameters(), ge.named_parameters()):
+            assert n1 == n2
+            scale = max(p1.grad.abs().max().item(), 1.0)
+            torch.testing.assert_close(p2.grad.cpu(), p1.grad, rtol=1e-3, atol=1e-4 * scale, msg=lambda m: f"{n1}: {m}")
+    usage = ge.get_moe_usage()
+    assert [u["layer"] for u in usage] == [0, 1] and all(abs(sum(u["avg_prob"]) - 1.0) < 1e-4 for u in usage)
+    assert all(abs(sum(u["top1_frac"]) - 1.0) < 1e-6 for u in usage) and ge.get_moe_usage() == []
+
+
+def _ddp_worker(rank, world, port, out):
+    """One rank of the 2-rank HIP data-parallel test (both ranks on cuda:0, gloo for the collective)."""
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from stem_gnn_amd import ops, parallel
+    from stem_gnn_amd.graph import EdgeTypeAttr
+    from stem_gnn_amd.pretrain import default_params, pretrain_step
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo")
+    torch.manual_seed(0)
+    D, L, H, K = 64, 2, 4, 64
+    _, gm = make_models(D, L, H, K, D, dev)
+    for p in gm.sem_encoder.parameters():
+        p.requires_grad_(False)
+    params = default_params()
+    fwd = parallel.wrap_ddp(gm, 0)
+    gen = torch.Generator().manual_seed(100)
+    batches = []
+    for r in range(world):
+        N, E = 500 + 40 * r, 4000 + 100 * r
+        x = torch.nn.functional.normalize(torch.randn(N, D, generator=gen), dim=-1)
+        half = torch.randint(0, N, (2, E // 2), generator=gen)
+        ei = torch.cat([half, half.flip(0)], dim=1)
+        table = torch.nn.functional.normalize(torch.randn(4, D, generator=gen), dim=-1)
+        et = torch.randint(0, 4, (E,), generator=gen)
+        batches.append((x, ei, table, et))
+    x, ei, table, et = batches[rank]
+
+    class NoStep:  # gradients only: the optimiser must not move the weights
+        def zero_grad(self, set_to_none=True):
+            for p in gm.parameters():
+                p.grad = None
+
+        def step(self, *a, **k):
+            pass
+
+    res = {}
+
+    def capture():  # runs between backward and clipping (pretrain_step's grad_sync hook): the reducer has finished
+        torch.cuda.synchronize()
+        res.update({n: p.grad.detach().cpu().clone() for n, p in gm.named_parameters() if p.grad is not None})
+
+    ops.manual_seed(1000 + rank)
+    gm.train()
+    pretrain_step(gm, NoStep(), None, params, x.to(dev), ei.to(dev), EdgeTypeAttr(table.to(dev), et.to(dev)), 128,
+                  record_draws=False, forward_fn=fwd, grad_sync=capture)
+    torch.cuda.synchronize()
+    out[rank] = res
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_hip_ddp_averages_gradients(dev):
+    """Two ranks of the HIP PretrainModel under wrap_ddp (DistributedDataParallel; both ranks on the one card, gloo
+    moving the buckets): every rank ends with the same gradients, and they are the mean of the two ranks' own
+    gradients as one process computes them for the same two batches and draws (custom autograd phases under the
+    reducer, teacher excluded, BatchNorm statistics per rank)."""
+    import socket
+    import torch.multiprocessing as mp
+    from stem_gnn_amd import ops
+    from stem_gnn_amd.graph import EdgeTypeAttr
+    from stem_gnn_amd.pretrain import default_params, pretrain_step
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    mgr = ctx.Manager()
+    out = mgr.dict()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=280)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    g0, g1 = out[0], out[1]
+    assert set(g0) == set(g1) and not any(k.startswith("sem_encoder") for k in g0)
+    for k in g0:
+        torch.testing.assert_close(g0[k], g1[k], rtol=0, atol=0, msg=lambda m: f"{k}: ranks disagree: {m}")
+    # the same two batches in one process, gradients accumulated by hand
+    torch.manual_seed(0)
+    D, L, H, K = 64, 2, 4, 64
+    _, gm = make_models(D, L, H, K, D, dev)
+    params = default_params()
+    gen = torch.Generator().manual_seed(100)
+    acc = {}
+    for r in range(2):
+        N, E = 500 + 40 * r, 4000 + 100 * r
+        x = torch.nn.functional.normalize(torch.randn(N, D, generator=gen), dim=-1)
+        half = torch.randint(0, N, (2, E // 2), generator=gen)
+        ei = torch.cat([half, half.flip(0)], dim=1)
+        table = torch.nn.functional.normalize(torch.randn(4, D, generator=gen), dim=-1)
+        et = torch.randint(0, 4, (E,), generator=gen)
+
+        class NoStep:
+            def zero_grad(self, set_to_none=True):
+                for p in gm.parameters():
+                    p.grad = None
+
+            def step(self, *a, **k):
+                pass
+
+        def capture():
+            for n, p in gm.named_parameters():
+                if p.grad is not None and not n.startswith("sem_encoder"):
+                    acc[n] = acc.get(n, 0) + p.grad.detach().cpu() / 2
+
+        ops.manual_seed(1000 + r)
+        gm.train()
+        # BatchNorm buffers and the EMA teacher move during a step; every rank of the DDP run starts from the initial state
+        state = {k: v.clone() for k, v in gm.state_dict().items()}
+        pretrain_step(gm, NoStep(), None, params, x.to(dev), ei.to(dev), EdgeTypeAttr(table.to(dev), et.to(dev)), 128,
+                      record_draws=False, grad_sync=capture)
+        gm.load_state_dict(state)
+    for k in g0:
+        scale = max(acc[k].abs().max().item(), 1e-6)
+        torch.testing.assert_close(g0[k], acc[k], rtol=1e-4, atol=1e-5 * max(scale, 1.0), msg=lambda m: f"{k}: {m}")
