@@ -35,10 +35,11 @@ WORKLOADS = {
     "c3": dict(nodes=169_343, edges=2_315_598, dim=768, types=1, full_batch=True, codebook=512,
                desc="C3 stand-in: ogbn-arxiv-sized (169,343 nodes, 2,315,598 directed entries after ToUndirected), "
                     "D=768, K=512, full batch"),
-    "c5": dict(nodes=2_000_000, edges=8_000_000, dim=768, types=12, full_batch=False, codebook=2048,
-               feat_rows=300_000,
-               desc="C5 stand-in: multi-dataset mix as one 2M-node/8M-edge union graph, 300k-row text table, 12 edge "
-                    "types, D=768, K=2048, neighbour-sampled [10,10], 1024 seeds/rank"),
+    "c5": dict(nodes=0, edges=0, dim=768, types=0, full_batch=False, codebook=2048, mix="all",
+               desc="C5 stand-in: --pretrain_dataset all as a union of nine synthetic member graphs with the real "
+                    "datasets' node / edge / text-row / edge-type counts (molecule sets scaled to 1.2M nodes), seeds "
+                    "weighted per member (config/pt_data.yaml) and rebuilt per epoch, D=768, K=2048, "
+                    "neighbour-sampled [10,10], 1024 seeds/rank"),
 }
 
 
@@ -219,8 +220,13 @@ def main():
     seed_everything(params["seed"])
 
     # ---- data: identical synthetic graph on every rank (replicated structure + features)
-    g = make_graph(wl["nodes"], wl["edges"], D, wl["types"], kind="U", device=dev, graph_seed=1234, feat_seed=0,
-                   feat_rows=wl.get("feat_rows", 0))
+    if wl.get("mix"):
+        from stem_gnn_amd.data.multi import mix_weights, synthetic_mix
+        g = synthetic_mix(wl["mix"], dim=D, device=dev, seed=1234)
+        wl = dict(wl, nodes=g.num_nodes, edges=int(g.edge_index.size(1)), types=int(g.edge_text_feat.size(0)))
+    else:
+        g = make_graph(wl["nodes"], wl["edges"], D, wl["types"], kind="U", device=dev, graph_seed=1234, feat_seed=0,
+                       feat_rows=wl.get("feat_rows", 0))
     total = args.steps + args.warmup
     batches = []
     # The loader hands every batch over in the kernels' native layout (both CSR views + edge types
@@ -234,8 +240,13 @@ def main():
     else:
         sampler = HipNeighborSampler(g.edge_index, g.xe, g.num_nodes, g.x, g.node_text_feat, g.edge_text_feat,
                               [10] * params["num_layers"], seed=100 + rank)
-        loader = NeighborLoader(sampler, torch.arange(g.num_nodes, device=dev), args.batch_size, shuffle=True,
-                                rank=rank, world_size=world, seed=7)
+        if wl.get("mix"):
+            from stem_gnn_amd.data.sampler import MixLoader
+            loader = MixLoader(sampler, g.ptr, list(mix_weights(wl["mix"]).values()), args.batch_size, rank=rank,
+                               world_size=world, seed=7, device=dev)
+        else:
+            loader = NeighborLoader(sampler, torch.arange(g.num_nodes, device=dev), args.batch_size, shuffle=True,
+                                    rank=rank, world_size=world, seed=7)
         def epochs():  # batch stream that starts a new epoch when a rank's shard runs out (same count on all ranks)
             while True:
                 yield from loader

@@ -596,3 +596,33 @@ def eval_link_full_batch(model: OracleTaskModel, x, edge_index, edge_attr, y, sp
         out = {k: hit[m].mean().item() * 100 for k, m in (("train", split["train"]), ("val", split["valid"]),
                                                            ("test", split["test"]))}
     return out, pred
+
+
+def get_train_node_idx(ptr, weights, generator=None):
+    """Weighted seed list of one pretraining epoch (reference dataset/process_datasets.py:186-198), restated: member i
+    of the union graph (nodes ptr[i] .. ptr[i+1]) contributes every node int(w_i) times and a random
+    int(frac(w_i) * n_i)-subset of its nodes once more."""
+    total = torch.tensor([], dtype=torch.long)
+    for i, (s, e) in enumerate(zip(ptr[:-1].tolist(), ptr[1:].tolist())):
+        arr = torch.arange(s, e)
+        whole, frac = int(weights[i]), weights[i] - int(weights[i])
+        left = arr.repeat(whole)
+        right = arr[torch.randperm(arr.size(0), generator=generator)[: int(frac * arr.size(0))]]
+        total = torch.cat([total, left, right])
+    return total
+
+
+def merge_member_graphs(members):
+    """preprocess_dataset_list + Batch.from_data_list (process_datasets.py:166-182) for members given as dicts with
+    x, xe, edge_index, node_text_feat, edge_text_feat: the shifted ids and the member node offsets."""
+    x_start = xe_start = n_start = 0
+    xs, xes, eis, ptr = [], [], [], [0]
+    for m in members:
+        xs.append(m["x"] + x_start)
+        xes.append(m["xe"] + xe_start)
+        eis.append(m["edge_index"] + n_start)
+        x_start += m["node_text_feat"].shape[0]
+        xe_start += m["edge_text_feat"].shape[0]
+        n_start += m["x"].shape[0]
+        ptr.append(n_start)
+    return torch.cat(xs), torch.cat(xes), torch.cat(eis, dim=1), torch.tensor(ptr)

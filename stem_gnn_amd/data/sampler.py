@@ -91,6 +91,35 @@ class NeighborLoader:
             yield self.sampler.sample(self.nodes[i:i + self.batch_size])
 
 
+class MixLoader:
+    """The loader of a multi-dataset mix (reference pretrain.py:144-153): the weighted seed list is REBUILT at the start
+    of every epoch (``get_train_node_idx``: random shares of the members with fractional weights change per epoch),
+    shuffled with a seed shared by all ranks, dealt round-robin to the ranks, and sampled in batches.  ``ptr`` /
+    ``weights``: member node offsets and seed weights (data/multi.py)."""
+
+    def __init__(self, sampler, ptr: Tensor, weights, batch_size: int, rank: int = 0, world_size: int = 1, seed: int = 0,
+                 device=None):
+        from .multi import get_train_node_idx
+        self._build = get_train_node_idx
+        self.sampler, self.ptr, self.weights, self.batch_size = sampler, ptr, list(weights), batch_size
+        self.rank, self.world_size, self.seed, self.epoch = rank, world_size, seed, 0
+        self.device = device if device is not None else sampler.rowptr.device
+        self.num_seeds = None
+
+    def _epoch_nodes(self) -> Tensor:
+        g = torch.Generator(device=self.device).manual_seed(self.seed + 7919 * self.epoch)  # same list on every rank
+        nodes = self._build(self.ptr, self.weights, device=self.device, generator=g)
+        nodes = nodes[torch.randperm(nodes.numel(), generator=g, device=self.device)]
+        self.num_seeds = int(nodes.numel())
+        return nodes[self.rank::self.world_size]
+
+    def __iter__(self):
+        nodes = self._epoch_nodes()
+        self.epoch += 1
+        for i in range(0, nodes.numel(), self.batch_size):
+            yield self.sampler.sample(nodes[i:i + self.batch_size])
+
+
 class PrefetchLoader:
     """Wraps a loader of device-resident batches (e.g. NeighborLoader over a HipNeighborSampler): batch i+1 is
     sampled on a side HIP stream BEFORE the caller enqueues step i, so the sampler's launches and its one

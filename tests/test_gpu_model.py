@@ -626,3 +626,45 @@ def test_two_rank_hip_ddp_averages_gradients(dev):
     for k in g0:
         scale = max(acc[k].abs().max().item(), 1e-6)
         torch.testing.assert_close(g0[k], acc[k], rtol=1e-4, atol=1e-5 * max(scale, 1.0), msg=lambda m: f"{k}: {m}")
+
+
+def test_pretrain_step_on_a_multi_dataset_mix_batch(dev):
+    """BASELINE config 5 plumbing (`--pretrain_dataset all`): a union of nine member graphs (data/multi.py), the
+    per-epoch weighted seed list, HIP-sampled batches whose edges never leave a member, 264 edge types (the type table
+    does not fit LDS: K1's global-table mode) -- and the step on such a batch against the CPU oracle."""
+    from stem_gnn_amd import ops
+    from stem_gnn_amd.data.multi import mix_weights, synthetic_mix
+    from stem_gnn_amd.data.sampler import HipNeighborSampler, MixLoader
+    from stem_gnn_amd.graph import EdgeTypeAttr
+    from stem_gnn_amd.pretrain import default_params, pretrain_step
+    D, L, H, K = 64, 2, 4, 64
+    u = synthetic_mix("all", dim=D, device=dev, scale=0.01, seed=5)
+    assert len(u.names) == 9 and u.edge_text_feat.size(0) == 1 + 1 + 1 + 1 + 11 + 237 + 4 + 4 + 4
+    weights = list(mix_weights("all").values())
+    s = HipNeighborSampler(u.edge_index, u.xe, u.num_nodes, u.x, u.node_text_feat, u.edge_text_feat, [6, 6], seed=2)
+    loader = MixLoader(s, u.ptr, weights, 128, seed=3, device=dev)
+    it = iter(loader)
+    b = next(it)
+    sizes = (u.ptr[1:] - u.ptr[:-1]).tolist()
+    assert loader.num_seeds == sum(int(w) * n + int((w - int(w)) * n) for w, n in zip(weights, sizes))
+    member = torch.bucketize(b.n_id.cpu(), u.ptr[1:], right=True)
+    ei = b.edge_index.cpu()
+    assert torch.equal(member[ei[0]], member[ei[1]])  # sampled edges stay inside their member graph
+    assert len(set(member[:128].tolist())) >= 3        # a batch mixes members
+    om, gm = make_models(D, L, H, K, D, dev)
+    params = default_params()
+    x = ops.gather_rows(u.node_text_feat, b.x.contiguous())
+    opt_o = torch.optim.AdamW(om.parameters(), lr=1e-4, weight_decay=1e-5)
+    opt_g = torch.optim.AdamW(gm.parameters(), lr=1e-4, weight_decay=1e-5)
+    ops.manual_seed(8)
+    loss_g, losses_g, draws = pretrain_step(gm, opt_g, None, params, x, b.graph, EdgeTypeAttr(u.edge_text_feat, b.xe), 128)
+    cpu_draws = {k: ([m.cpu() for m in v] if isinstance(v, list) else v.cpu()) for k, v in draws.items()}
+    loss_o, losses_o, _ = O.pretrain_step(om, opt_o, None, params, x.cpu(), ei, u.edge_text_feat[b.xe].cpu(), 128, cpu_draws)
+    for k in losses_o:
+        torch.testing.assert_close(losses_g[k].cpu().reshape(-1), losses_o[k].reshape(-1), rtol=1e-4, atol=1e-5,
+                                   msg=lambda m: f"{k}: {m}")
+    # a second epoch redraws the fractional members' share
+    first = loader._epoch_nodes()
+    loader.epoch += 1
+    second = loader._epoch_nodes()
+    assert first.numel() == second.numel() and not torch.equal(first, second)
