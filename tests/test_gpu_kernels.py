@@ -780,3 +780,129 @@ def test_linear_with_zero_tail_promise(dev, m, rows, k1, k2, n):
     torch.testing.assert_close(gp[0].grad[:rows].cpu(), ref[0].grad[:rows], rtol=1e-4, atol=1e-4)
     for i in (1, 2, 3, 4):
         torch.testing.assert_close(gp[i].grad.cpu(), ref[i].grad, rtol=1e-4, atol=2e-3 if i in (1, 3) else 1e-3)
+
+
+# ---------------------------------------------------------------------------- round-2 kernels
+@pytest.mark.parametrize("m,k1,k2,n,rows", [(1000, 128, 0, 128, -1), (777, 64, 32, 96, -1), (2000, 128, 128, 128, 300),
+                                            (130, 16, 0, 512, -1), (4097, 512, 0, 128, -1)])
+def test_plane_products_are_bit_identical_to_the_staged_ones(dev, m, k1, k2, n, rows):
+    """csrc/pgemm.hip (operands as three bf16 planes, LDS-DMA staging, transposing reads for the weight gradient)
+    runs the same six-product arithmetic as csrc/linear.hip in the same order: forward (+ concat-K, + rows that carry
+    no first operand, + BatchNorm column sums), backward-data through transposed weight planes, weight gradient."""
+    from stem_gnn_amd import ops
+    torch.manual_seed(m + n)
+    a = torch.randn(m, k1, device=dev) * (1 + 3 * torch.rand(m, 1, device=dev))
+    w = torch.randn(n, k1, device=dev) * 0.2
+    a2 = torch.randn(m, k2, device=dev) if k2 else None
+    w2 = torch.randn(n, k2, device=dev) * 0.2 if k2 else None
+    b = torch.randn(n, device=dev)
+    if rows >= 0:
+        a[rows:] = 0
+    y0, p0, _ = ops.linear_fwd(a, w, a2, w2, b, True, rows)
+    wp = ops.weight_planes([w] + ([w2] if k2 else []), [False] * (2 if k2 else 1))
+    ap = ops.split_planes(a if rows < 0 else a[:rows].contiguous()) if k2 else ops.split_planes(a)
+    y1, p1 = ops.pgemm_fwd(ap, wp[0], ops.split_planes(a2) if k2 else None, wp[1] if k2 else None, b, True, rows)
+    assert torch.equal(y1, y0)
+    torch.testing.assert_close(p1.sum(0), p0.sum(0), rtol=1e-5, atol=1e-3)  # same sums, different row tiles
+    # planes are exact: h + m + l == the fp32 value
+    pl = ops.split_planes(a).view(torch.bfloat16).float()
+    assert torch.equal((pl[0] + pl[1]) + pl[2], a)
+    # backward-data: dx = dy w through the planes of w^T
+    dy = torch.randn(m, n, device=dev)
+    d0 = ops.linear_bwd_data(dy, w)
+    d1, _ = ops.pgemm_fwd(ops.split_planes(dy), ops.weight_planes([w], [True])[0])
+    assert torch.equal(d1, d0)
+    # weight gradient (+ bias gradient: fp32 sums in a different order)
+    if n % 8 == 0 and k1 % 8 == 0:
+        w0, b0 = ops.linear_bwd_weight(dy, a, True)
+        w1, b1 = ops.pgemm_dw(ops.split_planes(dy), ops.split_planes(a), True)
+        assert torch.equal(w1, w0)
+        torch.testing.assert_close(b1, b0, rtol=1e-5, atol=1e-4 * max(b0.abs().max().item(), 1.0))
+
+
+def test_linear_row_limited_output(dev):
+    """stemgnn_linear_fwd_rows: rows past store_rows feed the column statistics but are not written."""
+    from stem_gnn_amd._lib import lib, check
+    from stem_gnn_amd import ops
+    torch.manual_seed(0)
+    m, k, n, r = 1500, 64, 128, 200
+    x, w, b = torch.randn(m, k, device=dev), torch.randn(n, k, device=dev), torch.randn(n, device=dev)
+    y0, p0, blocks = ops.linear_fwd(x, w, None, None, b, True)
+    y = torch.full((r + 50, n), 7.0, device=dev)
+    part = torch.empty_like(p0)
+    check(lib.stemgnn_linear_fwd_rows(x.data_ptr(), w.data_ptr(), k, None, None, 0, b.data_ptr(), m, n, y.data_ptr(),
+                                      part.data_ptr(), None, -1, r, torch.cuda.current_stream().cuda_stream))
+    assert torch.equal(y[:r], y0[:r]) and bool((y[r:] == 7.0).all())
+    assert torch.equal(part, p0)
+
+
+def test_sage_agg_bwd_accumulates(dev):
+    from stem_gnn_amd import ops
+    from stem_gnn_amd._lib import lib, check
+    from stem_gnn_amd.graph import GraphStructure
+    n, e, d = 400, 3000, 64
+    torch.manual_seed(1)
+    ei = torch.randint(0, n, (2, e))
+    ei[0, :200] = torch.randint(0, 50, (200,))  # some nodes have no out-edges at all
+    gs = GraphStructure(ei.to(dev), n).ensure_transpose()
+    x, g, base = torch.randn(n, d, device=dev), torch.randn(n, d, device=dev), torch.randn(n, d, device=dev)
+    ref = ops.sage_agg_bwd(g, x, gs, None, None)
+    out = base.clone()
+    check(lib.stemgnn_sage_agg_bwd_acc(g.data_ptr(), x.data_ptr(), n, d, gs.rowptr_t.data_ptr(), gs.dst_t.data_ptr(),
+                                       gs.eid_t.data_ptr(), gs.inv_deg.data_ptr(), None, None, None, 0, out.data_ptr(),
+                                       torch.cuda.current_stream().cuda_stream))
+    torch.testing.assert_close(out, base + ref, rtol=1e-6, atol=1e-6)
+    no_out = torch.bincount(ei[0], minlength=n) == 0
+    assert bool(no_out.any()) and torch.equal(out[no_out.to(dev)], base[no_out.to(dev)])  # untouched, not zeroed
+
+
+@pytest.mark.parametrize("N,H,K,D,Dc", [(1000, 4, 128, 128, 128), (333, 2, 40, 96, 48), (50, 1, 8, 32, 32), (2500, 4, 16, 64, 64)])
+def test_vq_project_out_algebra_and_fused_backward(dev, N, H, K, D, Dc):
+    """The code-table form of project_out (table read, segment-sum weight gradient) and the assignment backward with
+    project_out's backward-data product inside, against the plain products they replace."""
+    from stem_gnn_amd import ops
+    from stem_gnn_amd._lib import lib, check
+    torch.manual_seed(N + K)
+    st = torch.cuda.current_stream().cuda_stream
+    HD = H * Dc
+    embed = torch.nn.functional.normalize(torch.randn(H, K, Dc, device=dev), dim=-1) * (1 + 0.1 * torch.rand(H, K, 1, device=dev))
+    w_out, b_out = torch.randn(D, HD, device=dev) * 0.1, torch.randn(D, device=dev)
+    ind = torch.randint(0, K, (N, H), device=dev)
+    codes = torch.stack([embed[h][ind[:, h]] for h in range(H)], dim=1).reshape(N, HD)
+    # forward: table + gather-sum == project_out(codes)
+    table = torch.empty(H, K, D, device=dev)
+    check(lib.stemgnn_small_gemm(embed.data_ptr(), Dc, 1, K * Dc, w_out.data_ptr(), 1, HD, Dc, table.data_ptr(), D, 1, K * D,
+                                 K, D, Dc, H, st))
+    out = torch.empty(N, D, device=dev)
+    check(lib.stemgnn_codes_project(table.data_ptr(), ind.data_ptr(), b_out.data_ptr(), N, H, K, D, out.data_ptr(), st))
+    torch.testing.assert_close(out, codes @ w_out.t() + b_out, rtol=1e-4, atol=1e-5)
+    # backward: segment sums -> dW_out, db_out
+    g = torch.randn(N, D, device=dev)
+    sums = torch.empty(H * K, D, device=dev)
+    ws = torch.empty(lib.stemgnn_code_segment_sums_workspace_bytes(N, H, K, D), dtype=torch.uint8, device=dev)
+    check(lib.stemgnn_code_segment_sums(ind.data_ptr(), H, K, g.data_ptr(), N, D, sums.data_ptr(), ws.data_ptr(), ws.numel(), st))
+    ref_sums = torch.zeros(H, K, D, device=dev)
+    for h in range(H):
+        ref_sums[h].index_add_(0, ind[:, h], g)
+    torch.testing.assert_close(sums.view(H, K, D), ref_sums, rtol=1e-4, atol=1e-4)
+    gw = torch.empty(D, HD, device=dev)
+    check(lib.stemgnn_small_gemm(sums.data_ptr(), 1, D, K * D, embed.data_ptr(), Dc, 1, K * Dc, gw.data_ptr(), HD, 1, Dc,
+                                 D, Dc, K, H, st))
+    torch.testing.assert_close(gw, g.t() @ codes, rtol=1e-4, atol=1e-3)
+    gb = torch.empty(D, device=dev)
+    check(lib.stemgnn_segment_colsum(sums.data_ptr(), K, D, gb.data_ptr(), st))
+    torch.testing.assert_close(gb, g.sum(0), rtol=1e-4, atol=1e-3)
+    # fused assignment backward == backward-data product + assignment backward
+    xp = torch.randn(N, HD, device=dev)
+    xp[3] = 0  # a row under the eps clamp of F.normalize
+    norm = xp.view(N, H, Dc).norm(dim=-1).contiguous()
+    g_loss = torch.tensor([0.7], device=dev)
+    g_q = ops.linear_bwd_data(g, w_out)
+    ref = torch.empty_like(xp)
+    check(lib.stemgnn_vq_assign_bwd(g_q.data_ptr(), g_loss.data_ptr(), 10.0, xp.data_ptr(), norm.data_ptr(), ind.data_ptr(),
+                                    embed.data_ptr(), N, H, Dc, K, ref.data_ptr(), st))
+    got = torch.full_like(xp, float("nan"))
+    check(lib.stemgnn_vq_assign_bwd_fused(g.data_ptr(), D, w_out.data_ptr(), g_loss.data_ptr(), 10.0, xp.data_ptr(),
+                                          norm.data_ptr(), ind.data_ptr(), embed.data_ptr(), N, H, Dc, K, got.data_ptr(), st))
+    scale = ref.abs().max().item()
+    torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-6 * max(scale, 1.0))
