@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--e2e-steps", type=int, default=40, help="extra steps timed with the loader inside the loop (0: skip)")
+    ap.add_argument("--feature-dtype", default="auto", choices=["auto", "f32", "bf16"],
+                    help="storage of node features / layer outputs (auto: bf16 for c5 -- BASELINE config 5 -- else f32)")
     ap.add_argument("--no-extra", action="store_true", help="skip the K1 legs at C2 / C3 size and the dense-product leg")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
     return ap.parse_args()
@@ -227,6 +229,9 @@ def main():
     else:
         g = make_graph(wl["nodes"], wl["edges"], D, wl["types"], kind="U", device=dev, graph_seed=1234, feat_seed=0,
                        feat_rows=wl.get("feat_rows", 0))
+    feat_bf16 = args.feature_dtype == "bf16" or (args.feature_dtype == "auto" and args.workload == "c5")
+    if feat_bf16:
+        g.node_text_feat = g.node_text_feat.bfloat16()  # the feature table lives in HBM as bf16; arithmetic stays fp32
     total = args.steps + args.warmup
     batches = []
     # The loader hands every batch over in the kernels' native layout (both CSR views + edge types
@@ -376,7 +381,7 @@ def main():
             "metric": "pretrain edges/sec (fwd+bwd) on 1M-node/20M-edge synthetic graph, 1/2/4/8 GPUs",
             "value": edges / dt, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if not feat_bf16 else "f32 (arithmetic, VQ core, gradients) on bf16-stored features", "data": "synthetic",
             "config": {"workload": wl["desc"], "nodes": wl["nodes"], "edges": wl["edges"], "feat_dim": D,
                        "layers": params["num_layers"], "vq_heads": params["codebook_head"],
                        "codebook_size": params["codebook_size"], "code_dim": params["code_dim"],
@@ -408,7 +413,7 @@ def main():
             # The dense products are the largest share of the step: the layer product
             # lin_l(agg) + lin_r(x) at this batch's row count, timed back to back.  Executed matrix-core work is six
             # bf16 MFMA products per fp32 product (csrc/linear.hip), priced against the dense bf16 peak; informational.
-            xb = batches[args.warmup][0]
+            xb = batches[args.warmup][0].float()
             Mb = int(xb.size(0))
             lay = model.encoder.layers[0]
             wl_, wr_, bl_ = lay.lin_l.weight.detach(), lay.lin_r.weight.detach(), lay.lin_l.bias.detach()
@@ -434,7 +439,7 @@ def main():
             out["configs_extra"] = k1_at_full_graph_sizes(dev)
         if world == 1 and not args.no_cpu_baseline:
             x, ei, xe, bs = batches[args.warmup]
-            out["cpu_baseline"] = cpu_baseline(params, (x.cpu(), ei.edge_index.cpu(), g.edge_text_feat.cpu(), xe.cpu()), bs,
+            out["cpu_baseline"] = cpu_baseline(params, (x.float().cpu(), ei.edge_index.cpu(), g.edge_text_feat.cpu(), xe.cpu()), bs,
                                                args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if world > 1:

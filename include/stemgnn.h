@@ -31,6 +31,10 @@ extern "C" {
 
 #define STEMGNN_ABI_VERSION 1
 
+/* element kinds of operands that may be stored as bf16 (the *_k entry points); values widen exactly at the load and
+ * are rounded to nearest-even at the store, arithmetic is fp32 */
+enum { STEMGNN_F32 = 0, STEMGNN_BF16 = 1 };
+
 enum {
   STEMGNN_OK = 0,
   STEMGNN_ERR_INVALID_ARG = -1, /* null pointer, negative size, unsupported D / K / Dc */
@@ -514,6 +518,33 @@ int stemgnn_pgemm_dw(const uint16_t* dy, int64_t dy_stride, const uint16_t* x, i
                      int64_t out_dim, int64_t in_dim, float* dw, float* db, void* workspace, size_t workspace_bytes,
                      void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * bf16 feature storage (BASELINE config 5): the *_k forms of the entry points above take the node-feature /
+ * layer-output operand as either fp32 or bf16 (`kind`: STEMGNN_F32 / STEMGNN_BF16; `void*` = float* or uint16_t*).
+ * ------------------------------------------------------------------------------------ */
+int stemgnn_sage_agg_fwd_k(const void* x, int32_t x_kind, int64_t num_nodes, int64_t dim, const int32_t* rowptr,
+                           const int32_t* src, const int32_t* eid, const float* edge_attr, const float* etab,
+                           const int32_t* etype_slot, int64_t num_types, float* agg, void* stream);
+int stemgnn_sage_agg_bwd_acc_k(const float* g_agg, const void* x, int32_t x_kind, int64_t num_nodes, int64_t dim,
+                               const int32_t* rowptr_t, const int32_t* dst_t, const int32_t* eid_t, const float* inv_deg,
+                               const float* edge_attr, const float* etab, const int32_t* etype_slot_t, int64_t num_types,
+                               float* g_x, void* stream);
+int stemgnn_linear_fwd_rows_k(const float* x1, const float* w1, int64_t k1, const void* x2, int32_t x2_kind,
+                              const float* w2, int64_t k2, const float* bias, int64_t num_rows, int64_t out_dim, float* y,
+                              float* stats_partial, int64_t* stats_blocks_host, int64_t x1_rows, int64_t store_rows,
+                              void* stream);
+int stemgnn_linear_bwd_weight_k(const float* dy, const void* x, int32_t x_kind, int64_t num_rows, int64_t out_dim,
+                                int64_t in_dim, float* dw, float* db, void* workspace, size_t workspace_bytes,
+                                void* stream);
+int stemgnn_bn_act_drop_fwd_k(const float* y, int64_t num_rows, int64_t dim, const float* mean, const float* rstd,
+                              const float* gamma, const float* beta, int act, float negative_slope, float p,
+                              uint64_t seed, uint64_t offset, void* out, int32_t out_kind, void* stream);
+int stemgnn_mask_columns_k(const void* x, int32_t kind, int64_t num_rows, int64_t dim, float p, uint64_t seed,
+                           uint64_t offset, void* out, void* stream);
+/* bad_count may be NULL (no range check) */
+int stemgnn_gather_rows_k(const void* table, int32_t kind, int64_t num_table_rows, int64_t dim, const int64_t* index,
+                          int64_t n, void* out, int32_t* bad_count, void* stream);
+
 /* ====================================================================================
  * Phase entry points: one call enqueues a whole module forward (or its backward) of the pretraining path, so the
  * host pays one crossing per module instead of one per kernel.  Same arithmetic as the single-op entry points
@@ -565,6 +596,10 @@ typedef struct stemgnn_encoder_cfg {
   int64_t out_rows;                  /* forward only: z holds rows [0, out_rows) of the output (the last layer's
                                         product and normalisation are not written past them; its BatchNorm statistics
                                         still run over every row).  <= 0 or >= N: all rows */
+  int32_t feature_kind;              /* STEMGNN_F32 (0) or STEMGNN_BF16 (1): how x and the outputs of the layers before
+                                        the last one are STORED (BASELINE config 5: bf16 feature storage).  All
+                                        arithmetic is fp32 either way; z, the aggregates, the pre-normalisation
+                                        products and every gradient stay fp32; the input takes no gradient. */
 } stemgnn_encoder_cfg;
 
 /* Encoder.forward (model/encoder.py:279-323) for the 'sage' backbone without MoE layers: per layer K1 over the
@@ -575,14 +610,14 @@ typedef struct stemgnn_encoder_cfg {
  * z [N (or cfg->out_rows), out_dim of the last layer]. */
 size_t stemgnn_encoder_save_bytes(int64_t num_nodes, int64_t active_rows, const stemgnn_sage_layer* layers,
                                   const stemgnn_encoder_cfg* cfg);
-int stemgnn_encoder_fwd(const stemgnn_graph_view* graph, const float* x, const float* edge_attr, const float* etab,
+int stemgnn_encoder_fwd(const stemgnn_graph_view* graph, const void* x, const float* edge_attr, const float* etab,
                         int64_t num_types, const stemgnn_sage_layer* layers, const stemgnn_encoder_cfg* cfg, float* z,
                         void* save, size_t save_bytes, void* stream);
 /* Its backward: g_z [N, out] -> parameter gradients (layer structs) and, when g_x != NULL, the input gradient.
  * g_z is only read.  `scratch`: stemgnn_encoder_bwd_scratch_bytes. */
 size_t stemgnn_encoder_bwd_scratch_bytes(int64_t num_nodes, int64_t active_rows, const stemgnn_sage_layer* layers,
                                          const stemgnn_encoder_cfg* cfg);
-int stemgnn_encoder_bwd(const stemgnn_graph_view* graph, const float* x, const float* edge_attr, const float* etab,
+int stemgnn_encoder_bwd(const stemgnn_graph_view* graph, const void* x, const float* edge_attr, const float* etab,
                         int64_t num_types, const stemgnn_sage_layer* layers, const stemgnn_encoder_cfg* cfg,
                         const float* g_z, float* g_x, const void* save, size_t save_bytes, void* scratch,
                         size_t scratch_bytes, void* stream);

@@ -181,6 +181,11 @@ class OracleEncoder(nn.Module):
                 z = self._act(z)
                 if self.training and self.p > 0 and dropout_masks is not None:
                     z = z * dropout_masks[i].to(z.dtype) / (1.0 - self.p)
+                if getattr(self, "bf16_storage", False):
+                    # emulation of the product's bf16 feature storage (no reference counterpart: the reference has no
+                    # autocast call): a layer output that the next layer reads is rounded to bf16 (nearest-even) where
+                    # the product stores it; arithmetic stays fp32 and the rounding is transparent to the gradient
+                    z = z + (z.bfloat16().to(z.dtype) - z).detach()
         if reg_total is not None and self.training:
             self._last_env_reg = reg_total / env_idx
         else:

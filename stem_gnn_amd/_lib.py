@@ -65,7 +65,7 @@ class HeadsParams(ctypes.Structure):
 class EncoderCfg(ctypes.Structure):
     """stemgnn_encoder_cfg (include/stemgnn.h)."""
     _fields_ = [("num_layers", I32), ("use_bn", I32), ("training", I32), ("act", I32), ("negative_slope", c_float),
-                ("dropout_p", c_float), ("out_rows", I64)]
+                ("dropout_p", c_float), ("out_rows", I64), ("feature_kind", I32)]
 
 _SIGNATURES = {
     "stemgnn_abi_version": (c_int, []),
@@ -116,6 +116,13 @@ _SIGNATURES = {
                                   P, P, P, P, P, P, P, c_size_t, P]),
     "stemgnn_heads_bwd_scratch_bytes": (c_size_t, [P, I64, I64, I64]),
     "stemgnn_heads_bwd": (c_int, [P, I64, P, P, P, I64, I64, P, P, P, P, P, c_size_t, I64, P, c_size_t, P]),
+    "stemgnn_sage_agg_fwd_k": (c_int, [P, I32, I64, I64, P, P, P, P, P, P, I64, P, P]),
+    "stemgnn_sage_agg_bwd_acc_k": (c_int, [P, P, I32, I64, I64, P, P, P, P, P, P, P, I64, P, P]),
+    "stemgnn_linear_fwd_rows_k": (c_int, [P, P, I64, P, I32, P, I64, P, I64, I64, P, P, P, I64, I64, P]),
+    "stemgnn_linear_bwd_weight_k": (c_int, [P, P, I32, I64, I64, I64, P, P, P, c_size_t, P]),
+    "stemgnn_bn_act_drop_fwd_k": (c_int, [P, I64, I64, P, P, P, P, c_int, c_float, c_float, c_uint64, c_uint64, P, I32, P]),
+    "stemgnn_mask_columns_k": (c_int, [P, I32, I64, I64, c_float, c_uint64, c_uint64, P, P]),
+    "stemgnn_gather_rows_k": (c_int, [P, I32, I64, I64, P, I64, P, P, P]),
     "stemgnn_encoder_save_bytes": (c_size_t, [I64, I64, P, P]),
     "stemgnn_encoder_fwd": (c_int, [P, P, P, P, I64, P, P, P, P, c_size_t, P]),
     "stemgnn_encoder_bwd_scratch_bytes": (c_size_t, [I64, I64, P, P]),

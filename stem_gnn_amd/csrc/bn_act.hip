@@ -201,7 +201,7 @@ __global__ void __launch_bounds__(kBlock)
 k_apply(const float* __restrict__ y, const float* __restrict__ g_out, int64_t N, int D,
         const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
         const float* __restrict__ beta, const float* __restrict__ sum_gb, const float* __restrict__ sum_gbx,
-        Epilogue ep, float* __restrict__ out) {
+        Epilogue ep, float* __restrict__ out, int out_kind) {
   const int nvec = D / 4;
   const int64_t total = N * nvec;
   const float inv_n = 1.0f / static_cast<float>(N);
@@ -242,7 +242,7 @@ k_apply(const float* __restrict__ y, const float* __restrict__ g_out, int64_t N,
         o[k] = mean ? gam[k] * rr[k] * (gb - sb[k] * inv_n - xh * sx[k] * inv_n) : gb * gam[k];
       }
     }
-    st4(out + 4 * i, make_float4(o[0], o[1], o[2], o[3]));
+    st4_kind(out, 4 * i, out_kind, make_float4(o[0], o[1], o[2], o[3]));  // bf16 storage rounds here (RNE)
   }
 }
 
@@ -330,7 +330,24 @@ int stemgnn_bn_act_drop_fwd(const float* y, int64_t N, int64_t D, const float* m
   if (!y || !out) return STEMGNN_ERR_INVALID_ARG;
   Epilogue ep = make_epilogue(act, negative_slope, p, seed, offset);
   k_apply<false><<<elementwise_grid(N * (D / 4)), kBlock, 0, st>>>(y, nullptr, N, static_cast<int>(D), mean, rstd,
-                                                                  gamma, beta, nullptr, nullptr, ep, out);
+                                                                  gamma, beta, nullptr, nullptr, ep, out, kF32);
+  STEMGNN_LAUNCH_CHECK();
+  return STEMGNN_OK;
+}
+
+int stemgnn_bn_act_drop_fwd_k(const float* y, int64_t N, int64_t D, const float* mean, const float* rstd,
+                              const float* gamma, const float* beta, int act, float negative_slope, float p,
+                              uint64_t seed, uint64_t offset, void* out, int32_t out_kind, void* stream_) {
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  if (!dims_ok(N, D) || (act != 0 && act != 1) || p < 0.f || p > 1.f) return STEMGNN_ERR_INVALID_ARG;
+  if ((mean == nullptr) != (rstd == nullptr) || (gamma == nullptr) != (beta == nullptr)) return STEMGNN_ERR_INVALID_ARG;
+  if (out_kind != kF32 && out_kind != kBF16) return STEMGNN_ERR_INVALID_ARG;
+  if (N == 0) return STEMGNN_OK;
+  if (!y || !out) return STEMGNN_ERR_INVALID_ARG;
+  Epilogue ep = make_epilogue(act, negative_slope, p, seed, offset);
+  k_apply<false><<<elementwise_grid(N * (D / 4)), kBlock, 0, st>>>(y, nullptr, N, static_cast<int>(D), mean, rstd,
+                                                                  gamma, beta, nullptr, nullptr, ep,
+                                                                  static_cast<float*>(out), out_kind);
   STEMGNN_LAUNCH_CHECK();
   return STEMGNN_OK;
 }
@@ -365,7 +382,7 @@ int stemgnn_bn_act_drop_bwd(const float* g_out, const float* y, int64_t N, int64
     sum_gbx = gg;
   }
   k_apply<true><<<elementwise_grid(N * (D / 4)), kBlock, 0, st>>>(y, g_out, N, static_cast<int>(D), mean, rstd, gamma,
-                                                                 beta, sum_gb, sum_gbx, ep, g_y);
+                                                                 beta, sum_gb, sum_gbx, ep, g_y, kF32);
   STEMGNN_LAUNCH_CHECK();
   return STEMGNN_OK;
 }

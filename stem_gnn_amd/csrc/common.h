@@ -154,5 +154,51 @@ __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
+// ---- bf16 feature storage (BASELINE config 5): node features and the layers' outputs may live in HBM as bf16
+// (element kind 1) instead of fp32 (kind 0).  A bf16 value is the upper half of an fp32 pattern, so a load widens
+// exactly; a store rounds to nearest-even (v_cvt_pk_bf16_f32, what torch's .bfloat16() does).  All arithmetic stays
+// fp32: the kernels widen at the load and round at the store, nothing else changes.
+enum { kF32 = 0, kBF16 = 1 };
+__device__ __forceinline__ float4 ld4_bf16(const uint16_t* p) {
+  const uint2 v = *reinterpret_cast<const uint2*>(p);
+  return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                     __uint_as_float(v.y & 0xffff0000u));
+}
+// Raw (un-widened) form of four consecutive elements: gather loops keep the loaded bits in registers and widen at the
+// point of use, so that no conversion sits between a load and the next one (the compiler otherwise waits per load).
+template <int KIND> struct Raw4;
+template <> struct Raw4<kF32> {
+  float4 v;
+  __device__ __forceinline__ void load(const void* base, int64_t i) { v = ld4(static_cast<const float*>(base) + i); }
+  __device__ __forceinline__ void clear() { v = make_float4(0.f, 0.f, 0.f, 0.f); }
+  __device__ __forceinline__ float4 widen() const { return v; }
+};
+template <> struct Raw4<kBF16> {
+  uint2 v;
+  __device__ __forceinline__ void load(const void* base, int64_t i) {
+    v = *reinterpret_cast<const uint2*>(static_cast<const uint16_t*>(base) + i);
+  }
+  __device__ __forceinline__ void clear() { v = make_uint2(0u, 0u); }
+  __device__ __forceinline__ float4 widen() const {
+    return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                       __uint_as_float(v.y & 0xffff0000u));
+  }
+};
+__device__ __forceinline__ uint32_t bf16_bits(float f) {
+  const __bf16 b = static_cast<__bf16>(f);
+  return static_cast<uint32_t>(__builtin_bit_cast(uint16_t, b));
+}
+__device__ __forceinline__ void st4_bf16(uint16_t* p, float4 v) {
+  *reinterpret_cast<uint2*>(p) = make_uint2(bf16_bits(v.x) | (bf16_bits(v.y) << 16), bf16_bits(v.z) | (bf16_bits(v.w) << 16));
+}
+// four consecutive elements starting at element index i of a row-major matrix of either kind (i a multiple of 4)
+__device__ __forceinline__ float4 ld4_kind(const void* base, int64_t i, int kind) {
+  return kind == kBF16 ? ld4_bf16(static_cast<const uint16_t*>(base) + i) : ld4(static_cast<const float*>(base) + i);
+}
+__device__ __forceinline__ void st4_kind(void* base, int64_t i, int kind, float4 v) {
+  if (kind == kBF16) st4_bf16(static_cast<uint16_t*>(base) + i, v);
+  else st4(static_cast<float*>(base) + i, v);
+}
+
 
 }  // namespace stemgnn

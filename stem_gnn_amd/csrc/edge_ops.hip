@@ -107,7 +107,7 @@ k_edge_concat_bwd(const float* __restrict__ g_out, int64_t N, int D, const int64
 template <int G>
 __global__ void __launch_bounds__(kBlock)
 k_gather_rows(const float* __restrict__ table, int64_t R, int D, const int64_t* __restrict__ index, int64_t n,
-              float* __restrict__ out, int32_t* __restrict__ bad_count) {
+              float* __restrict__ out, int32_t* __restrict__ bad_count, int kind) {
   const int lane = threadIdx.x % G;
   const int64_t i = static_cast<int64_t>(blockIdx.x) * (kBlock / G) + threadIdx.x / G;
   if (i >= n) return;
@@ -115,8 +115,8 @@ k_gather_rows(const float* __restrict__ table, int64_t R, int D, const int64_t* 
   const bool ok = r >= 0 && r < R;
   if (!ok && bad_count != nullptr && lane == 0) atomicAdd(bad_count, 1);  // the reference's indexing raises here
   const int nvec = D / 4;
-  for (int c = lane; c < nvec; c += G)
-    st4(out + i * D + 4 * c, ok ? ld4(table + r * D + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f));
+  for (int c = lane; c < nvec; c += G)  // table and output share their element kind: bf16 rows move as they are
+    st4_kind(out, i * D + 4 * c, kind, ok ? ld4_kind(table, r * D + 4 * c, kind) : make_float4(0.f, 0.f, 0.f, 0.f));
 }
 
 // topo_recon_loss terms (reference model/pt_model.py:62-65, EPS = 1e-15):
@@ -254,7 +254,19 @@ int stemgnn_gather_rows(const float* table, int64_t R, int64_t D, const int64_t*
   if (n == 0) return STEMGNN_OK;
   if (!table || !index || !out) return STEMGNN_ERR_INVALID_ARG;
   STEMGNN_EDGE_DISPATCH(k_gather_rows, n, table, R, static_cast<int>(D), index, n, out,
-                        static_cast<int32_t*>(nullptr));
+                        static_cast<int32_t*>(nullptr), kF32);
+  return STEMGNN_OK;
+}
+
+int stemgnn_gather_rows_k(const void* table, int32_t kind, int64_t R, int64_t D, const int64_t* index, int64_t n, void* out,
+                          int32_t* bad_count, void* stream_) {
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  if (R < 0 || n < 0 || !dim_ok(D) || (kind != kF32 && kind != kBF16)) return STEMGNN_ERR_INVALID_ARG;
+  if (bad_count) STEMGNN_HIP_TRY(hipMemsetAsync(bad_count, 0, sizeof(int32_t), st));
+  if (n == 0) return STEMGNN_OK;
+  if (!table || !index || !out) return STEMGNN_ERR_INVALID_ARG;
+  STEMGNN_EDGE_DISPATCH(k_gather_rows, n, static_cast<const float*>(table), R, static_cast<int>(D), index, n,
+                        static_cast<float*>(out), bad_count, kind);
   return STEMGNN_OK;
 }
 
@@ -265,7 +277,7 @@ int stemgnn_gather_rows_checked(const float* table, int64_t R, int64_t D, const 
   STEMGNN_HIP_TRY(hipMemsetAsync(bad_count, 0, sizeof(int32_t), st));
   if (n == 0) return STEMGNN_OK;
   if (!table || !index || !out) return STEMGNN_ERR_INVALID_ARG;
-  STEMGNN_EDGE_DISPATCH(k_gather_rows, n, table, R, static_cast<int>(D), index, n, out, bad_count);
+  STEMGNN_EDGE_DISPATCH(k_gather_rows, n, table, R, static_cast<int>(D), index, n, out, bad_count, kF32);
   return STEMGNN_OK;
 }
 

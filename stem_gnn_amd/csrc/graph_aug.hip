@@ -201,7 +201,7 @@ k_sample_edges(const int64_t* __restrict__ edge_index, const int64_t* __restrict
 // philox(seed, offset)[c] < p  (the keep mask of stemgnn_dropout_keep_mask(D, p, seed, offset)).
 __global__ void __launch_bounds__(kThreads)
 k_mask_columns(const float* __restrict__ x, int64_t N, int D, float p, uint64_t seed, uint64_t offset,
-               float* __restrict__ out) {
+               float* __restrict__ out, int kind) {
   const int nvec = D / 4;
   const int64_t total = N * nvec;
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < total;
@@ -209,12 +209,12 @@ k_mask_columns(const float* __restrict__ x, int64_t N, int D, float p, uint64_t 
     const int c = static_cast<int>(i % nvec);
     uint32_t r[4];
     Philox::gen(seed, offset, static_cast<uint64_t>(c), r);
-    float4 v = *reinterpret_cast<const float4*>(x + 4 * i);
+    float4 v = ld4_kind(x, 4 * i, kind);
     if (Philox::to_unit(r[0]) < p) v.x = 0.f;
     if (Philox::to_unit(r[1]) < p) v.y = 0.f;
     if (Philox::to_unit(r[2]) < p) v.z = 0.f;
     if (Philox::to_unit(r[3]) < p) v.w = 0.f;
-    *reinterpret_cast<float4*>(out + 4 * i) = v;
+    st4_kind(out, 4 * i, kind, v);  // a bf16 value masked or kept is still a bf16 value: no rounding happens
   }
 }
 
@@ -301,7 +301,20 @@ int stemgnn_mask_columns(const float* x, int64_t N, int64_t D, float p, uint64_t
   int64_t g = (N * (D / 4) + kThreads - 1) / kThreads;
   if (g > 4096) g = 4096;
   k_mask_columns<<<static_cast<unsigned>(g), kThreads, 0, static_cast<hipStream_t>(stream_)>>>(
-      x, N, static_cast<int>(D), p, seed, offset, out);
+      x, N, static_cast<int>(D), p, seed, offset, out, kF32);
+  STEMGNN_LAUNCH_CHECK();
+  return STEMGNN_OK;
+}
+
+int stemgnn_mask_columns_k(const void* x, int32_t kind, int64_t N, int64_t D, float p, uint64_t seed, uint64_t offset,
+                           void* out, void* stream_) {
+  if (N < 0 || D <= 0 || D % 4 != 0 || p < 0.f || p > 1.f || (kind != kF32 && kind != kBF16)) return STEMGNN_ERR_INVALID_ARG;
+  if (N == 0) return STEMGNN_OK;
+  if (!x || !out) return STEMGNN_ERR_INVALID_ARG;
+  int64_t g = (N * (D / 4) + kThreads - 1) / kThreads;
+  if (g > 4096) g = 4096;
+  k_mask_columns<<<static_cast<unsigned>(g), kThreads, 0, static_cast<hipStream_t>(stream_)>>>(
+      static_cast<const float*>(x), N, static_cast<int>(D), p, seed, offset, static_cast<float*>(out), kind);
   STEMGNN_LAUNCH_CHECK();
   return STEMGNN_OK;
 }

@@ -203,7 +203,7 @@ __device__ __forceinline__ int stage_row(int idx) {
   const int r = idx >> 3;
   return (r & ~7) | ((r & 1) << 2) | ((r >> 1) & 3);
 }
-template <int BM, bool STATS, bool BT = false>
+template <int BM, bool STATS, bool BT = false, int X2K = kF32>
 __global__ void __launch_bounds__(kBlock, 2)
 k_linear_fwd_x3(const float* __restrict__ x1, const float* __restrict__ w1, int K1, const float* __restrict__ x2,
              const float* __restrict__ w2, int K2, const float* __restrict__ bias, int64_t M, int N,
@@ -230,6 +230,7 @@ k_linear_fwd_x3(const float* __restrict__ x1, const float* __restrict__ w1, int 
   const int steps = c1 + c2;
 
   float4 ra[FA], rb[4];
+  bool held_bf16 = false;  // ra holds raw bf16 bits of the second operand (X2K == kBF16 only)
   auto fetch = [&](int step) {
     const bool second = step >= c1;
     const float* xs = second ? x2 : x1;
@@ -251,9 +252,18 @@ k_linear_fwd_x3(const float* __restrict__ x1, const float* __restrict__ w1, int 
       if (t < FA) {
         const int64_t m = m0 + r;
         // rows >= x1_rows of the first operand are zero by promise and are never read (the buffer may end there)
-        ra[t] = (m < (second ? M : x1_rows) && k < K) ? ld4(xs + m * K + k) : zero4();
+        // the second operand (the layer input h) may be stored as bf16: widened here, the cut that follows is exact
+        // the bits stay as loaded (two dwords of ra[t]) until stash(): a widening here would sit between the loads
+        if (X2K == kBF16 && second) {
+          const uint2 raw = (m < M && k < K) ? *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(xs) + m * K + k)
+                                             : make_uint2(0u, 0u);
+          ra[t] = make_float4(__uint_as_float(raw.x), __uint_as_float(raw.y), 0.f, 0.f);
+        } else {
+          ra[t] = (m < (second ? M : x1_rows) && k < K) ? ld4(xs + m * K + k) : zero4();
+        }
       }
     }
+    held_bf16 = X2K == kBF16 && second;
   };
   auto stash = [&]() {
     if (BT) stash_transposed(rb, sB, PB, tid);
@@ -269,7 +279,12 @@ k_linear_fwd_x3(const float* __restrict__ x1, const float* __restrict__ w1, int 
         *reinterpret_cast<uint2*>(sB + 2 * PB + off) = l;
       }
       if (t < FA) {
-        split3(ra[t], h, m, l);
+        if (X2K == kBF16 && held_bf16) {  // four bf16 values ARE the h plane of their fp32 widening; m = l = 0
+          h = make_uint2(__float_as_uint(ra[t].x), __float_as_uint(ra[t].y));
+          m = l = make_uint2(0u, 0u);
+        } else {
+          split3(ra[t], h, m, l);
+        }
         *reinterpret_cast<uint2*>(sA + off) = h;
         *reinterpret_cast<uint2*>(sA + PA + off) = m;
         *reinterpret_cast<uint2*>(sA + 2 * PA + off) = l;
@@ -525,6 +540,7 @@ k_linear_bwd_weight(const float* __restrict__ dy, const float* __restrict__ x, i
 // and a v_mfma_f32_32x32x16_bf16 lane wants 8 consecutive m: each thread stages a 4 (m) x 4 (n or k) micro-tile,
 // splits it and stores it transposed, so the LDS planes are [n][32 m] / [k][32 m] and the fragment reads are the
 // forward kernel's.  db comes from the staged registers (shuffle over the 8 lanes that share a column group).
+template <int XK>  // element kind of x (common.h: kF32 / kBF16), compile-time: a run-time kind cost the fp32 launch 18 %
 __global__ void __launch_bounds__(kBlock, 2)
 k_linear_bwd_weight_x3(const float* __restrict__ dy, const float* __restrict__ x, int64_t M, int N, int K,
                        int64_t rows_per_split, float* __restrict__ partial_dw /*[S][N][K]*/,
@@ -543,14 +559,16 @@ k_linear_bwd_weight_x3(const float* __restrict__ dy, const float* __restrict__ x
   const int mq = tid & 7, cq = tid >> 3;  // rows 4 mq .. 4 mq + 3 of the chunk, columns 4 cq .. 4 cq + 3 of the tile
   const bool do_db = blockIdx.z == 0 && partial_db != nullptr;
 
-  float4 ra[4], rb[4];
+  float4 ra[4];
+  Raw4<XK> rb[4];  // widened at the stash: no conversion between the prefetch loads
   auto fetch = [&](int step) {
     const int64_t mm = mbeg + static_cast<int64_t>(step) * kKC + 4 * mq;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int64_t m = mm + i;
       ra[i] = (m < mend && n0 + 4 * cq < N) ? ld4(dy + m * N + n0 + 4 * cq) : zero4();
-      rb[i] = (m < mend && k0 + 4 * cq < K) ? ld4(x + m * K + k0 + 4 * cq) : zero4();
+      if (m < mend && k0 + 4 * cq < K) rb[i].load(x, m * K + k0 + 4 * cq);
+      else rb[i].clear();
     }
   };
   auto stash_t = [&](const float4 (&q)[4], unsigned char* planes) { stash_transposed(q, planes, PL, tid); };
@@ -567,7 +585,10 @@ k_linear_bwd_weight_x3(const float* __restrict__ dy, const float* __restrict__ x
   if (steps > 0) fetch(0);
   for (int step = 0; step < steps; ++step) {
     stash_t(ra, sA);
-    stash_t(rb, sB);
+    {
+      const float4 wb[4] = {rb[0].widen(), rb[1].widen(), rb[2].widen(), rb[3].widen()};
+      stash_t(wb, sB);
+    }
     if (do_db) {
       float4 c = make_float4(ra[0].x + ra[1].x + ra[2].x + ra[3].x, ra[0].y + ra[1].y + ra[2].y + ra[3].y,
                              ra[0].z + ra[1].z + ra[2].z + ra[3].z, ra[0].w + ra[1].w + ra[2].w + ra[3].w);
@@ -958,7 +979,19 @@ int stemgnn_linear_fwd(const float* x1, const float* w1, int64_t K1, const float
 int stemgnn_linear_fwd_rows(const float* x1, const float* w1, int64_t K1, const float* x2, const float* w2, int64_t K2,
                             const float* bias, int64_t M, int64_t N, float* y, float* stats_partial,
                             int64_t* stats_blocks_host, int64_t x1_rows, int64_t store_rows, void* stream_) {
+  return stemgnn_linear_fwd_rows_k(x1, w1, K1, x2, kF32, w2, K2, bias, M, N, y, stats_partial, stats_blocks_host, x1_rows,
+                                   store_rows, stream_);
+}
+
+int stemgnn_linear_fwd_rows_k(const float* x1, const float* w1, int64_t K1, const void* x2_, int32_t x2_kind,
+                              const float* w2, int64_t K2, const float* bias, int64_t M, int64_t N, float* y,
+                              float* stats_partial, int64_t* stats_blocks_host, int64_t x1_rows, int64_t store_rows,
+                              void* stream_) {
   hipStream_t st = static_cast<hipStream_t>(stream_);
+  if (x2_kind != kF32 && x2_kind != kBF16) return STEMGNN_ERR_INVALID_ARG;
+  const float* x2 = static_cast<const float*>(x2_);
+  const bool bf = x2_kind == kBF16 && K2 > 0;
+  if (bf && !gemm_x3()) return STEMGNN_ERR_INVALID_ARG;  // the fp32-MFMA cross-check twins read fp32 only
   const int64_t sr = (store_rows < 0 || store_rows > M) ? M : store_rows;
   if (!lin_dims_ok(M, N, K1) || K2 < 0 || K2 % 4 != 0) return STEMGNN_ERR_INVALID_ARG;
   const int64_t x1r = (x1_rows < 0 || x1_rows > M) ? M : x1_rows;
@@ -974,10 +1007,12 @@ int stemgnn_linear_fwd_rows(const float* x1, const float* w1, int64_t K1, const 
   if (plan.main_tiles > 0) {
     dim3 grid(static_cast<unsigned>(plan.main_tiles), static_cast<unsigned>(gy));
     if (stats_partial) {
-      if (x3) k_linear_fwd_x3<128, true><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, stats_partial, 0, 0, x1r, sr);
+      if (x3 && bf) k_linear_fwd_x3<128, true, false, kBF16><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, stats_partial, 0, 0, x1r, sr);
+      else if (x3) k_linear_fwd_x3<128, true><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, stats_partial, 0, 0, x1r, sr);
       else k_linear_fwd<128, true><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, stats_partial, 0, 0, x1r, sr);
     } else {
-      if (x3) k_linear_fwd_x3<128, false><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, nullptr, 0, 0, x1r, sr);
+      if (x3 && bf) k_linear_fwd_x3<128, false, false, kBF16><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, nullptr, 0, 0, x1r, sr);
+      else if (x3) k_linear_fwd_x3<128, false><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, nullptr, 0, 0, x1r, sr);
       else k_linear_fwd<128, false><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, nullptr, 0, 0, x1r, sr);
     }
     STEMGNN_LAUNCH_CHECK();
@@ -988,13 +1023,17 @@ int stemgnn_linear_fwd_rows(const float* x1, const float* w1, int64_t K1, const 
     dim3 grid(static_cast<unsigned>(plan.tail_tiles), static_cast<unsigned>(gy));
     const int64_t row_base = plan.main_tiles * kBM;
     if (stats_partial) {
-      if (x3) k_linear_fwd_x3<32, true><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, stats_partial,
-                                                                 row_base, plan.main_tiles, x1r, sr);
+      if (x3 && bf) k_linear_fwd_x3<32, true, false, kBF16><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, stats_partial,
+                                                                                     row_base, plan.main_tiles, x1r, sr);
+      else if (x3) k_linear_fwd_x3<32, true><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, stats_partial,
+                                                                      row_base, plan.main_tiles, x1r, sr);
       else k_linear_fwd<32, true><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, stats_partial,
                                                            row_base, plan.main_tiles, x1r, sr);
     } else {
-      if (x3) k_linear_fwd_x3<32, false><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, nullptr,
-                                                                  row_base, plan.main_tiles, x1r, sr);
+      if (x3 && bf) k_linear_fwd_x3<32, false, false, kBF16><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, nullptr,
+                                                                                      row_base, plan.main_tiles, x1r, sr);
+      else if (x3) k_linear_fwd_x3<32, false><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, nullptr,
+                                                                       row_base, plan.main_tiles, x1r, sr);
       else k_linear_fwd<32, false><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, nullptr,
                                                             row_base, plan.main_tiles, x1r, sr);
     }
@@ -1039,7 +1078,15 @@ size_t stemgnn_linear_bwd_weight_workspace_bytes(int64_t M, int64_t N, int64_t K
 
 int stemgnn_linear_bwd_weight(const float* dy, const float* x, int64_t M, int64_t N, int64_t K, float* dw, float* db,
                               void* workspace, size_t workspace_bytes, void* stream_) {
+  return stemgnn_linear_bwd_weight_k(dy, x, kF32, M, N, K, dw, db, workspace, workspace_bytes, stream_);
+}
+
+int stemgnn_linear_bwd_weight_k(const float* dy, const void* x_, int32_t x_kind, int64_t M, int64_t N, int64_t K, float* dw,
+                                float* db, void* workspace, size_t workspace_bytes, void* stream_) {
   hipStream_t st = static_cast<hipStream_t>(stream_);
+  const float* x = static_cast<const float*>(x_);
+  if (x_kind != kF32 && x_kind != kBF16) return STEMGNN_ERR_INVALID_ARG;
+  if (x_kind == kBF16 && !gemm_x3()) return STEMGNN_ERR_INVALID_ARG;  // the fp32-MFMA cross-check twins read fp32 only
   if (!lin_dims_ok(M, N, K) || N % 4 != 0 || !dw) return STEMGNN_ERR_INVALID_ARG;
   if (!fits_i32(M)) return STEMGNN_ERR_TOO_LARGE;
   if (M == 0) {
@@ -1055,10 +1102,14 @@ int stemgnn_linear_bwd_weight(const float* dy, const float* x, int64_t M, int64_
   float* pw = reinterpret_cast<float*>(align_up(reinterpret_cast<uintptr_t>(workspace), 256));
   float* pb = pw + static_cast<size_t>(S) * N * K;
   dim3 grid(static_cast<unsigned>(S), static_cast<unsigned>((N + kBN - 1) / kBN), static_cast<unsigned>((K + kBN - 1) / kBN));
-  if (gemm_x3())
-    k_linear_bwd_weight_x3<<<grid, kBlock, 0, st>>>(dy, x, M, static_cast<int>(N), static_cast<int>(K), rows, pw,
-                                                    db ? pb : nullptr);
-  else
+  if (gemm_x3()) {
+    if (x_kind == kBF16)
+      k_linear_bwd_weight_x3<kBF16><<<grid, kBlock, 0, st>>>(dy, x, M, static_cast<int>(N), static_cast<int>(K), rows, pw,
+                                                             db ? pb : nullptr);
+    else
+      k_linear_bwd_weight_x3<kF32><<<grid, kBlock, 0, st>>>(dy, x, M, static_cast<int>(N), static_cast<int>(K), rows, pw,
+                                                            db ? pb : nullptr);
+  } else
     k_linear_bwd_weight<<<grid, kBlock, 0, st>>>(dy, x, M, static_cast<int>(N), static_cast<int>(K), rows, pw,
                                                  db ? pb : nullptr);
   STEMGNN_LAUNCH_CHECK();

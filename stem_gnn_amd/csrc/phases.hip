@@ -49,6 +49,7 @@ inline bool encoder_args_ok(const stemgnn_sage_layer* layers, const stemgnn_enco
     if (cfg->use_bn && (!y.bn_weight || !y.bn_bias)) return false;
     if ((y.bn_running_mean == nullptr) != (y.bn_running_var == nullptr)) return false;
   }
+  if (cfg->feature_kind != kF32 && cfg->feature_kind != kBF16) return false;
   return cfg->dropout_p >= 0.f && cfg->dropout_p < 1.f;
 }
 
@@ -73,7 +74,8 @@ inline EncoderPlan plan_encoder(const void* save, int64_t N, int64_t A, const st
     } else {
       s.y = c.take<float>(static_cast<size_t>(std::max<int64_t>(last ? p.R : N, 1)) * y.out_dim);
     }
-    s.h = last ? z : c.take<float>(static_cast<size_t>(std::max<int64_t>(N, 1)) * y.out_dim);
+    // layer outputs before the last one are stored in the feature kind (bf16: half the bytes); z is always fp32
+    s.h = last ? z : c.take<float>(static_cast<size_t>(std::max<int64_t>(N, 1)) * y.out_dim / (cfg->feature_kind == kBF16 ? 2 : 1) + 4);
     if (cfg->use_bn) {
       s.mean = c.take<float>(y.out_dim);
       s.rstd = c.take<float>(y.out_dim);
@@ -149,7 +151,7 @@ size_t stemgnn_encoder_save_bytes(int64_t N, int64_t A, const stemgnn_sage_layer
   return plan_encoder(nullptr, N, A, layers, cfg, nullptr).bytes;
 }
 
-int stemgnn_encoder_fwd(const stemgnn_graph_view* g, const float* x, const float* edge_attr, const float* etab,
+int stemgnn_encoder_fwd(const stemgnn_graph_view* g, const void* x, const float* edge_attr, const float* etab,
                         int64_t T, const stemgnn_sage_layer* layers, const stemgnn_encoder_cfg* cfg, float* z, void* save,
                         size_t save_bytes, void* stream) {
   if (!g || !encoder_args_ok(layers, cfg)) return STEMGNN_ERR_INVALID_ARG;
@@ -163,19 +165,20 @@ int stemgnn_encoder_fwd(const stemgnn_graph_view* g, const float* x, const float
   hipStream_t st = static_cast<hipStream_t>(stream);
   const EncoderPlan p = plan_encoder(save, N, A, layers, cfg, z);
   const int L = cfg->num_layers;
-  const float* h = x;
+  const int fk = cfg->feature_kind;
+  const void* h = x;
   for (int l = 0; l < L; ++l) {
     const stemgnn_sage_layer& y = layers[l];
     const LayerSave& s = p.layers[l];
     const bool last = l == L - 1;
     // K1 over the rows that can receive edges; the product below skips the aggregate's half past them
     if (A > 0)
-      STEMGNN_TRY(stemgnn_sage_agg_fwd(h, A, y.in_dim, g->rowptr, g->src, g->eid, edge_attr, etab, g->etype_slot, T,
-                                       s.agg, stream));
+      STEMGNN_TRY(stemgnn_sage_agg_fwd_k(h, fk, A, y.in_dim, g->rowptr, g->src, g->eid, edge_attr, etab, g->etype_slot, T,
+                                         s.agg, stream));
     const bool batch_stats = cfg->use_bn && cfg->training;
     const int64_t rows_out = last ? p.R : N;  // the last layer's values are wanted for the leading rows only
-    STEMGNN_TRY(stemgnn_linear_fwd_rows(s.agg, y.w_l, y.in_dim, h, y.w_r, y.in_dim, y.b_l, N, y.out_dim, s.y,
-                                        batch_stats ? p.stats_partial : nullptr, nullptr, A, rows_out, stream));
+    STEMGNN_TRY(stemgnn_linear_fwd_rows_k(s.agg, y.w_l, y.in_dim, h, fk, y.w_r, y.in_dim, y.b_l, N, y.out_dim, s.y,
+                                          batch_stats ? p.stats_partial : nullptr, nullptr, A, rows_out, stream));
     if (last && p.tail_identity) break;
     const float *mean = nullptr, *rstd = nullptr;
     if (batch_stats) {
@@ -194,9 +197,9 @@ int stemgnn_encoder_fwd(const stemgnn_graph_view* g, const float* x, const float
     }
     const int act = last ? 0 : cfg->act;
     const float pdrop = (last || !cfg->training) ? 0.f : cfg->dropout_p;
-    STEMGNN_TRY(stemgnn_bn_act_drop_fwd(s.y, rows_out, y.out_dim, mean, rstd, cfg->use_bn ? y.bn_weight : nullptr,
-                                        cfg->use_bn ? y.bn_bias : nullptr, act, cfg->negative_slope, pdrop, y.drop_seed,
-                                        y.drop_offset, s.h, stream));
+    STEMGNN_TRY(stemgnn_bn_act_drop_fwd_k(s.y, rows_out, y.out_dim, mean, rstd, cfg->use_bn ? y.bn_weight : nullptr,
+                                          cfg->use_bn ? y.bn_bias : nullptr, act, cfg->negative_slope, pdrop,
+                                          y.drop_seed, y.drop_offset, s.h, last ? kF32 : fk, stream));
     h = s.h;
   }
   return STEMGNN_OK;
@@ -217,7 +220,7 @@ size_t stemgnn_encoder_bwd_scratch_bytes(int64_t N, int64_t A, const stemgnn_sag
          1024;
 }
 
-int stemgnn_encoder_bwd(const stemgnn_graph_view* g, const float* x, const float* edge_attr, const float* etab,
+int stemgnn_encoder_bwd(const stemgnn_graph_view* g, const void* x, const float* edge_attr, const float* etab,
                         int64_t T, const stemgnn_sage_layer* layers, const stemgnn_encoder_cfg* cfg, const float* g_z,
                         float* g_x, const void* save, size_t save_bytes, void* scratch, size_t scratch_bytes,
                         void* stream) {
@@ -227,6 +230,7 @@ int stemgnn_encoder_bwd(const stemgnn_graph_view* g, const float* x, const float
   if (N <= 0) return N == 0 ? STEMGNN_OK : STEMGNN_ERR_INVALID_ARG;
   if (!cfg->training && cfg->use_bn) return STEMGNN_ERR_INVALID_ARG;  // running-statistics backward: single-op path
   if (cfg->out_rows > 0 && cfg->out_rows < N) return STEMGNN_ERR_INVALID_ARG;  // a truncated forward has no backward
+  if (cfg->feature_kind == kBF16 && g_x) return STEMGNN_ERR_INVALID_ARG;         // stored features take no gradient
   if (!x || !g_z || !save || !scratch || !g->rowptr_t || !g->inv_deg) return STEMGNN_ERR_INVALID_ARG;
   if (save_bytes < stemgnn_encoder_save_bytes(N, A, layers, cfg) ||
       scratch_bytes < stemgnn_encoder_bwd_scratch_bytes(N, A, layers, cfg))
@@ -254,7 +258,7 @@ int stemgnn_encoder_bwd(const stemgnn_graph_view* g, const float* x, const float
     const stemgnn_sage_layer& y = layers[l];
     const LayerSave& s = p.layers[l];
     const bool last = l == L - 1;
-    const float* h_prev = l == 0 ? x : p.layers[l - 1].h;
+    const void* h_prev = l == 0 ? x : static_cast<const void*>(p.layers[l - 1].h);  // stored in the feature kind
     const float* g_y = g_h;
     if (!(last && p.tail_identity)) {
       const int act = last ? 0 : cfg->act;
@@ -270,8 +274,8 @@ int stemgnn_encoder_bwd(const stemgnn_graph_view* g, const float* x, const float
     // an aggregate
     if (y.g_w_r || y.g_b_l) {
       if (!y.g_w_r) return STEMGNN_ERR_INVALID_ARG;
-      STEMGNN_TRY(stemgnn_linear_bwd_weight(g_y, h_prev, N, y.out_dim, y.in_dim, y.g_w_r, y.b_l ? y.g_b_l : nullptr,
-                                            dw_ws, dwb, stream));
+      STEMGNN_TRY(stemgnn_linear_bwd_weight_k(g_y, h_prev, cfg->feature_kind, N, y.out_dim, y.in_dim, y.g_w_r,
+                                              y.b_l ? y.g_b_l : nullptr, dw_ws, dwb, stream));
     }
     if (y.g_w_l) {
       if (A > 0) {
@@ -286,8 +290,8 @@ int stemgnn_encoder_bwd(const stemgnn_graph_view* g, const float* x, const float
     if (A > 0) {
       STEMGNN_TRY(stemgnn_linear_bwd_data(g_y, y.w_l, A, y.out_dim, y.in_dim, g_agg, stream));
       // the aggregation's backward adds onto lin_r's share (no separate accumulation pass)
-      STEMGNN_TRY(stemgnn_sage_agg_bwd_acc(g_agg, h_prev, N, y.in_dim, g->rowptr_t, g->dst_t, g->eid_t, g->inv_deg,
-                                           edge_attr, etab, g->etype_slot_t, T, g_prev, stream));
+      STEMGNN_TRY(stemgnn_sage_agg_bwd_acc_k(g_agg, h_prev, cfg->feature_kind, N, y.in_dim, g->rowptr_t, g->dst_t,
+                                             g->eid_t, g->inv_deg, edge_attr, etab, g->etype_slot_t, T, g_prev, stream));
     }
     g_h = g_prev;
   }

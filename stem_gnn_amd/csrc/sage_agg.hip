@@ -107,7 +107,7 @@ __device__ __forceinline__ void plan_append(const SplitArgs& sp, int row, int be
 // ---------------------------------------------------------------------------------------
 // Forward.  G lanes per destination row, each lane owns V float4 columns (col = lane + G*v).
 // ---------------------------------------------------------------------------------------
-template <int G, int V, int MODE, int R, int UU = 0>
+template <int G, int V, int MODE, int R, int UU = 0, int XK = 0>
 __global__ void __launch_bounds__(kBlock)
 k_sage_agg_fwd(const float* __restrict__ x, int64_t N, int D, const int32_t* __restrict__ rowptr,
                const int32_t* __restrict__ src, const int32_t* __restrict__ aux,  // eid (dense) or etype per slot
@@ -118,6 +118,9 @@ k_sage_agg_fwd(const float* __restrict__ x, int64_t N, int D, const int32_t* __r
   // neighbour rows in flight per group: 4 on full graphs (8 measured slower there); UU overrides it for launches over
   // the ~1e4 active rows of a sampled batch, which are a chain of round trips and want a whole row's edges in flight
   constexpr int U = UU ? UU : (V <= 3 ? 4 : (V == 4 ? 2 : 1));
+  // XK: the source rows are stored as fp32 (0) or bf16 (1, common.h: kBF16).  Compile-time, and the loaded bits stay
+  // raw until the accumulate phase: a widening next to each load made the compiler wait per load (1.4x at D = 768).
+  relu &= 1;
   const int lane = threadIdx.x % G;
   const int group = threadIdx.x / G;
   const int nvec = D / 4;
@@ -191,18 +194,19 @@ k_sage_agg_fwd(const float* __restrict__ x, int64_t N, int D, const int32_t* __r
         if (MODE != kNoEdge) my_aux = aux[base + lane];
       }
       for (int j = 0; j < cnt; j += U) {
-        float4 xv[U][V], ev[U][V];
+        Raw4<XK> xv[U][V];
+        float4 ev[U][V];
 #pragma unroll
         for (int k = 0; k < U; ++k) {
           const int jj = (j + k < cnt) ? j + k : j;  // clamp: duplicate load, contribution masked below
           const int s = __shfl(my_src, jj, G);
           const int a = __shfl(my_aux, jj, G);
-          const float* xr = x + static_cast<int64_t>(s) * D;
+          const int64_t xr = static_cast<int64_t>(s) * D;
 #pragma unroll
           for (int v = 0; v < V; ++v) {
             const int c = lane + G * v;
             if (c < nvec) {
-              xv[k][v] = ld4(xr + 4 * c);
+              xv[k][v].load(x, xr + 4 * c);
               if (MODE == kDenseEdge) ev[k][v] = ld4(edge_attr + static_cast<int64_t>(a) * D + 4 * c);
               else if (MODE == kTableLds) ev[k][v] = ld4(lds_tab + static_cast<int64_t>(a) * D + 4 * c);
               else if (MODE == kTableGlobal) ev[k][v] = ld4(etab + static_cast<int64_t>(a) * D + 4 * c);
@@ -216,10 +220,11 @@ k_sage_agg_fwd(const float* __restrict__ x, int64_t N, int D, const int32_t* __r
 #pragma unroll
             for (int v = 0; v < V; ++v) {
               if (lane + G * v < nvec) {
-                acc[v].x += msg(xv[k][v].x + ev[k][v].x, relu);
-                acc[v].y += msg(xv[k][v].y + ev[k][v].y, relu);
-                acc[v].z += msg(xv[k][v].z + ev[k][v].z, relu);
-                acc[v].w += msg(xv[k][v].w + ev[k][v].w, relu);
+                const float4 xw = xv[k][v].widen();
+                acc[v].x += msg(xw.x + ev[k][v].x, relu);
+                acc[v].y += msg(xw.y + ev[k][v].y, relu);
+                acc[v].z += msg(xw.z + ev[k][v].z, relu);
+                acc[v].w += msg(xw.w + ev[k][v].w, relu);
               }
             }
           }
@@ -305,6 +310,7 @@ k_sage_agg_bwd(const float* __restrict__ g_agg, const float* __restrict__ x, int
   // bit 1 of `relu`: ACCUMULATE -- g_x already holds a gradient (lin_r's backward-data product) and this pass adds
   // to it; rows without out-edges are then left alone instead of being zeroed.  Row mode only.
   const bool accumulate = (relu & 2) != 0;
+  const int xk = (relu >> 2) & 1;  // bit 2: the layer input x (read for the relu mask) is stored as bf16
   relu &= 1;
   // Same latency ordering as the forward: extent, first chunk of (target, weight, type), the source row and the
   // zero rows all go out before the table is staged; nobody returns above the barrier inside stage_table.
@@ -345,7 +351,7 @@ k_sage_agg_bwd(const float* __restrict__ g_agg, const float* __restrict__ x, int
   for (int v = 0; v < V; ++v) {
     acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int c = lane + G * v;
-    xs[v] = (live && c < nvec && beg < end) ? ld4(x + row * D + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    xs[v] = (live && c < nvec && beg < end) ? ld4_kind(x, row * D + 4 * c, xk) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   float4 prior[V];
 #pragma unroll
@@ -456,11 +462,15 @@ int launch_fwd_r(size_t lds, dim3 grid, hipStream_t st, const float* x, int64_t 
       g_k1_profile.events.emplace_back(ev0, ev1);
     }
   }
+  const bool xb = (relu & 4) != 0;  // bit 2: bf16-stored source rows
   if (ev0) {
-    hipExtLaunchKernelGGL((k_sage_agg_fwd<G, V, MODE, R, UU>), grid, dim3(kBlock), lds, st, ev0, ev1, 0, x, N, D, rowptr,
-                          src, aux, ea, etab, T, agg, relu, sp);
+    if (xb) hipExtLaunchKernelGGL((k_sage_agg_fwd<G, V, MODE, R, UU, 1>), grid, dim3(kBlock), lds, st, ev0, ev1, 0, x, N, D,
+                                  rowptr, src, aux, ea, etab, T, agg, relu, sp);
+    else hipExtLaunchKernelGGL((k_sage_agg_fwd<G, V, MODE, R, UU, 0>), grid, dim3(kBlock), lds, st, ev0, ev1, 0, x, N, D,
+                               rowptr, src, aux, ea, etab, T, agg, relu, sp);
   } else {
-    k_sage_agg_fwd<G, V, MODE, R, UU><<<grid, kBlock, lds, st>>>(x, N, D, rowptr, src, aux, ea, etab, T, agg, relu, sp);
+    if (xb) k_sage_agg_fwd<G, V, MODE, R, UU, 1><<<grid, kBlock, lds, st>>>(x, N, D, rowptr, src, aux, ea, etab, T, agg, relu, sp);
+    else k_sage_agg_fwd<G, V, MODE, R, UU, 0><<<grid, kBlock, lds, st>>>(x, N, D, rowptr, src, aux, ea, etab, T, agg, relu, sp);
   }
   STEMGNN_LAUNCH_CHECK();
   return STEMGNN_OK;
@@ -700,6 +710,23 @@ int stemgnn_sage_agg_bwd(const float* g_agg, const float* x, int64_t N, int64_t 
                          const float* etab, const int32_t* etype_slot_t, int64_t T, float* g_x, void* stream_) {
   return sage_agg_bwd_impl(g_agg, x, N, D, rowptr_t, dst_t, eid_t, inv_deg, edge_attr, etab, etype_slot_t, T, g_x, 1,
                            nullptr, 0, stream_);
+}
+
+int stemgnn_sage_agg_fwd_k(const void* x, int32_t x_kind, int64_t N, int64_t D, const int32_t* rowptr, const int32_t* src,
+                           const int32_t* eid, const float* edge_attr, const float* etab, const int32_t* etype_slot,
+                           int64_t T, float* agg, void* stream_) {
+  if (x_kind != kF32 && x_kind != kBF16) return STEMGNN_ERR_INVALID_ARG;
+  return sage_agg_fwd_impl(static_cast<const float*>(x), N, D, rowptr, src, eid, edge_attr, etab, etype_slot, T, agg,
+                           1 | (x_kind << 2), nullptr, 0, stream_);
+}
+
+int stemgnn_sage_agg_bwd_acc_k(const float* g_agg, const void* x, int32_t x_kind, int64_t N, int64_t D,
+                               const int32_t* rowptr_t, const int32_t* dst_t, const int32_t* eid_t, const float* inv_deg,
+                               const float* edge_attr, const float* etab, const int32_t* etype_slot_t, int64_t T,
+                               float* g_x, void* stream_) {
+  if (x_kind != kF32 && x_kind != kBF16) return STEMGNN_ERR_INVALID_ARG;
+  return sage_agg_bwd_impl(g_agg, static_cast<const float*>(x), N, D, rowptr_t, dst_t, eid_t, inv_deg, edge_attr, etab,
+                           etype_slot_t, T, g_x, 1 | 2 | (x_kind << 2), nullptr, 0, stream_);
 }
 
 int stemgnn_sage_agg_bwd_acc(const float* g_agg, const float* x, int64_t N, int64_t D, const int32_t* rowptr_t,

@@ -369,6 +369,9 @@ class Encoder(nn.Module):
         if z is not None:
             self._last_env_reg = self._zero_reg(z.device)
             return z
+        if x.dtype != torch.float32:
+            raise NotImplementedError("bf16-stored features run through the encoder phase only (sage backbone without "
+                                      "MoE layers, no hub rows); this configuration needs fp32 features")
         z = self._encode_layers(x, graph, edge_attr)
         return z if out_rows is None else z[:out_rows]
 

@@ -240,7 +240,8 @@ class PretrainModel(nn.Module):
                 and orig_edge_attr.etype.dtype == torch.int64
                 and isinstance(self.feat_recon_decoder, nn.Linear) and isinstance(self.topo_sem_recon_decoder, nn.Linear)
                 and isinstance(dec, InnerProductDecoder) and dec.proj_z and query.size(0) >= 2
-                and 0 < bs <= query.size(0) and orig_x.dtype == torch.float32 and orig_x.size(1) % 4 == 0):
+                and 0 < bs <= query.size(0) and orig_x.dtype in (torch.float32, torch.bfloat16)
+                and orig_x.size(1) % 4 == 0):
             return None
         d = query.size(1)
         if (tuple(self.topo_sem_recon_decoder.weight.shape) != (d, 2 * d) or tuple(dec.lin.weight.shape) != (d, d)
@@ -263,8 +264,10 @@ class PretrainModel(nn.Module):
         _, o3 = ops.next_dropout_key()
         lins = (self.feat_recon_decoder, dec.lin, self.topo_sem_recon_decoder, self.sem_projector)
         params = [t for lin in lins for t in (lin.weight, lin.bias)]
+        # the feature head's target: the seed rows in fp32 (bf16-stored features widen exactly)
+        x_feat = orig_x if orig_x.dtype == torch.float32 else orig_x[:int(bs)].float()
         return ops.HeadsFn.apply(query, graph, orig_edge_attr.table, orig_edge_attr.etype.contiguous(),
-                                 orig_x.contiguous(), z_t.contiguous(), int(bs), k, (seed, (o1, o2, o3)),
+                                 x_feat.contiguous(), z_t.contiguous(), int(bs), k, (seed, (o1, o2, o3)),
                                  self.last_draws, *params)
 
     def forward(self, aug_g, g, topo_recon_ratio=1.0, bs=None, no_codebook=False, draws=None):

@@ -44,6 +44,15 @@ def _req(t: Tensor, dtype, name: str, ndim: Optional[int] = None) -> Tensor:
     return t
 
 
+def _kind(t: Tensor) -> int:
+    """Element kind of a feature operand (include/stemgnn.h: STEMGNN_F32 / STEMGNN_BF16)."""
+    if t.dtype == torch.float32:
+        return 0
+    if t.dtype == torch.bfloat16:
+        return 1
+    raise RuntimeError(f"feature storage must be float32 or bfloat16, got {t.dtype}")
+
+
 def _workspace(nbytes: int, device) -> Tensor:
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
@@ -176,11 +185,11 @@ def negative_sample_into(g, selected: Tensor, k: int, seed: int, offset: int, ou
 
 def mask_columns(x: Tensor, p: float, key=None):
     """mask_feature(x, p, mode='col'): -> (masked copy, (seed, offset)); keep mask =
-    dropout_keep_mask(D, p, seed, offset)."""
-    _req(x, torch.float32, "x", 2)
+    dropout_keep_mask(D, p, seed, offset).  x fp32 or bf16 (bf16 feature storage); the copy has x's dtype."""
+    _req(x, x.dtype if x.dtype == torch.bfloat16 else torch.float32, "x", 2)
     seed, offset = key if key is not None else next_dropout_key()
     out = torch.empty_like(x)
-    check(lib.stemgnn_mask_columns(_p(x), x.size(0), x.size(1), float(p), seed, offset, _p(out), _stream()),
+    check(lib.stemgnn_mask_columns_k(_p(x), _kind(x), x.size(0), x.size(1), float(p), seed, offset, _p(out), _stream()),
           "mask_columns")
     return out, (seed, offset)
 
@@ -450,7 +459,7 @@ def graph_view(graph, need_transpose: bool) -> GraphView:
 def encoder_phase_ok(graph, x: Tensor, dense: Optional[Tensor], etab: Optional[Tensor]) -> bool:
     """The fused phase covers what the pretraining path runs: fp32 CUDA rows, a graph without heavy rows (no split
     plan on either side) and at most one edge-attribute form."""
-    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.size(1) % 4 == 0):
+    if not (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and x.dim() == 2 and x.size(1) % 4 == 0):
         return False
     if graph.num_nodes != x.size(0) or graph.num_nodes == 0:
         return False
@@ -487,7 +496,7 @@ class EncoderFn(torch.autograd.Function):
                 g = grads[5 * l:5 * l + 5]
                 y.g_w_l, y.g_b_l, y.g_w_r, y.g_bn_weight, y.g_bn_bias = (_p(t) for t in g)
         cfg = EncoderCfg(L, int(cfg_d["use_bn"]), int(cfg_d["training"]), int(cfg_d["act"]), float(cfg_d["slope"]),
-                         float(cfg_d["p"]), int(cfg_d.get("out_rows") or 0))
+                         float(cfg_d["p"]), int(cfg_d.get("out_rows") or 0), int(cfg_d.get("feature_kind") or 0))
         return arr, cfg
 
     @staticmethod
@@ -496,6 +505,9 @@ class EncoderFn(torch.autograd.Function):
         for t in params:
             if t is not None:
                 _req(t, torch.float32, "encoder parameter")
+        meta = (dict(meta[0], feature_kind=_kind(x)), meta[1])  # the input's dtype IS the storage mode
+        if x.dtype == torch.bfloat16 and x.requires_grad:
+            raise RuntimeError("encoder phase: bf16-stored features take no gradient")
         arr, cfg = EncoderFn._layers(meta, params)
         need_bwd = bool(meta[0].get("wants_grad", True))  # grad mode is off inside forward: the caller decides
         gv = graph_view(graph, need_bwd)
@@ -1384,21 +1396,20 @@ def set_gather_validation(flag: bool) -> None:
 
 
 def gather_rows(table: Tensor, index: Tensor, validate: Optional[bool] = None) -> Tensor:
-    """out[i] = table[index[i]] (device-side node_text_feat[x] of reference pretrain.py:33-38).  Out-of-range
-    indices raise IndexError when validation is on (the default); with validation off their rows read as zeros."""
-    _req(table, torch.float32, "table", 2)
+    """out[i] = table[index[i]] (device-side node_text_feat[x] of reference pretrain.py:33-38), in the table's dtype
+    (fp32, or bf16 when the features are stored as bf16).  Out-of-range indices raise IndexError when validation is on
+    (the default); with validation off their rows read as zeros."""
+    _req(table, table.dtype if table.dtype == torch.bfloat16 else torch.float32, "table", 2)
     _req(index, torch.int64, "index", 1)
-    out = torch.empty(index.numel(), table.size(1), dtype=torch.float32, device=table.device)
-    if _validate_gather if validate is None else validate:
-        bad = torch.empty(1, dtype=torch.int32, device=table.device)
-        check(lib.stemgnn_gather_rows_checked(_p(table), table.size(0), table.size(1), _p(index), index.numel(), _p(out),
-                                              _p(bad), _stream()), "gather_rows")
+    out = torch.empty(index.numel(), table.size(1), dtype=table.dtype, device=table.device)
+    check_range = _validate_gather if validate is None else validate
+    bad = torch.empty(1, dtype=torch.int32, device=table.device) if check_range else None
+    check(lib.stemgnn_gather_rows_k(_p(table), _kind(table), table.size(0), table.size(1), _p(index), index.numel(),
+                                    _p(out), _p(bad), _stream()), "gather_rows")
+    if bad is not None:
         n_bad = int(bad.item())
         if n_bad:
             raise IndexError(f"gather_rows: {n_bad} of {index.numel()} indices lie outside [0, {table.size(0)})")
-        return out
-    check(lib.stemgnn_gather_rows(_p(table), table.size(0), table.size(1), _p(index), index.numel(), _p(out), _stream()),
-          "gather_rows")
     return out
 
 

@@ -668,3 +668,49 @@ def test_pretrain_step_on_a_multi_dataset_mix_batch(dev):
     loader.epoch += 1
     second = loader._epoch_nodes()
     assert first.numel() == second.numel() and not torch.equal(first, second)
+
+
+def test_pretrain_step_with_bf16_feature_storage(dev):
+    """BASELINE config 5's bf16 option as this library builds it: node features and the layer outputs that the next
+    layer reads are STORED as bf16 (half the bytes for K1's gather, the layer products' activation operand and K2),
+    all arithmetic, the aggregates, z, the VQ core and every gradient stay fp32.  Two bars, both written here:
+      * 1e-4 against the oracle with the SAME storage roundings emulated (round-to-nearest-even at the same points);
+      * 2e-2 against the plain fp32 oracle: what the storage mode itself costs (bf16 has 8 significant bits)."""
+    from stem_gnn_amd import ops
+    from stem_gnn_amd.graph import EdgeTypeAttr
+    from stem_gnn_amd.pretrain import default_params, pretrain_step
+    N, E, D, L, H, K, bs = 600, 5000, 64, 2, 4, 64, 200
+    om, gm = make_models(D, L, H, K, D, dev)
+    om32, _ = make_models(D, L, H, K, D, dev)
+    om.encoder.bf16_storage = om.sem_encoder.bf16_storage = True
+    params = default_params()
+    torch.manual_seed(12)
+    x = torch.nn.functional.normalize(torch.randn(N, D), dim=-1).bfloat16()   # the stored features
+    half = torch.randint(0, N, (2, E // 2))
+    ei = torch.cat([half, half.flip(0)], dim=1)[:, torch.randperm(E)]
+    table = torch.nn.functional.normalize(torch.randn(4, D), dim=-1)
+    et = torch.randint(0, 4, (E,))
+    opt_o = torch.optim.AdamW(om.parameters(), lr=1e-4, weight_decay=1e-5)
+    opt_32 = torch.optim.AdamW(om32.parameters(), lr=1e-4, weight_decay=1e-5)
+    opt_g = torch.optim.AdamW(gm.parameters(), lr=1e-4, weight_decay=1e-5)
+    ops.manual_seed(5)
+    xg = x.to(dev)
+    assert xg.dtype == torch.bfloat16
+    for step in range(2):
+        loss_g, losses_g, draws = pretrain_step(gm, opt_g, None, params, xg, ei.to(dev), EdgeTypeAttr(table.to(dev), et.to(dev)), bs)
+        cpu_draws = {k: ([m.cpu() for m in v] if isinstance(v, list) else v.cpu()) for k, v in draws.items()}
+        loss_o, losses_o, _ = O.pretrain_step(om, opt_o, None, params, x.float(), ei, table[et], bs, cpu_draws)
+        loss_f, losses_f, _ = O.pretrain_step(om32, opt_32, None, params, x.float(), ei, table[et], bs, cpu_draws)
+        for k in losses_o:
+            torch.testing.assert_close(losses_g[k].cpu().reshape(-1), losses_o[k].reshape(-1), rtol=1e-4, atol=1e-5,
+                                       msg=lambda m: f"step {step} {k} (storage emulated): {m}")
+            torch.testing.assert_close(losses_g[k].cpu().reshape(-1), losses_f[k].reshape(-1), rtol=2e-2, atol=1e-3,
+                                       msg=lambda m: f"step {step} {k} (plain fp32 oracle): {m}")
+    # the modules really ran on bf16 storage: the student's first-layer output is a bf16 tensor's worth of values
+    with torch.no_grad():
+        z = gm.encoder(xg, ei.to(dev), EdgeTypeAttr(table.to(dev), et.to(dev)))
+    assert z.dtype == torch.float32 and tuple(z.shape) == (N, D)
+    for (n1, p1), (n2, p2) in zip(om.named_parameters(), gm.named_parameters()):
+        if "lin_l.bias" in n1 or n1.startswith("sem_encoder"):
+            continue
+        torch.testing.assert_close(p2.detach().cpu(), p1.detach(), rtol=1e-3, atol=3e-4, msg=lambda m: f"{n1}: {m}")
