@@ -292,6 +292,10 @@ int stemgnn_linear_set_mode(int mode);
  * sampled batch, whose edges all end in the leading, expanded nodes; x1 may be a [x1_rows, K1] buffer): row tiles
  * past them skip the x1 half of the contraction.  Pass -1 (or M) when x1 has M meaningful rows. */
 size_t stemgnn_linear_stats_partial_bytes(int64_t num_rows, int64_t out_dim);
+/* The weight-stationary kernel (csrc/wsgemm.hip) takes the products with one 128-column operand and at least
+ * `min_tiles` 128-row tiles (default 128; 0 = never: every product on the tile kernel).  Negative: query only.
+ * Returns the previous value.  Both kernels return the same bits; the switch exists for A/B runs and tests. */
+int stemgnn_linear_set_ws(int min_tiles);
 int64_t stemgnn_linear_stats_blocks(int64_t num_rows, int64_t out_dim);
 int stemgnn_linear_fwd(const float* x1, const float* w1, int64_t k1, const float* x2, const float* w2, int64_t k2,
                        const float* bias, int64_t num_rows, int64_t out_dim, float* y, float* stats_partial,

@@ -142,6 +142,7 @@ _SIGNATURES = {
     "stemgnn_bn_stats_from_partials": (c_int, [P, I64, I64, I64, c_float, P, P, P, P, c_float, P, P]),
     "stemgnn_linear_stats_partial_bytes": (c_size_t, [I64, I64]),
     "stemgnn_linear_stats_blocks": (I64, [I64, I64]),
+    "stemgnn_linear_set_ws": (I32, [I32]),
     "stemgnn_clip_grad_max_tensors": (I32, []),
     "stemgnn_clip_grad_workspace_bytes": (c_size_t, [I64, I32]),
     "stemgnn_clip_grad_norm": (c_int, [P, P, I32, c_float, P, P, c_size_t, P]),

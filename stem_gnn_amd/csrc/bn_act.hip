@@ -141,10 +141,26 @@ __device__ inline void reduce_partials(const float* __restrict__ partial, int bl
   __shared__ double red_s[kBlock], red_q[kBlock];
   double s = 0.0, q = 0.0;
   if (c < D) {
-    for (int b = slice; b < blocks; b += kFinSlices) {
-      s += partial[(static_cast<int64_t>(b) * 2) * D + c];
-      q += partial[(static_cast<int64_t>(b) * 2 + 1) * D + c];
+    // eight loads in flight per thread (the slabs sit in L2; a one-at-a-time walk is a chain of its latencies), four
+    // running sums combined in a fixed order
+    double sa[4] = {0.0, 0.0, 0.0, 0.0}, qa[4] = {0.0, 0.0, 0.0, 0.0};
+    int b = slice;
+    for (; b + 3 * kFinSlices < blocks; b += 4 * kFinSlices) {
+      float v[4], u[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[j] = partial[(static_cast<int64_t>(b + j * kFinSlices) * 2) * D + c];
+        u[j] = partial[(static_cast<int64_t>(b + j * kFinSlices) * 2 + 1) * D + c];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { sa[j] += v[j]; qa[j] += u[j]; }
     }
+    for (int j = 0; b < blocks; b += kFinSlices, ++j) {
+      sa[j] += partial[(static_cast<int64_t>(b) * 2) * D + c];
+      qa[j] += partial[(static_cast<int64_t>(b) * 2 + 1) * D + c];
+    }
+    s = (sa[0] + sa[1]) + (sa[2] + sa[3]);
+    q = (qa[0] + qa[1]) + (qa[2] + qa[3]);
   }
   red_s[threadIdx.x] = s;
   red_q[threadIdx.x] = q;

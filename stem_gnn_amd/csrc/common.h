@@ -144,6 +144,13 @@ __device__ __forceinline__ floatx16 mfma_x3(const bf16x8 (&a)[3], const bf16x8 (
   return c;
 }
 
+// csrc/wsgemm.hip: the weight-stationary dense product (K == 128): rows row_base.. of  y = x w^T + b  (bt: y = x w with w
+// given as [K][N]); stats_partial[stats_block0 + tile][2][N] takes the column sums / sums of squares per 128-row tile
+bool linear_ws_ok(int64_t M, int64_t N, int64_t K);
+int linear_ws_launch(const float* x, const float* w, const float* bias, int64_t M, int64_t N, int64_t K, float* y,
+                     float* stats_partial, int64_t row_base, int64_t stats_block0, int64_t store_rows, bool bt,
+                     hipStream_t st);
+
 // csrc/linear.hip: row-split count of a weight-gradient product and the fixed-order reduction of its partial slabs
 // (out[i] = sum_s partial[s][i]; the second family, e.g. the bias gradient, is optional), shared with csrc/pgemm.hip
 int plane_split_count(int64_t M, int64_t out_tiles);

@@ -184,12 +184,13 @@ k_linear_fwd(const float* __restrict__ x1, const float* __restrict__ w1, int K1,
   if (STATS) {
     __syncthreads();
     if (tid < kBN && n0 + tid < N) {
-      float t1 = 0.f, t2 = 0.f;
+      // one slab per 64-row half of a 128-row tile (what the weight-stationary kernel's tiles are), one per 32-row tile
 #pragma unroll
-      for (int w = 0; w < WM; ++w) { t1 += s_stats[w][0][tid]; t2 += s_stats[w][1][tid]; }
-      float* p = stats_partial + (stats_block0 + blockIdx.x) * 2 * N;
-      p[n0 + tid] = t1;
-      p[N + n0 + tid] = t2;
+      for (int w = 0; w < WM; ++w) {
+        float* p = stats_partial + (stats_block0 + static_cast<int64_t>(blockIdx.x) * WM + w) * 2 * N;
+        p[n0 + tid] = s_stats[w][0][tid];
+        p[N + n0 + tid] = s_stats[w][1][tid];
+      }
     }
   }
 }
@@ -386,12 +387,12 @@ k_linear_fwd_x3(const float* __restrict__ x1, const float* __restrict__ w1, int 
       }
       __syncthreads();
       if (tid < kBN && n0 + tid < N) {
-        float t1 = 0.f, t2 = 0.f;
 #pragma unroll
-        for (int w = 0; w < WM; ++w) { t1 += s_stats[w][0][tid]; t2 += s_stats[w][1][tid]; }
-        float* p = stats_partial + (stats_block0 + blockIdx.x) * 2 * N;
-        p[n0 + tid] = t1;
-        p[N + n0 + tid] = t2;
+        for (int w = 0; w < WM; ++w) {
+          float* p = stats_partial + (stats_block0 + static_cast<int64_t>(blockIdx.x) * WM + w) * 2 * N;
+          p[n0 + tid] = s_stats[w][0][tid];
+          p[N + n0 + tid] = s_stats[w][1][tid];
+        }
       }
     }
     return;
@@ -428,12 +429,13 @@ k_linear_fwd_x3(const float* __restrict__ x1, const float* __restrict__ w1, int 
   if (STATS) {
     __syncthreads();
     if (tid < kBN && n0 + tid < N) {
-      float t1 = 0.f, t2 = 0.f;
+      // one slab per 64-row half of a 128-row tile (what the weight-stationary kernel's tiles are), one per 32-row tile
 #pragma unroll
-      for (int w = 0; w < WM; ++w) { t1 += s_stats[w][0][tid]; t2 += s_stats[w][1][tid]; }
-      float* p = stats_partial + (stats_block0 + blockIdx.x) * 2 * N;
-      p[n0 + tid] = t1;
-      p[N + n0 + tid] = t2;
+      for (int w = 0; w < WM; ++w) {
+        float* p = stats_partial + (stats_block0 + static_cast<int64_t>(blockIdx.x) * WM + w) * 2 * N;
+        p[n0 + tid] = s_stats[w][0][tid];
+        p[N + n0 + tid] = s_stats[w][1][tid];
+      }
     }
   }
 }
@@ -918,8 +920,11 @@ inline FwdPlan plan_fwd(int64_t M, int64_t N) {
 // re-read) want S small: S = 512 / (#output tiles), capped at 256 (one tile: 58.8 us at S = 247
 // vs 65 us at S = 458; four tiles: 134-149 us at S = 128 vs 176-183 us at S = 458).
 inline int pick_splits(int64_t M, int64_t tiles) {
-  int64_t target = 512 / (tiles < 1 ? 1 : tiles);
-  if (target > 256) target = 256;
+  static const int64_t env_blocks = [] { const char* e = getenv("STEMGNN_DW_BLOCKS"); return e ? atoll(e) : 0; }();
+  static const int64_t env_cap = [] { const char* e = getenv("STEMGNN_DW_CAP"); return e ? atoll(e) : 0; }();
+  int64_t target = (env_blocks > 0 ? env_blocks : 512) / (tiles < 1 ? 1 : tiles);
+  const int64_t cap = env_cap > 0 ? env_cap : 256;
+  if (target > cap) target = cap;
   if (target < 1) target = 1;
   int64_t rows = (M + target - 1) / target;
   rows = (rows + kKC - 1) / kKC * kKC;
@@ -929,6 +934,21 @@ inline int pick_splits(int64_t M, int64_t tiles) {
   if (s > kMaxSplits) s = kMaxSplits;
   return static_cast<int>(s);
 }
+
+// the weight-stationary kernel wants most CUs busy: products with fewer 128-row tiles stay on the tile kernel.
+// STEMGNN_WS=0 (or stemgnn_linear_set_ws) keeps every product there (A/B, tests).
+std::atomic<int> g_ws_min_tiles{-1};  // -1: not read yet; 0: off
+inline int64_t ws_min_tiles() {
+  int v = g_ws_min_tiles.load(std::memory_order_relaxed);
+  if (v < 0) {
+    const char* e = getenv("STEMGNN_WS");
+    v = (e && e[0] == '0') ? 0 : 128;
+    g_ws_min_tiles.store(v, std::memory_order_relaxed);
+  }
+  return v;
+}
+inline bool ws_enabled() { return ws_min_tiles() > 0; }
+#define kWsMinTiles ws_min_tiles()
 
 inline int64_t out_tiles(int64_t N, int64_t K) { return ((N + kBN - 1) / kBN) * ((K + kBN - 1) / kBN); }
 
@@ -952,6 +972,12 @@ using namespace stemgnn;
 
 extern "C" {
 
+int stemgnn_linear_set_ws(int min_tiles) {
+  const int prev = static_cast<int>(ws_min_tiles());
+  if (min_tiles >= 0) g_ws_min_tiles.store(min_tiles, std::memory_order_relaxed);
+  return prev;
+}
+
 int stemgnn_linear_set_mode(int mode) {
   const int prev = gemm_x3() ? 1 : 0;
   if (mode == 0 || mode == 1) g_gemm_mode.store(mode, std::memory_order_relaxed);
@@ -960,13 +986,13 @@ int stemgnn_linear_set_mode(int mode) {
 
 size_t stemgnn_linear_stats_partial_bytes(int64_t M, int64_t N) {
   if (M < 0 || N <= 0) return 0;
-  return static_cast<size_t>((M + 31) / 32) * 2 * N * sizeof(float) + 256;  // upper bound over every tile plan
+  return static_cast<size_t>((M + 31) / 32 + 2) * 2 * N * sizeof(float) + 256;  // upper bound over every tile plan
 }
 
 int64_t stemgnn_linear_stats_blocks(int64_t M, int64_t N) {
   if (M < 0 || N <= 0) return 0;
   const FwdPlan p = plan_fwd(M, N);
-  return p.main_tiles + p.tail_tiles;
+  return 2 * p.main_tiles + p.tail_tiles;  // a slab per 64-row half of a 128-row tile, one per 32-row tile
 }
 
 int stemgnn_linear_fwd(const float* x1, const float* w1, int64_t K1, const float* x2, const float* w2, int64_t K2,
@@ -1004,6 +1030,24 @@ int stemgnn_linear_fwd_rows_k(const float* x1, const float* w1, int64_t K1, cons
   const FwdPlan plan = plan_fwd(M, N);
   const int k1 = static_cast<int>(K1), k2 = static_cast<int>(K2), n = static_cast<int>(N);
   const bool x3 = gemm_x3();
+  // Weight-stationary kernel (csrc/wsgemm.hip) for a product with ONE 128-column operand.  (Splitting a sampled
+  // batch's layer product -- leading tiles with both operands on the tile kernel, the rest there -- was measured: the
+  // small leading launch costs more than the rest gains, 54 vs 41 us per layer at C4.)
+  if (x3 && !bf && ws_enabled() && N % kBN == 0) {
+    const int64_t tiles = (M + kBM - 1) / kBM;
+    const float *xs = nullptr, *wsrc = nullptr;
+    if (K2 == 0 && K1 == 128 && x1r >= M) { xs = x1; wsrc = w1; }
+    else if (K2 == 128 && x1r == 0) { xs = x2; wsrc = w2; }  // no row carries the first operand
+    if (xs && tiles >= kWsMinTiles) {
+      const int rc = linear_ws_launch(xs, wsrc, bias, M, N, 128, y, stats_partial, 0, 0, sr, false, st);
+      if (rc != STEMGNN_OK) return rc;
+      // what callers reduce over (stemgnn_linear_stats_blocks): the slabs past the 64-row tiles written here are zero
+      const int64_t count = 2 * plan.main_tiles + plan.tail_tiles, written = (M + 63) / 64;
+      if (stats_partial && count > written)
+        STEMGNN_HIP_TRY(hipMemsetAsync(stats_partial + written * 2 * N, 0, sizeof(float) * (count - written) * 2 * N, st));
+      return STEMGNN_OK;
+    }
+  }
   if (plan.main_tiles > 0) {
     dim3 grid(static_cast<unsigned>(plan.main_tiles), static_cast<unsigned>(gy));
     if (stats_partial) {
@@ -1024,18 +1068,18 @@ int stemgnn_linear_fwd_rows_k(const float* x1, const float* w1, int64_t K1, cons
     const int64_t row_base = plan.main_tiles * kBM;
     if (stats_partial) {
       if (x3 && bf) k_linear_fwd_x3<32, true, false, kBF16><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, stats_partial,
-                                                                                     row_base, plan.main_tiles, x1r, sr);
+                                                                                     row_base, 2 * plan.main_tiles, x1r, sr);
       else if (x3) k_linear_fwd_x3<32, true><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, stats_partial,
-                                                                      row_base, plan.main_tiles, x1r, sr);
+                                                                      row_base, 2 * plan.main_tiles, x1r, sr);
       else k_linear_fwd<32, true><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, stats_partial,
-                                                           row_base, plan.main_tiles, x1r, sr);
+                                                           row_base, 2 * plan.main_tiles, x1r, sr);
     } else {
       if (x3 && bf) k_linear_fwd_x3<32, false, false, kBF16><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, nullptr,
-                                                                                      row_base, plan.main_tiles, x1r, sr);
+                                                                                      row_base, 2 * plan.main_tiles, x1r, sr);
       else if (x3) k_linear_fwd_x3<32, false><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, nullptr,
-                                                                       row_base, plan.main_tiles, x1r, sr);
+                                                                       row_base, 2 * plan.main_tiles, x1r, sr);
       else k_linear_fwd<32, false><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, nullptr,
-                                                            row_base, plan.main_tiles, x1r, sr);
+                                                            row_base, 2 * plan.main_tiles, x1r, sr);
     }
     STEMGNN_LAUNCH_CHECK();
   }
@@ -1055,6 +1099,8 @@ int stemgnn_linear_bwd_data(const float* dy, const float* w, int64_t M, int64_t 
   const FwdPlan plan = plan_fwd(M, K);
   const int kc = static_cast<int>(N), n = static_cast<int>(K);
   const bool x3 = gemm_x3();
+  if (x3 && ws_enabled() && N == 128 && K % kBN == 0 && (M + kBM - 1) / kBM >= kWsMinTiles)
+    return linear_ws_launch(dy, w, nullptr, M, K, 128, dx, nullptr, 0, 0, M, true, st);
   if (plan.main_tiles > 0) {
     dim3 grid(static_cast<unsigned>(plan.main_tiles), static_cast<unsigned>(gy));
     if (x3) k_linear_fwd_x3<128, false, true><<<grid, kBlock, 0, st>>>(dy, w, kc, nullptr, nullptr, 0, nullptr, M, n, dx, nullptr, 0, 0, M, M);

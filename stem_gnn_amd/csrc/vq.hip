@@ -405,12 +405,14 @@ __device__ __forceinline__ int stage_row8(int idx) {
 // cores (the tile of csrc/linear.hip's backward-data product: exact bf16 pieces, weight read as stored and transposed
 // while staged) and consumed from LDS by the row-wise arithmetic of k_vq_assign_bwd -- the [N, H*Dc] gradient of the
 // quantised rows (vq.py:937,1041: straight-through + project_out) is never written to or read from HBM.
-// grid (row tiles, heads); one head's Dc <= 128 columns are one tile.
+// grid (row tiles, column tiles).  A column tile is 128 columns of the [N, H*Dc] gradient: `hpt` whole heads when Dc
+// divides 128 (H = 4, Dc = 32: ONE tile holds all heads, so g_out is read once and no matrix work is spent on
+// padding columns), else one head per tile (hpt = 1, columns Dc .. 127 of the tile are padding).
 __global__ void __launch_bounds__(kBlock, 2)
 k_vq_assign_bwd_fused(const float* __restrict__ g_out, int D, const float* __restrict__ w_out /*[D][H*Dc]*/,
                       const float* __restrict__ g_loss, float coef, const float* __restrict__ xp,
                       const float* __restrict__ norm, const int64_t* __restrict__ ind, const float* __restrict__ embed,
-                      int64_t N, int H, int Dc, int K, float* __restrict__ g_xp) {
+                      int64_t N, int H, int Dc, int K, float* __restrict__ g_xp, int hpt) {
   constexpr int BM = 128, BN = 128;
   constexpr int PA = BM * kLdP, PB = BN * kLdP;
   __shared__ __attribute__((aligned(16))) unsigned char smem[3 * PA + 3 * PB];
@@ -418,10 +420,12 @@ k_vq_assign_bwd_fused(const float* __restrict__ g_out, int D, const float* __res
   unsigned char* const sB = smem + 3 * PA;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, hi = lane >> 5, lj = lane & 31;
-  const int h = blockIdx.y;
+  const int h0 = blockIdx.y * hpt;  // first head of the tile
   const int64_t m0 = static_cast<int64_t>(blockIdx.x) * BM;
   const int64_t HD = static_cast<int64_t>(H) * Dc;
-  const float* wh = w_out + static_cast<int64_t>(h) * Dc;  // column block of the head; row stride HD
+  const int c0 = h0 * Dc;                                    // first column of the tile
+  const int ncols = min(hpt * Dc, static_cast<int>(HD) - c0);  // live columns of the tile
+  const float* wh = w_out + c0;                              // column block of the tile; row stride HD
   const int steps = (D + kKC - 1) / kKC;
 
   float4 ra[4], rb[4];
@@ -435,7 +439,7 @@ k_vq_assign_bwd_fused(const float* __restrict__ g_out, int D, const float* __res
       ra[t] = (m < N && k < D) ? ld4(g_out + m * D + k) : make_float4(0.f, 0.f, 0.f, 0.f);
       // weight rows k0 + 4 (tid & 7) + t (contraction index d), columns 4 (tid >> 3) .. + 3 of the head
       const int kk = k0 + 4 * (tid & 7) + t, nn = 4 * (tid >> 3);
-      rb[t] = (kk < D && nn < Dc) ? ld4(wh + static_cast<int64_t>(kk) * HD + nn) : make_float4(0.f, 0.f, 0.f, 0.f);
+      rb[t] = (kk < D && nn < ncols) ? ld4(wh + static_cast<int64_t>(kk) * HD + nn) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   auto stash = [&]() {
@@ -492,7 +496,10 @@ k_vq_assign_bwd_fused(const float* __restrict__ g_out, int D, const float* __res
   float* tile = reinterpret_cast<float*>(smem);
   const float s = g_loss ? g_loss[0] * coef : 0.f;
   const int l32 = tid & 31, grp = tid >> 5;  // 8 groups of 32 lanes
-  const bool col_ok = 4 * l32 < Dc;
+  const bool col_ok = 4 * l32 < ncols;
+  const int hl = col_ok ? h0 + (4 * l32) / Dc : h0;  // the head of this lane's four columns
+  const int cl = 4 * l32 - (hl - h0) * Dc;           // ... and their place in the head
+  const int lph = hpt > 1 ? Dc / 4 : 32;             // lanes that share a head (a power of two when hpt > 1)
   int64_t code[16];
   float nrm[16];
 #pragma unroll
@@ -501,8 +508,8 @@ k_vq_assign_bwd_fused(const float* __restrict__ g_out, int D, const float* __res
     code[i] = 0;
     nrm[i] = 1.f;
     if (m < N) {
-      code[i] = ind[m * H + h];
-      nrm[i] = norm[m * H + h];
+      code[i] = ind[m * H + hl];
+      nrm[i] = norm[m * H + hl];
     }
   }
 #pragma unroll
@@ -515,8 +522,8 @@ k_vq_assign_bwd_fused(const float* __restrict__ g_out, int D, const float* __res
       if (c < 0 || c >= K) c = 0;
       xv[pass] = qv[pass] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (m < N && col_ok) {
-        xv[pass] = ld4(xp + m * HD + static_cast<int64_t>(h) * Dc + 4 * l32);
-        qv[pass] = ld4(embed + (static_cast<int64_t>(h) * K + c) * Dc + 4 * l32);
+        xv[pass] = ld4(xp + m * HD + c0 + 4 * l32);
+        qv[pass] = ld4(embed + (static_cast<int64_t>(hl) * K + c) * Dc + cl);
       }
     }
     if (wm == half) {
@@ -546,11 +553,15 @@ k_vq_assign_bwd_fused(const float* __restrict__ g_out, int D, const float* __res
                          gq.w + s * (n.w - qv[pass].w));
         dot = gx.x * n.x + gx.y * n.y + gx.z * n.z + gx.w * n.w;
       }
+      // the row's dot product per head: the lph lanes of a head are an aligned power-of-two run of the group
 #pragma unroll
-      for (int o = 16; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 32);
+      for (int o = 16; o > 0; o >>= 1) {
+        const float other = __shfl_xor(dot, o, 32);
+        if (o < lph) dot += other;
+      }
       if (clamped) dot = 0.f;
       if (live && col_ok)
-        st4(g_xp + m * HD + static_cast<int64_t>(h) * Dc + 4 * l32,
+        st4(g_xp + m * HD + c0 + 4 * l32,
             make_float4((gx.x - n.x * dot) * inv, (gx.y - n.y * dot) * inv, (gx.z - n.z * dot) * inv,
                         (gx.w - n.w * dot) * inv));
     }
@@ -735,9 +746,11 @@ int stemgnn_vq_assign_bwd_fused(const float* g_out, int64_t D, const float* w_ou
   if (N == 0) return STEMGNN_OK;
   if (!g_out || !w_out || !xp || !norm || !ind || !embed || !g_xp) return STEMGNN_ERR_INVALID_ARG;
   const float coef = commit_weight * 2.0f / static_cast<float>(static_cast<double>(N) * H * Dc);
-  dim3 grid(static_cast<unsigned>(row_blocks(N)), static_cast<unsigned>(H));
+  // heads per 128-column tile: whole heads when Dc divides 128 (then Dc / 4 lanes per head is a power of two)
+  const int hpt = (128 % Dc == 0) ? static_cast<int>(std::min<int64_t>(H, 128 / Dc)) : 1;
+  dim3 grid(static_cast<unsigned>(row_blocks(N)), static_cast<unsigned>((H + hpt - 1) / hpt));
   k_vq_assign_bwd_fused<<<grid, kBlock, 0, st>>>(g_out, static_cast<int>(D), w_out, g_loss, coef, xp, norm, ind, embed, N,
-                                                 static_cast<int>(H), static_cast<int>(Dc), static_cast<int>(K), g_xp);
+                                                 static_cast<int>(H), static_cast<int>(Dc), static_cast<int>(K), g_xp, hpt);
   STEMGNN_LAUNCH_CHECK();
   return STEMGNN_OK;
 }

@@ -1,0 +1,284 @@
+// Weight-stationary form of the dense product  Y = X W^T + b  (and  dX = dY W)  for K <= 128 contraction columns:
+// the form every single-operand product of the D = 128 configurations takes (reference model/encoder.py:62-70 lin_r,
+// model/pt_model.py decoders, vq.py project_in / project_out).
+//
+// The tile kernel of csrc/linear.hip stages BOTH operands through LDS for every 128 x 128 tile: the same 64 KB of
+// weights are loaded, cut into bf16 pieces and written to LDS 800 times per launch at C4's batch size, and the pipes
+// a tile uses (loads, the cut on the VALU, LDS, matrix cores, stores) mostly take turns.  Here a persistent
+// 256-thread block (two per CU) keeps its 128 weight columns in REGISTERS as ready-made matrix-core fragments (wave =
+// 64 rows x 32 columns, 96 registers of weight pieces for K = 128, cut once per block), walks over 64-row tiles, and
+// only the activation rows go through LDS.  The registers freed from the weight staging hold the NEXT tile's
+// activation chunks, so a whole tile of loads per block (64 KB per CU) is in flight while the current one is
+// multiplied and stored; the output leaves through an LDS staging tile as 512-byte rows.  One barrier per 32-column
+// chunk, five per tile.  The waves of a block run in lockstep (measured on a 512-thread, 128-row variant: the
+// phases of a tile added up, whatever the instruction order); the two blocks of a CU drift apart and fill each
+// other's gaps.
+//
+// Arithmetic is the three-way bf16 cut of common.h (fp32-accurate); the accumulation order per output element is
+// the tile kernel's, so both kernels return the same bits.
+#include "common.h"
+
+#include <cstdlib>
+
+namespace stemgnn {
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kTileM = 64, kTileN = 128, kKC = 32;
+constexpr int kLdT = kTileN + 4;             // fp32 row stride of the staging tile
+constexpr int kPlane = kTileM * kLdP;        // bytes of one bf16 plane of an activation chunk
+constexpr int kSlot = 3 * kPlane;            // h, m, l
+constexpr size_t kRingBytes = 2 * kSlot;
+constexpr size_t kStageBytes = static_cast<size_t>(kTileM) * kLdT * sizeof(float);
+constexpr size_t kStatsBytes = 2 * kTileN * sizeof(float);
+constexpr size_t kLdsBytes = kRingBytes + kStageBytes + kStatsBytes;
+
+// staging row of float4 slot idx (8 slots per row): rows of every group of eight in the order 0 4 1 5 2 6 3 7 (the two
+// rows one ds_write_b64 group covers share no bank; csrc/linear.hip)
+__device__ __forceinline__ int stage_row(int idx) {
+  const int r = idx >> 3;
+  return (r & ~7) | ((r & 1) << 2) | ((r >> 1) & 3);
+}
+
+__device__ __forceinline__ bf16x8 as_bf16x8(uint4 v) { return __builtin_bit_cast(bf16x8, v); }
+
+template <int V> struct IntTag { static constexpr int value = V; };
+
+// KS = K / 32 chunks per tile.  BT: the weight is given as [K][N] (backward-data, dX = dY W), else as [N][K].
+// N is a multiple of 128 (no column guards anywhere).
+//
+// Every global load and store of the steady-state loop is UNCONDITIONAL (row indices are clamped instead of
+// predicated; a row past M is a copy of row M - 1 that is never stored nor counted).  vmcnt counts loads and stores
+// in one in-order queue, and the compiler can only emit a counted wait -- "the chunk fetched a tile ago has landed"
+// while fourteen younger loads and stores stay in flight -- when the number of younger operations is the same on
+// every path; one predicated load or store between a fetch and its use turns every wait into vmcnt(0), which drains
+// the prefetch and the stores once per tile (measured: no faster than the tile kernel).  Tiles that store all their
+// rows, tiles that store none (rows past store_rows only feed the statistics) and the one tile on the boundary run
+// through three instances of the same body, in that order.
+template <int KS, bool STATS, bool BT>
+__global__ void __launch_bounds__(kThreads, 2)
+k_linear_ws(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, int64_t M, int N,
+            float* __restrict__ y, float* __restrict__ stats_partial /*[64-row tiles][2][N]*/, int64_t row_base,
+            int64_t stats_block0, int64_t store_rows, int dbg) {
+  constexpr int K = KS * kKC;
+  static_assert(KS % 2 == 0, "the last step refills ring slot 0 while slot (KS - 1) & 1 is read");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const ring = smem;
+  float* const tile = reinterpret_cast<float*>(smem + kRingBytes);
+  float* const s_stats = reinterpret_cast<float*>(smem + kRingBytes + kStageBytes);  // [sum|sumsq][128]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave, hi = lane >> 5, lj = lane & 31;
+  const int n0 = blockIdx.y * kTileN;
+  const int64_t row_end = store_rows < M ? store_rows : M;
+  // without statistics nothing past the stored rows is wanted
+  const int64_t tiles = ((STATS ? M : row_end) - row_base + kTileM - 1) / kTileM;
+
+  // ---- the block's weight columns as matrix-core fragments: lane (lj, hi) holds column n0 + 32 wn + lj,
+  // contraction steps 16 ks + 8 hi .. + 7 of every 16-wide step ks, cut into the three bf16 planes
+  bf16x8 bw[2 * KS][3];
+  {
+    const int n = n0 + 32 * wn + lj;
+#pragma unroll
+    for (int ks = 0; ks < 2 * KS; ++ks) {
+      const int k = 16 * ks + 8 * hi;
+      float4 lo, up;
+      if (BT) {
+        const float* p = w + static_cast<int64_t>(k) * N + n;
+        const int64_t ld = N;
+        lo = make_float4(p[0], p[ld], p[2 * ld], p[3 * ld]);
+        up = make_float4(p[4 * ld], p[5 * ld], p[6 * ld], p[7 * ld]);
+      } else {
+        lo = ld4(w + static_cast<int64_t>(n) * K + k);
+        up = ld4(w + static_cast<int64_t>(n) * K + k + 4);
+      }
+      uint4 h, m, l;
+      split8(lo, up, h, m, l);
+      bw[ks][0] = as_bf16x8(h);
+      bw[ks][1] = as_bf16x8(m);
+      bw[ks][2] = as_bf16x8(l);
+    }
+  }
+  const float bias_v = bias != nullptr ? bias[n0 + 32 * wn + lj] : 0.f;
+
+  // ---- activation chunks: 64 rows x 32 columns = 512 float4, two per thread; ra[s] = chunk s of a tile
+  float4 ra[KS][2];
+  const int r0 = stage_row(tid), r1 = stage_row(kThreads + tid), c4s = 4 * (tid & 7);
+  auto fetch = [&](int64_t t, int s) {
+    const int64_t m0 = row_base + (t < tiles ? t : tiles - 1) * kTileM;  // past the last tile: a harmless re-read
+    const int64_t ma = m0 + r0 < M ? m0 + r0 : M - 1, mb = m0 + r1 < M ? m0 + r1 : M - 1;
+    if (dbg & 1) { ra[s][0] = ra[s][1] = make_float4(1.f, 2.f, 3.f, 4.f); return; }  // probe: no activation loads
+    ra[s][0] = ld4(x + ma * K + s * kKC + c4s);
+    ra[s][1] = ld4(x + mb * K + s * kKC + c4s);
+  };
+  auto stash = [&](int s, int slot) {
+    unsigned char* const base = ring + slot * kSlot;
+    if (dbg & 2) return;  // probe: no cut, no LDS writes
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int off = (i ? r1 : r0) * kLdP + 2 * c4s;
+      uint2 h, m, l;
+      split3(ra[s][i], h, m, l);
+      *reinterpret_cast<uint2*>(base + off) = h;
+      *reinterpret_cast<uint2*>(base + kPlane + off) = m;
+      *reinterpret_cast<uint2*>(base + 2 * kPlane + off) = l;
+    }
+  };
+
+  int64_t t = blockIdx.x;
+  if (t >= tiles) return;  // whole block
+  const int64_t stride = gridDim.x;
+#pragma unroll
+  for (int s = 0; s < KS; ++s) fetch(t, s);
+  stash(0, 0);
+  fetch(t + stride, 0);
+  __syncthreads();
+
+  // CLS 0: every row of the tile is stored; 1: none is (statistics only); 2: the boundary tile (predicated stores)
+  auto do_tile = [&](auto cls) {
+    constexpr int CLS = decltype(cls)::value;
+    const int64_t m0 = row_base + t * kTileM;
+    floatx16 acc[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const unsigned char* const slot = ring + (s & 1) * kSlot;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int ko = q * 32 + hi * 16;  // bytes: lane half 0 takes k 0..7, half 1 k 8..15 of the 16-wide step
+        bf16x8 a[2][3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+          for (int tm = 0; tm < 2; ++tm)
+            a[tm][p] = *reinterpret_cast<const bf16x8*>(slot + p * kPlane + (tm * 32 + lj) * kLdP + ko);
+        if (!(dbg & 4)) {  // probe: no matrix instructions
+#pragma unroll
+          for (int tm = 0; tm < 2; ++tm) acc[tm] = mfma_x3(a[tm], bw[2 * s + q], acc[tm]);
+        }
+      }
+      // behind the matrix instructions (they run on while the VALU cuts the next chunk): chunk s + 1 of this tile --
+      // or, at the last step, chunk 0 of the next -- goes to the other ring slot (last read one barrier ago), and
+      // its registers take the same chunk of the tile after
+      if (s + 1 < KS) {
+        stash(s + 1, (s + 1) & 1);
+        fetch(t + stride, s + 1);
+      } else {
+        stash(0, 0);
+        fetch(t + 2 * stride, 0);
+      }
+      // Issue order of the step (the waves of a block run its steps in lockstep, so nothing else hides one pipe
+      // behind another): per 16-wide k step the six fragment reads, then the twelve matrix instructions with the
+      // VALU work of the cut in their shadow (a 32x32x16 occupies the matrix pipe for 32 cycles, the two waves of a
+      // SIMD alternate on it), the LDS writes and the refill loads last.
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);  // DS read
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);  // VALU
+        }
+      }
+      __builtin_amdgcn_sched_group_barrier(0x200, 6, 0);  // DS write
+      __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);  // VMEM read
+      __syncthreads();
+    }
+
+    // ---- epilogue: the tile (+ bias) through the staging buffer, out as 512-byte rows
+    const int nl = 32 * wn + lj;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        acc[tm][r] += bias_v;
+        if (CLS != 1) tile[(tm * 32 + 4 * hi + (r & 3) + 8 * (r >> 2)) * kLdT + nl] = acc[tm][r];
+      }
+    if (STATS) {
+      // column sums of the 64 rows (tm, then r: the tile kernel's order per 64-row half), then the two lane halves
+      float s1 = 0.f, s2 = 0.f;
+      const int64_t live = M - m0 - 4 * hi;  // rows of this lane's sequence below M (whole tile: >= 64)
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (tm * 32 + (r & 3) + 8 * (r >> 2) < live) { s1 += acc[tm][r]; s2 += acc[tm][r] * acc[tm][r]; }
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (hi == 0) { s_stats[nl] = s1; s_stats[kTileN + nl] = s2; }
+    }
+    __syncthreads();
+    if (CLS != 1) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int rl = (tid >> 5) + 8 * i, c4 = tid & 31;
+        const int64_t m = m0 + rl;
+        if (dbg & 8) continue;  // probe: no output stores
+        if (CLS == 0 || m < row_end) st4(y + m * N + n0 + 4 * c4, ld4(tile + rl * kLdT + 4 * c4));
+      }
+    }
+    if (STATS)  // 256 values per tile, one per thread
+      stats_partial[(stats_block0 + t) * 2 * N + static_cast<int64_t>(tid >> 7) * N + n0 + (tid & 127)] = s_stats[tid];
+  };
+
+  // The first fully stored tile is peeled: at the loop header the compiler merges the wait counters of the entry
+  // path and of the back edge to the smaller count, and the prologue (no stores, fewer loads in flight) would cap
+  // every wait of the loop at 7 younger operations -- which drains the 8 stores of the previous tile at every tile.
+  if (t < tiles && row_base + (t + 1) * kTileM <= row_end) {
+    do_tile(IntTag<0>{});
+    t += stride;
+  }
+  for (; t < tiles && row_base + (t + 1) * kTileM <= row_end; t += stride) do_tile(IntTag<0>{});
+  for (; t < tiles && row_base + t * kTileM < row_end; t += stride) do_tile(IntTag<2>{});
+  if (STATS)
+    for (; t < tiles; t += stride) do_tile(IntTag<1>{});
+}
+
+template <int KS, bool STATS, bool BT>
+int launch_ws(const float* x, const float* w, const float* bias, int64_t M, int N, float* y, float* stats_partial,
+              int64_t row_base, int64_t stats_block0, int64_t store_rows, hipStream_t st) {
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1)
+      n = 256;
+    return n;
+  }();
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_linear_ws<KS, STATS, BT>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     static_cast<int>(kLdsBytes));
+  if (attr != hipSuccess) return STEMGNN_ERR_HIP;
+  const int64_t row_end = store_rows < M ? store_rows : M;
+  const int64_t tiles = ((STATS ? M : row_end) - row_base + kTileM - 1) / kTileM;  // as in the kernel
+  if (tiles <= 0) return STEMGNN_OK;
+  const int gy = (N + kTileN - 1) / kTileN;
+  int64_t gx = 2 * cus / gy;  // two resident blocks per CU
+  if (gx < 1) gx = 1;
+  if (gx > tiles) gx = tiles;
+  dim3 grid(static_cast<unsigned>(gx), static_cast<unsigned>(gy));
+  static const int dbg = [] { const char* e = getenv("STEMGNN_WS_DBG"); return e ? atoi(e) : 0; }();  // ablation probe
+  k_linear_ws<KS, STATS, BT><<<grid, kThreads, kLdsBytes, st>>>(x, w, bias, M, N, y, stats_partial, row_base,
+                                                               stats_block0, store_rows, dbg);
+  STEMGNN_LAUNCH_CHECK();
+  return STEMGNN_OK;
+}
+
+}  // namespace
+
+bool linear_ws_ok(int64_t M, int64_t N, int64_t K) { return K == 128 && N % 128 == 0 && M > 0; }
+
+int linear_ws_launch(const float* x, const float* w, const float* bias, int64_t M, int64_t N, int64_t K, float* y,
+                     float* stats_partial, int64_t row_base, int64_t stats_block0, int64_t store_rows, bool bt,
+                     hipStream_t st) {
+  if (!linear_ws_ok(M, N, K)) return STEMGNN_ERR_INVALID_ARG;
+  const int n = static_cast<int>(N);
+  if (bt) return launch_ws<4, false, true>(x, w, bias, M, n, y, nullptr, row_base, 0, store_rows, st);
+  if (stats_partial) return launch_ws<4, true, false>(x, w, bias, M, n, y, stats_partial, row_base, stats_block0, store_rows, st);
+  return launch_ws<4, false, false>(x, w, bias, M, n, y, nullptr, row_base, 0, store_rows, st);
+}
+
+}  // namespace stemgnn

@@ -791,6 +791,7 @@ class LinearFn(torch.autograd.Function):
             gy1, x1p = gy[:rows], x1[:rows]  # leading rows: contiguous views
             if need[0]:
                 gx1 = torch.empty_like(x1)
+                gx1[rows:].zero_()  # rows past x1_rows do not reach the output: their gradient is zero, not garbage
                 if rows > 0:
                     check(lib.stemgnn_linear_bwd_data(_p(gy1), _p(w1), rows, gy.size(1), w1.size(1), _p(gx1), _stream()),
                           "linear_bwd_data")
@@ -1180,7 +1181,9 @@ class QueryFanOutFn(torch.autograd.Function):
         if g_q is None:
             g = torch.zeros(N, D, dtype=torch.float32, device=ei.device)
         else:
-            g = g_q.contiguous()  # freshly produced by the topology decoder's backward-data product
+            # an incoming gradient is not this node's to mutate (another consumer, a hook or retain_grad may hold it):
+            # the scatter below accumulates into a copy
+            g = g_q.clone(memory_format=torch.contiguous_format)
         if g_zz is not None:
             check(lib.stemgnn_edge_concat_bwd(_p(g_zz.contiguous()), N, D, _p(ei), ei.size(1), _p(g), _stream()),
                   "edge_concat_bwd")

@@ -67,14 +67,19 @@ def allreduce_mean_grads_(params: Iterable[Tensor]) -> None:
         off += n
 
 
-def wrap_ddp(model: torch.nn.Module, device_index=None):
+def wrap_ddp(model: torch.nn.Module, device_index=None, find_unused_parameters=False):
     """DistributedDataParallel over the trainable parameters.  The EMA teacher never receives
     gradients (reference pt_model.py:93 detaches it) and is excluded; BatchNorm statistics stay
-    per-rank (no buffer broadcast), like the per-batch statistics of the single-GPU path."""
+    per-rank (no buffer broadcast), like the per-batch statistics of the single-GPU path.
+
+    ``find_unused_parameters``: pass True for runs in which some trainable parameters receive no gradient in a step
+    (``forward(..., no_codebook=True)`` bypasses the VQ projections; a zero loss weight drops a decoder): the reducer
+    then searches the graph for them instead of raising.  The default path (every parameter used, MoE routing soft)
+    runs without the search."""
     if hasattr(model, "sem_encoder"):
         for p in model.sem_encoder.parameters():
             p.requires_grad_(False)
-    kw = dict(broadcast_buffers=False, gradient_as_bucket_view=True)
+    kw = dict(broadcast_buffers=False, gradient_as_bucket_view=True, find_unused_parameters=bool(find_unused_parameters))
     if device_index is not None:
         kw["device_ids"] = [device_index]
     return torch.nn.parallel.DistributedDataParallel(model, **kw)

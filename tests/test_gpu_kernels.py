@@ -820,6 +820,53 @@ def test_plane_products_are_bit_identical_to_the_staged_ones(dev, m, k1, k2, n, 
         torch.testing.assert_close(b1, b0, rtol=1e-5, atol=1e-4 * max(b0.abs().max().item(), 1.0))
 
 
+@pytest.mark.parametrize("m,k2,n,rows,store", [(1000, 0, 128, -1, -1), (777, 0, 512, -1, 300), (2000, 128, 128, 300, -1),
+                                               (1300, 128, 256, 0, -1), (4097, 0, 128, -1, 1000), (129, 0, 96, -1, -1)])
+def test_weight_stationary_product_returns_the_tile_kernels_bits(dev, m, k2, n, rows, store):
+    """csrc/wsgemm.hip (weights as register-resident matrix-core fragments, one persistent block per CU) against the
+    tile kernel of csrc/linear.hip on the products it takes over: a single 128-column operand (also as the second
+    operand when no row carries the first), row-limited output, BatchNorm column sums, backward-data through the
+    weight as stored; shapes it does not take (two live operands, N not a multiple of 128) must fall through."""
+    from stem_gnn_amd import ops
+    from stem_gnn_amd._lib import lib, check
+    torch.manual_seed(m + n)
+    st = torch.cuda.current_stream().cuda_stream
+    k = 128
+    a = torch.randn(m, k, device=dev) * (1 + 3 * torch.rand(m, 1, device=dev))
+    w = torch.randn(n, k, device=dev) * 0.2
+    a2 = torch.randn(m, k2, device=dev) if k2 else None
+    w2 = torch.randn(n, k2, device=dev) * 0.2 if k2 else None
+    b = torch.randn(n, device=dev)
+    if rows >= 0:
+        a[rows:] = 0
+    sr = store if store >= 0 else m
+
+    def run():
+        y = torch.full((m, n), 7.0, device=dev)
+        part = torch.zeros(max(int(lib.stemgnn_linear_stats_blocks(m, n)), 1), 2, n, device=dev)
+        check(lib.stemgnn_linear_fwd_rows(a.data_ptr(), w.data_ptr(), k, a2.data_ptr() if k2 else None,
+                                          w2.data_ptr() if k2 else None, k2, b.data_ptr(), m, n, y.data_ptr(), part.data_ptr(),
+                                          None, rows, sr, st))
+        dy = torch.randn(m, n, device=dev, generator=torch.Generator(device=dev).manual_seed(5))
+        return y, part, ops.linear_bwd_data(dy, w) if n == 128 else None
+
+    prev = lib.stemgnn_linear_set_ws(0)
+    try:
+        y0, p0, d0 = run()
+        lib.stemgnn_linear_set_ws(1)  # every eligible product, whatever its size
+        y1, p1, d1 = run()
+    finally:
+        lib.stemgnn_linear_set_ws(prev)
+    assert torch.equal(y1, y0)
+    assert bool((y1[sr:] == 7.0).all())
+    torch.testing.assert_close(p1.sum(0), p0.sum(0), rtol=1e-6, atol=1e-4 * max(p0.sum(0).abs().max().item(), 1.0))
+    ref = a @ w.t() + b + (a2 @ w2.t() if k2 else 0)
+    torch.testing.assert_close(y1[:sr], ref[:sr], rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(p1.sum(0)[0], ref.sum(0), rtol=1e-4, atol=2e-2)
+    if d0 is not None:
+        assert torch.equal(d1, d0)
+
+
 def test_linear_row_limited_output(dev):
     """stemgnn_linear_fwd_rows: rows past store_rows feed the column statistics but are not written."""
     from stem_gnn_amd._lib import lib, check
@@ -855,7 +902,8 @@ def test_sage_agg_bwd_accumulates(dev):
     assert bool(no_out.any()) and torch.equal(out[no_out.to(dev)], base[no_out.to(dev)])  # untouched, not zeroed
 
 
-@pytest.mark.parametrize("N,H,K,D,Dc", [(1000, 4, 128, 128, 128), (333, 2, 40, 96, 48), (50, 1, 8, 32, 32), (2500, 4, 16, 64, 64)])
+@pytest.mark.parametrize("N,H,K,D,Dc", [(1000, 4, 128, 128, 128), (333, 2, 40, 96, 48), (50, 1, 8, 32, 32), (2500, 4, 16, 64, 64),
+                                        (1000, 4, 64, 128, 32), (700, 6, 24, 128, 32), (300, 5, 12, 64, 8)])
 def test_vq_project_out_algebra_and_fused_backward(dev, N, H, K, D, Dc):
     """The code-table form of project_out (table read, segment-sum weight gradient) and the assignment backward with
     project_out's backward-data product inside, against the plain products they replace."""
@@ -894,6 +942,7 @@ def test_vq_project_out_algebra_and_fused_backward(dev, N, H, K, D, Dc):
     # fused assignment backward == backward-data product + assignment backward
     xp = torch.randn(N, HD, device=dev)
     xp[3] = 0  # a row under the eps clamp of F.normalize
+    xp[5, :Dc] = 0  # ... and one with only its first head there (heads share a column tile when Dc divides 128)
     norm = xp.view(N, H, Dc).norm(dim=-1).contiguous()
     g_loss = torch.tensor([0.7], device=dev)
     g_q = ops.linear_bwd_data(g, w_out)
