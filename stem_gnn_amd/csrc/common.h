@@ -151,6 +151,28 @@ int linear_ws_launch(const float* x, const float* w, const float* bias, int64_t 
                      float* stats_partial, int64_t row_base, int64_t stats_block0, int64_t store_rows, bool bt,
                      hipStream_t st);
 
+// csrc/linear.hip: weight gradients  dw = dy^T x  (+ db = column sums of dy), several per launch.  add() queues a
+// product (its slabs live in the caller's workspace, stemgnn_linear_bwd_weight_workspace_bytes(M, N, K), until the
+// flush); flush() runs ONE split-product launch per element kind over all queued products and ONE fixed-order
+// reduction of all slab families.  dy / x must stay valid and unchanged until flush().  A phase queues its layers'
+// gradients as their inputs become available and flushes once: fewer, fuller launches (the products of the rows that
+// carry an aggregate, and of the seed rows, are a fraction of a launch on their own).
+struct DwBatch {
+  static constexpr int kMax = 8;
+  struct Job {
+    const float* dy;
+    const void* x;
+    float *pw, *pb, *dw, *db;
+    int64_t M, N, K, rows;
+    int splits, kind;
+  };
+  Job jobs[kMax];
+  int count = 0;
+  int add(const float* dy, const void* x, int x_kind, int64_t M, int64_t N, int64_t K, float* dw, float* db,
+          void* workspace, size_t workspace_bytes, hipStream_t st);
+  int flush(hipStream_t st);
+};
+
 // csrc/linear.hip: row-split count of a weight-gradient product and the fixed-order reduction of its partial slabs
 // (out[i] = sum_s partial[s][i]; the second family, e.g. the bias gradient, is optional), shared with csrc/pgemm.hip
 int plane_split_count(int64_t M, int64_t out_tiles);

@@ -250,6 +250,13 @@ int stemgnn_heads_bwd(const stemgnn_heads_params* p, int64_t N, const float* q, 
 
   const bool fork = lanes_on();
   hipStream_t s1 = fork ? ln->side[0] : s0, s2 = fork ? ln->side[1] : s0;
+  // one stream: the four weight gradients run as one split-product launch and one reduction at the end (DwBatch)
+  DwBatch dws;
+  auto weight_grad = [&](const float* dy, const float* x, int64_t M, int64_t N_, int64_t K_, float* dw, float* db, void* ws,
+                         size_t wb, hipStream_t st) -> int {
+    if (fork) return stemgnn_linear_bwd_weight(dy, x, M, N_, K_, dw, db, ws, wb, st);
+    return dws.add(dy, x, kF32, M, N_, K_, dw, db, ws, wb, st);
+  };
   if (fork) {
     STEMGNN_HIP_TRY(hipEventRecord(ln->fork, s0));
     STEMGNN_HIP_TRY(hipStreamWaitEvent(s1, ln->fork, 0));
@@ -259,23 +266,23 @@ int stemgnn_heads_bwd(const stemgnn_heads_params* p, int64_t N, const float* q, 
   // ---- lane B: topo-sem head back to the gathered pairs
   STEMGNN_TRY(stemgnn_mse_loss_bwd(s.h_ts, s.target, k * D, 1.0f, g_losses + 2, g_hts, s1));
   STEMGNN_TRY(stemgnn_linear_bwd_data(g_hts, p->w_ts, k, D, 2 * D, g_zz, s1));
-  STEMGNN_TRY(stemgnn_linear_bwd_weight(g_hts, s.zz, k, D, 2 * D, p->g_w_ts, p->b_ts ? p->g_b_ts : nullptr, ws_ts, wb_ts, s1));
+  STEMGNN_TRY(weight_grad(g_hts, s.zz, k, D, 2 * D, p->g_w_ts, p->b_ts ? p->g_b_ts : nullptr, ws_ts, wb_ts, s1));
   if (fork) STEMGNN_HIP_TRY(hipEventRecord(ln->done[0], s1));
 
   // ---- lane C: the two seed-row heads
   STEMGNN_TRY(stemgnn_mse_loss_bwd(s.h_f, x_feat, bs * I, 1.0f, g_losses + 0, g_hf, s2));
   STEMGNN_TRY(stemgnn_linear_bwd_data(g_hf, p->w_feat, bs, I, D, g_head_f, s2));
-  STEMGNN_TRY(stemgnn_linear_bwd_weight(g_hf, q, bs, I, D, p->g_w_feat, p->b_feat ? p->g_b_feat : nullptr, ws_f, wb_f, s2));
+  STEMGNN_TRY(weight_grad(g_hf, q, bs, I, D, p->g_w_feat, p->b_feat ? p->g_b_feat : nullptr, ws_f, wb_f, s2));
   STEMGNN_TRY(stemgnn_cosine_loss_bwd(z_teacher, s.h_s, bs, D, 1.0f, g_losses + 3, s.cos_save, g_hs, s2));
   STEMGNN_TRY(stemgnn_linear_bwd_data(g_hs, p->w_sem, bs, D, D, g_head_s, s2));
-  STEMGNN_TRY(stemgnn_linear_bwd_weight(g_hs, q, bs, D, D, p->g_w_sem, p->b_sem ? p->g_b_sem : nullptr, ws_s, wb_s, s2));
+  STEMGNN_TRY(weight_grad(g_hs, q, bs, D, D, p->g_w_sem, p->b_sem ? p->g_b_sem : nullptr, ws_s, wb_s, s2));
   if (fork) STEMGNN_HIP_TRY(hipEventRecord(ln->done[1], s2));
 
   // ---- lane A: topology head; its backward-data product lays down the dense gradient the other lanes add into
   STEMGNN_TRY(zero_bytes(g_zl, static_cast<size_t>(N) * D * 4, s0));
   STEMGNN_TRY(stemgnn_edge_dot_bwd_scaled(s.coef, g_losses + 1, s.zl, N, D, topo_edges, 2 * k, g_zl, s0));
   STEMGNN_TRY(stemgnn_linear_bwd_data(g_zl, p->w_topo, N, D, D, g_q, s0));
-  STEMGNN_TRY(stemgnn_linear_bwd_weight(g_zl, q, N, D, D, p->g_w_topo, p->b_topo ? p->g_b_topo : nullptr, ws_t, wb_t, s0));
+  STEMGNN_TRY(weight_grad(g_zl, q, N, D, D, p->g_w_topo, p->b_topo ? p->g_b_topo : nullptr, ws_t, wb_t, s0));
   if (fork) STEMGNN_HIP_TRY(hipStreamWaitEvent(s0, ln->done[0], 0));
   STEMGNN_TRY(stemgnn_edge_concat_bwd(g_zz, N, D, ts_edges, k, g_q, s0));
   if (fork) STEMGNN_HIP_TRY(hipStreamWaitEvent(s0, ln->done[1], 0));
@@ -286,7 +293,7 @@ int stemgnn_heads_bwd(const stemgnn_heads_params* p, int64_t N, const float* q, 
     k_add2<<<static_cast<unsigned>(grid), kBlock, 0, s0>>>(g_q, g_head_f, g_head_s, n4);
     STEMGNN_LAUNCH_CHECK();
   }
-  return STEMGNN_OK;
+  return dws.flush(s0);
 }
 
 }  // extern "C"

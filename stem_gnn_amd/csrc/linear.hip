@@ -542,24 +542,48 @@ k_linear_bwd_weight(const float* __restrict__ dy, const float* __restrict__ x, i
 // and a v_mfma_f32_32x32x16_bf16 lane wants 8 consecutive m: each thread stages a 4 (m) x 4 (n or k) micro-tile,
 // splits it and stores it transposed, so the LDS planes are [n][32 m] / [k][32 m] and the fragment reads are the
 // forward kernel's.  db comes from the staged registers (shuffle over the 8 lanes that share a column group).
+// One launch serves several products (a phase's weight gradients): a block finds its job in a table passed by value.
+constexpr int kDwJobs = 8;
+struct DwJob {
+  const float* dy;
+  const void* x;
+  float* pw;   // [S][N][K] slabs
+  float* pb;   // [S][N] or null
+  int64_t M, rows_per_split;
+  int N, K, splits, ktiles, block_end;  // blocks [block_end of the job before, block_end)
+};
+struct DwTable {
+  DwJob job[kDwJobs];
+  int count;
+};
+
 template <int XK>  // element kind of x (common.h: kF32 / kBF16), compile-time: a run-time kind cost the fp32 launch 18 %
 __global__ void __launch_bounds__(kBlock, 2)
-k_linear_bwd_weight_x3(const float* __restrict__ dy, const float* __restrict__ x, int64_t M, int N, int K,
-                       int64_t rows_per_split, float* __restrict__ partial_dw /*[S][N][K]*/,
-                       float* __restrict__ partial_db /*[S][N]*/) {
+k_linear_bwd_weight_x3(const DwTable tab) {
   constexpr int PL = kBN * kLdP;
   __shared__ __attribute__((aligned(16))) unsigned char sA[3 * PL];  // dY^T planes [128 n][32 m]
   __shared__ __attribute__((aligned(16))) unsigned char sB[3 * PL];  // X^T  planes [128 k][32 m]
 
+  int j = 0, begin = 0;
+  while (j + 1 < tab.count && static_cast<int>(blockIdx.x) >= tab.job[j].block_end) { begin = tab.job[j].block_end; ++j; }
+  const DwJob& jb = tab.job[j];
+  const float* __restrict__ dy = jb.dy;
+  const float* __restrict__ x = static_cast<const float*>(jb.x);
+  const int64_t M = jb.M, rows_per_split = jb.rows_per_split;
+  const int N = jb.N, K = jb.K;
+  float* __restrict__ partial_dw = jb.pw;
+  float* __restrict__ partial_db = jb.pb;
+  const int local = static_cast<int>(blockIdx.x) - begin;
+  const int split = local % jb.splits, tile = local / jb.splits;  // splits of one output tile are neighbours
+
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wi = wave >> 1, wj = wave & 1, hi = lane >> 5, lj = lane & 31;
-  const int split = blockIdx.x;
-  const int n0 = blockIdx.y * kBN, k0 = blockIdx.z * kBN;
+  const int n0 = (tile / jb.ktiles) * kBN, k0 = (tile % jb.ktiles) * kBN;
   const int64_t mbeg = split * rows_per_split;
   const int64_t mend = min(M, mbeg + rows_per_split);
   const int steps = static_cast<int>((mend - mbeg + kKC - 1) / kKC);
   const int mq = tid & 7, cq = tid >> 3;  // rows 4 mq .. 4 mq + 3 of the chunk, columns 4 cq .. 4 cq + 3 of the tile
-  const bool do_db = blockIdx.z == 0 && partial_db != nullptr;
+  const bool do_db = k0 == 0 && partial_db != nullptr;
 
   float4 ra[4];
   Raw4<XK> rb[4];  // widened at the stash: no conversion between the prefetch loads
@@ -839,6 +863,48 @@ k_reduce_splits(const float* __restrict__ partial, int splits, int64_t n, float*
   if (slice == 0 && i < n) st4(out + i, red[threadIdx.x]);
 }
 
+// The same reduction for several slab families in one launch (a phase's weight and bias gradients).
+constexpr int kReduceItems = 2 * kDwJobs;
+struct ReduceItem {
+  const float* partial;
+  float* out;
+  int64_t n;
+  int splits, block_end;
+};
+struct ReduceTable {
+  ReduceItem item[kReduceItems];
+  int count;
+};
+__global__ void __launch_bounds__(kBlock) k_reduce_many(const ReduceTable tab) {
+  __shared__ float4 red[kBlock];
+  const int col = threadIdx.x & 15, slice = threadIdx.x >> 4;
+  int j = 0, begin = 0;
+  while (j + 1 < tab.count && static_cast<int>(blockIdx.x) >= tab.item[j].block_end) { begin = tab.item[j].block_end; ++j; }
+  const float* __restrict__ partial = tab.item[j].partial;
+  const int64_t n = tab.item[j].n;
+  const int splits = tab.item[j].splits;
+  const int64_t i = (static_cast<int64_t>(static_cast<int>(blockIdx.x) - begin) * 16 + col) * 4;
+  float4 a = zero4();
+  if (i < n) {
+    for (int s = slice; s < splits; s += 16) {
+      const float4 v = ld4(partial + static_cast<int64_t>(s) * n + i);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+  }
+  red[threadIdx.x] = a;
+  __syncthreads();
+  for (int o = 8; o > 0; o >>= 1) {
+    if (slice < o) {
+      const float4 b = red[threadIdx.x + o * 16];
+      float4 c = red[threadIdx.x];
+      c.x += b.x; c.y += b.y; c.z += b.z; c.w += b.w;
+      red[threadIdx.x] = c;
+    }
+    __syncthreads();
+  }
+  if (slice == 0 && i < n) st4(tab.item[j].out + i, red[threadIdx.x]);
+}
+
 // out[c][r] = in[r][c] for small weight matrices (backward-X uses the forward kernel on W^T).
 __global__ void __launch_bounds__(kBlock)
 k_transpose(const float* __restrict__ in, int R, int C, float* __restrict__ out) {
@@ -957,6 +1023,88 @@ inline int64_t out_tiles(int64_t N, int64_t K) { return ((N + kBN - 1) / kBN) * 
 
 namespace stemgnn {
 int plane_split_count(int64_t M, int64_t tiles) { return pick_splits(M, tiles); }
+
+int DwBatch::add(const float* dy, const void* x, int x_kind, int64_t M, int64_t N, int64_t K, float* dw, float* db,
+                 void* workspace, size_t workspace_bytes, hipStream_t st) {
+  if (x_kind != kF32 && x_kind != kBF16) return STEMGNN_ERR_INVALID_ARG;
+  if (x_kind == kBF16 && !gemm_x3()) return STEMGNN_ERR_INVALID_ARG;  // the fp32-MFMA cross-check twins read fp32 only
+  if (!lin_dims_ok(M, N, K) || N % 4 != 0 || !dw) return STEMGNN_ERR_INVALID_ARG;
+  if (!fits_i32(M)) return STEMGNN_ERR_TOO_LARGE;
+  if (M == 0) {
+    STEMGNN_HIP_TRY(hipMemsetAsync(dw, 0, sizeof(float) * N * K, st));
+    if (db) STEMGNN_HIP_TRY(hipMemsetAsync(db, 0, sizeof(float) * N, st));
+    return STEMGNN_OK;
+  }
+  if (!dy || !x || !workspace) return STEMGNN_ERR_INVALID_ARG;
+  if (workspace_bytes < stemgnn_linear_bwd_weight_workspace_bytes(M, N, K)) return STEMGNN_ERR_WORKSPACE;
+  if (count == kMax) {
+    const int rc = flush(st);
+    if (rc != STEMGNN_OK) return rc;
+  }
+  Job& j = jobs[count++];
+  j.splits = pick_splits(M, out_tiles(N, K));
+  j.rows = (M + j.splits - 1) / j.splits;
+  j.rows = (j.rows + kKC - 1) / kKC * kKC;
+  j.dy = dy; j.x = x; j.kind = x_kind; j.M = M; j.N = N; j.K = K; j.dw = dw; j.db = db;
+  j.pw = reinterpret_cast<float*>(align_up(reinterpret_cast<uintptr_t>(workspace), 256));
+  j.pb = j.pw + static_cast<size_t>(j.splits) * N * K;
+  return STEMGNN_OK;
+}
+
+int DwBatch::flush(hipStream_t st) {
+  if (count == 0) return STEMGNN_OK;
+  if (gemm_x3()) {
+    for (int kind = kF32; kind <= kBF16; ++kind) {
+      DwTable tab;
+      tab.count = 0;
+      int blocks = 0;
+      for (int i = 0; i < count; ++i) {
+        const Job& j = jobs[i];
+        if (j.kind != kind) continue;
+        DwJob& t = tab.job[tab.count++];
+        t.dy = j.dy; t.x = j.x; t.pw = j.pw; t.pb = j.db ? j.pb : nullptr;
+        t.M = j.M; t.rows_per_split = j.rows;
+        t.N = static_cast<int>(j.N); t.K = static_cast<int>(j.K); t.splits = j.splits;
+        t.ktiles = static_cast<int>((j.K + kBN - 1) / kBN);
+        blocks += j.splits * static_cast<int>(out_tiles(j.N, j.K));
+        t.block_end = blocks;
+      }
+      if (tab.count == 0) continue;
+      if (kind == kBF16) k_linear_bwd_weight_x3<kBF16><<<static_cast<unsigned>(blocks), kBlock, 0, st>>>(tab);
+      else k_linear_bwd_weight_x3<kF32><<<static_cast<unsigned>(blocks), kBlock, 0, st>>>(tab);
+      STEMGNN_LAUNCH_CHECK();
+    }
+  } else {
+    for (int i = 0; i < count; ++i) {
+      const Job& j = jobs[i];
+      dim3 grid(static_cast<unsigned>(j.splits), static_cast<unsigned>((j.N + kBN - 1) / kBN),
+                static_cast<unsigned>((j.K + kBN - 1) / kBN));
+      k_linear_bwd_weight<<<grid, kBlock, 0, st>>>(j.dy, static_cast<const float*>(j.x), j.M, static_cast<int>(j.N),
+                                                   static_cast<int>(j.K), j.rows, j.pw, j.db ? j.pb : nullptr);
+      STEMGNN_LAUNCH_CHECK();
+    }
+  }
+  ReduceTable red;
+  red.count = 0;
+  int blocks = 0;
+  for (int i = 0; i < count; ++i) {
+    const Job& j = jobs[i];
+    ReduceItem& a = red.item[red.count++];
+    a.partial = j.pw; a.out = j.dw; a.n = j.N * j.K; a.splits = j.splits;
+    blocks += static_cast<int>((a.n / 4 + 15) / 16);
+    a.block_end = blocks;
+    if (j.db) {
+      ReduceItem& b = red.item[red.count++];
+      b.partial = j.pb; b.out = j.db; b.n = j.N; b.splits = j.splits;
+      blocks += static_cast<int>((b.n / 4 + 15) / 16);
+      b.block_end = blocks;
+    }
+  }
+  k_reduce_many<<<static_cast<unsigned>(blocks), kBlock, 0, st>>>(red);
+  STEMGNN_LAUNCH_CHECK();
+  count = 0;
+  return STEMGNN_OK;
+}
 int reduce_splits_launch(const float* partial, int splits, int64_t n, float* out, const float* partial2, int64_t n2,
                          float* out2, hipStream_t st) {
   const int blocks1 = static_cast<int>((n / 4 + 15) / 16);
@@ -1130,41 +1278,10 @@ int stemgnn_linear_bwd_weight(const float* dy, const float* x, int64_t M, int64_
 int stemgnn_linear_bwd_weight_k(const float* dy, const void* x_, int32_t x_kind, int64_t M, int64_t N, int64_t K, float* dw,
                                 float* db, void* workspace, size_t workspace_bytes, void* stream_) {
   hipStream_t st = static_cast<hipStream_t>(stream_);
-  const float* x = static_cast<const float*>(x_);
-  if (x_kind != kF32 && x_kind != kBF16) return STEMGNN_ERR_INVALID_ARG;
-  if (x_kind == kBF16 && !gemm_x3()) return STEMGNN_ERR_INVALID_ARG;  // the fp32-MFMA cross-check twins read fp32 only
-  if (!lin_dims_ok(M, N, K) || N % 4 != 0 || !dw) return STEMGNN_ERR_INVALID_ARG;
-  if (!fits_i32(M)) return STEMGNN_ERR_TOO_LARGE;
-  if (M == 0) {
-    STEMGNN_HIP_TRY(hipMemsetAsync(dw, 0, sizeof(float) * N * K, st));
-    if (db) STEMGNN_HIP_TRY(hipMemsetAsync(db, 0, sizeof(float) * N, st));
-    return STEMGNN_OK;
-  }
-  if (!dy || !x || !workspace) return STEMGNN_ERR_INVALID_ARG;
-  if (workspace_bytes < stemgnn_linear_bwd_weight_workspace_bytes(M, N, K)) return STEMGNN_ERR_WORKSPACE;
-  const int S = pick_splits(M, out_tiles(N, K));
-  int64_t rows = (M + S - 1) / S;
-  rows = (rows + kKC - 1) / kKC * kKC;
-  float* pw = reinterpret_cast<float*>(align_up(reinterpret_cast<uintptr_t>(workspace), 256));
-  float* pb = pw + static_cast<size_t>(S) * N * K;
-  dim3 grid(static_cast<unsigned>(S), static_cast<unsigned>((N + kBN - 1) / kBN), static_cast<unsigned>((K + kBN - 1) / kBN));
-  if (gemm_x3()) {
-    if (x_kind == kBF16)
-      k_linear_bwd_weight_x3<kBF16><<<grid, kBlock, 0, st>>>(dy, x, M, static_cast<int>(N), static_cast<int>(K), rows, pw,
-                                                             db ? pb : nullptr);
-    else
-      k_linear_bwd_weight_x3<kF32><<<grid, kBlock, 0, st>>>(dy, x, M, static_cast<int>(N), static_cast<int>(K), rows, pw,
-                                                            db ? pb : nullptr);
-  } else
-    k_linear_bwd_weight<<<grid, kBlock, 0, st>>>(dy, x, M, static_cast<int>(N), static_cast<int>(K), rows, pw,
-                                                 db ? pb : nullptr);
-  STEMGNN_LAUNCH_CHECK();
-  const int64_t nk = N * K;
-  const int blocks1 = static_cast<int>((nk / 4 + 15) / 16);
-  const int blocks2 = db ? static_cast<int>((N / 4 + 15) / 16) : 0;
-  k_reduce_splits<<<static_cast<unsigned>(blocks1 + blocks2), kBlock, 0, st>>>(pw, S, nk, dw, pb, N, db, blocks1);
-  STEMGNN_LAUNCH_CHECK();
-  return STEMGNN_OK;
+  DwBatch batch;
+  const int rc = batch.add(dy, x_, x_kind, M, N, K, dw, db, workspace, workspace_bytes, st);
+  if (rc != STEMGNN_OK) return rc;
+  return batch.flush(st);
 }
 
 size_t stemgnn_code_segment_sums_workspace_bytes(int64_t M, int64_t H, int64_t K, int64_t D) {

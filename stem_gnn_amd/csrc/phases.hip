@@ -213,11 +213,14 @@ size_t stemgnn_encoder_bwd_scratch_bytes(int64_t N, int64_t A, const stemgnn_sag
   for (int l = 0; l < cfg->num_layers; ++l) {
     wi = std::max(wi, layers[l].in_dim);
     wo = std::max(wo, layers[l].out_dim);
-    dw = std::max(dw, stemgnn_linear_bwd_weight_workspace_bytes(N, layers[l].out_dim, layers[l].in_dim));
+    // every layer's weight gradients keep their slabs until the one reduction at the end of the phase
+    dw += a256(stemgnn_linear_bwd_weight_workspace_bytes(N, layers[l].out_dim, layers[l].in_dim)) +
+          a256(stemgnn_linear_bwd_weight_workspace_bytes(std::max<int64_t>(A, 1), layers[l].out_dim, layers[l].in_dim));
   }
   const size_t n1 = static_cast<size_t>(std::max<int64_t>(N, 1)), a1 = static_cast<size_t>(std::max<int64_t>(A, 1));
-  return a256(n1 * wo * 4) + 2 * a256(n1 * wi * 4) + a256(a1 * wi * 4) + a256(dw) + a256(stemgnn_bn_workspace_bytes(N, wo)) +
-         1024;
+  // ... and every layer its own pre-activation gradient (an operand of those products)
+  return cfg->num_layers * a256(n1 * wo * 4) + 2 * a256(n1 * wi * 4) + a256(a1 * wi * 4) + dw +
+         a256(stemgnn_bn_workspace_bytes(N, wo)) + 1024;
 }
 
 int stemgnn_encoder_bwd(const stemgnn_graph_view* g, const void* x, const float* edge_attr, const float* etab,
@@ -239,19 +242,18 @@ int stemgnn_encoder_bwd(const stemgnn_graph_view* g, const void* x, const float*
   const int L = cfg->num_layers;
   const EncoderPlan p = plan_encoder(save, N, A, layers, cfg, nullptr);
   int64_t wi = 0, wo = 0;
-  size_t dwb = 0;
   for (int l = 0; l < L; ++l) {
     wi = std::max(wi, layers[l].in_dim);
     wo = std::max(wo, layers[l].out_dim);
-    dwb = std::max(dwb, stemgnn_linear_bwd_weight_workspace_bytes(N, layers[l].out_dim, layers[l].in_dim));
   }
   Carver c(scratch);
-  float* g_y_buf = c.take<float>(static_cast<size_t>(N) * wo);
   float* g_h_buf[2] = {c.take<float>(static_cast<size_t>(N) * wi), c.take<float>(static_cast<size_t>(N) * wi)};
   float* g_agg = c.take<float>(static_cast<size_t>(std::max<int64_t>(A, 1)) * wi);
-  void* dw_ws = c.take<unsigned char>(dwb);
   const size_t bn_ws_bytes = stemgnn_bn_workspace_bytes(N, wo);
   void* bn_ws = c.take<unsigned char>(bn_ws_bytes);
+  // The weight gradients of all layers run as ONE split-product launch and ONE reduction at the end of the phase
+  // (DwBatch, csrc/linear.hip): each keeps its operand g_y and its slabs until then.
+  DwBatch dws;
 
   const float* g_h = g_z;  // gradient w.r.t. the current layer's output
   for (int l = L - 1; l >= 0; --l) {
@@ -260,6 +262,11 @@ int stemgnn_encoder_bwd(const stemgnn_graph_view* g, const void* x, const float*
     const bool last = l == L - 1;
     const void* h_prev = l == 0 ? x : static_cast<const void*>(p.layers[l - 1].h);  // stored in the feature kind
     const float* g_y = g_h;
+    float* g_y_buf = c.take<float>(static_cast<size_t>(N) * wo);
+    const size_t dwb_r = stemgnn_linear_bwd_weight_workspace_bytes(N, y.out_dim, y.in_dim);
+    const size_t dwb_l = stemgnn_linear_bwd_weight_workspace_bytes(std::max<int64_t>(A, 1), y.out_dim, y.in_dim);
+    void* dw_ws_r = c.take<unsigned char>(dwb_r);
+    void* dw_ws_l = c.take<unsigned char>(dwb_l);
     if (!(last && p.tail_identity)) {
       const int act = last ? 0 : cfg->act;
       const float pdrop = last ? 0.f : cfg->dropout_p;
@@ -274,12 +281,12 @@ int stemgnn_encoder_bwd(const stemgnn_graph_view* g, const void* x, const float*
     // an aggregate
     if (y.g_w_r || y.g_b_l) {
       if (!y.g_w_r) return STEMGNN_ERR_INVALID_ARG;
-      STEMGNN_TRY(stemgnn_linear_bwd_weight_k(g_y, h_prev, cfg->feature_kind, N, y.out_dim, y.in_dim, y.g_w_r,
-                                              y.b_l ? y.g_b_l : nullptr, dw_ws, dwb, stream));
+      STEMGNN_TRY(dws.add(g_y, h_prev, cfg->feature_kind, N, y.out_dim, y.in_dim, y.g_w_r, y.b_l ? y.g_b_l : nullptr,
+                          dw_ws_r, dwb_r, st));
     }
     if (y.g_w_l) {
       if (A > 0) {
-        STEMGNN_TRY(stemgnn_linear_bwd_weight(g_y, s.agg, A, y.out_dim, y.in_dim, y.g_w_l, nullptr, dw_ws, dwb, stream));
+        STEMGNN_TRY(dws.add(g_y, s.agg, kF32, A, y.out_dim, y.in_dim, y.g_w_l, nullptr, dw_ws_l, dwb_l, st));
       } else {
         STEMGNN_HIP_TRY(hipMemsetAsync(y.g_w_l, 0, sizeof(float) * y.out_dim * y.in_dim, st));
       }
@@ -295,7 +302,7 @@ int stemgnn_encoder_bwd(const stemgnn_graph_view* g, const void* x, const float*
     }
     g_h = g_prev;
   }
-  return STEMGNN_OK;
+  return dws.flush(st);
 }
 
 size_t stemgnn_vq_save_bytes(const stemgnn_vq_params* p, int64_t N) {

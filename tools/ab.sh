@@ -2,12 +2,10 @@
 # Same-box A/B: the working tree against a checkout of HEAD built under _ab/ (git-ignored).
 set -e
 mkdir -p gpurun_out
-for i in 1 2; do
+for i in 1 2 3; do
   (cd _ab && python bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-extra --e2e-steps 0 2>/dev/null) > gpurun_out/ab_head_$i.json
   python bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-extra --e2e-steps 0 2>/dev/null > gpurun_out/ab_tree_$i.json
 done
-python bench.py --workload c5 --feature-dtype bf16 --steps 20 --warmup 5 --no-cpu-baseline --no-extra --e2e-steps 0 2>/dev/null > gpurun_out/ab_c5_bf16.json
-python bench.py --workload c5 --feature-dtype f32 --steps 20 --warmup 5 --no-cpu-baseline --no-extra --e2e-steps 0 2>/dev/null > gpurun_out/ab_c5_f32.json
 python - <<'PY'
 import json,glob
 for f in sorted(glob.glob('gpurun_out/ab_*.json')):
