@@ -292,6 +292,14 @@ int stemgnn_linear_set_mode(int mode);
  * sampled batch, whose edges all end in the leading, expanded nodes; x1 may be a [x1_rows, K1] buffer): row tiles
  * past them skip the x1 half of the contraction.  Pass -1 (or M) when x1 has M meaningful rows. */
 size_t stemgnn_linear_stats_partial_bytes(int64_t num_rows, int64_t out_dim);
+/* y[M, N] = x[M, K] w^T + bias (w [N, K]), or y = x w with w given as [K, N] (weight_is_kn != 0: the backward-data
+ * form dx = dy w), for products over FEW rows (M <= 65536, N % 32 == 0, K % 16 == 0; exact-bf16 mode only): one wave
+ * per 32 x 32 output tile, operands read straight from global memory (csrc/wsgemm.hip).  Same bits as
+ * stemgnn_linear_fwd / stemgnn_linear_bwd_data.  The heads phase runs its three seed-row / sampled-pair products as
+ * one such launch. */
+int stemgnn_linear_few_rows(const float* x, const float* w, const float* bias, int64_t num_rows, int64_t out_dim,
+                            int64_t in_dim, float* y, int32_t weight_is_kn, void* stream);
+
 /* The weight-stationary kernel (csrc/wsgemm.hip) takes the products with one 128-column operand and at least
  * `min_tiles` 128-row tiles (default 128; 0 = never: every product on the tile kernel).  Negative: query only.
  * Returns the previous value.  Both kernels return the same bits; the switch exists for A/B runs and tests. */

@@ -143,6 +143,7 @@ _SIGNATURES = {
     "stemgnn_linear_stats_partial_bytes": (c_size_t, [I64, I64]),
     "stemgnn_linear_stats_blocks": (I64, [I64, I64]),
     "stemgnn_linear_set_ws": (I32, [I32]),
+    "stemgnn_linear_few_rows": (c_int, [P, P, P, I64, I64, I64, P, I32, P]),
     "stemgnn_clip_grad_max_tensors": (I32, []),
     "stemgnn_clip_grad_workspace_bytes": (c_size_t, [I64, I32]),
     "stemgnn_clip_grad_norm": (c_int, [P, P, I32, c_float, P, P, c_size_t, P]),

@@ -151,6 +151,24 @@ int linear_ws_launch(const float* x, const float* w, const float* bias, int64_t 
                      float* stats_partial, int64_t row_base, int64_t stats_block0, int64_t store_rows, bool bt,
                      hipStream_t st);
 
+// csrc/wsgemm.hip: products over few rows ( y = x w^T + b, or y = x w with w given as [K][N] ), several per launch; one
+// wave per 32 x 32 output tile, operands straight from global memory.  Same bits as the tile kernel.
+bool linear_direct_ok(int64_t M, int64_t N, int64_t K);
+struct DirectBatch {
+  static constexpr int kMax = 4;
+  struct Job {
+    const float *x, *w, *bias;
+    float* y;
+    int64_t M, N, K;
+    int bt;
+  };
+  Job jobs[kMax];
+  int count = 0;
+  int add(const float* x, const float* w, const float* bias, int64_t M, int64_t N, int64_t K, float* y, bool bt,
+          hipStream_t st);
+  int flush(hipStream_t st);
+};
+
 // csrc/linear.hip: weight gradients  dw = dy^T x  (+ db = column sums of dy), several per launch.  add() queues a
 // product (its slabs live in the caller's workspace, stemgnn_linear_bwd_weight_workspace_bytes(M, N, K), until the
 // flush); flush() runs ONE split-product launch per element kind over all queued products and ONE fixed-order

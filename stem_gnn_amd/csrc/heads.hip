@@ -183,20 +183,35 @@ int stemgnn_heads_fwd(const stemgnn_heads_params* p, const stemgnn_graph_view* g
   STEMGNN_TRY(stemgnn_edge_dot_fwd(s.zl, N, D, topo_edges, 2 * k, s.dots, s0));
   STEMGNN_TRY(stemgnn_edge_bce_loss(s.dots, k, k, losses + 1, s.coef, s0));
 
+  // The three products over few rows (sampled pairs, seed rows) share one launch when everything runs on one
+  // stream (DirectBatch, csrc/wsgemm.hip): on their own they are 8 - 90 tiles on 256 CUs, 12 - 20 us each.
+  const bool direct = !fork && stemgnn_linear_set_mode(-1) == 1 && linear_direct_ok(k, D, 2 * D) &&
+                      linear_direct_ok(bs, p->in_dim, D) && linear_direct_ok(bs, D, D);
+  DirectBatch small;
+
   // ---- lane B: topo-sem head.  10 % of the edges, their endpoints and types in one launch; the target rows are the
   // type table's; cat(q_u, q_v) -> Linear -> mse (pt_model.py:72-81)
   STEMGNN_TRY(stemgnn_sample_edges(edge_index, edge_type, E, k, seed, off_ts, ts_perm, ts_edges, k, ts_type, nullptr, s1));
   STEMGNN_TRY(stemgnn_gather_rows(etab, T, D, ts_type, k, s.target, s1));
   STEMGNN_TRY(stemgnn_edge_concat_fwd(q, N, D, ts_edges, k, s.zz, s1));
-  STEMGNN_TRY(stemgnn_linear_fwd(s.zz, p->w_ts, 2 * D, nullptr, nullptr, 0, p->b_ts, k, D, s.h_ts, nullptr, nullptr, -1, s1));
+  if (direct) {
+    STEMGNN_TRY(small.add(s.zz, p->w_ts, p->b_ts, k, D, 2 * D, s.h_ts, false, s0));
+    STEMGNN_TRY(small.add(q, p->w_feat, p->b_feat, bs, p->in_dim, D, s.h_f, false, s0));
+    STEMGNN_TRY(small.add(q, p->w_sem, p->b_sem, bs, D, D, s.h_s, false, s0));
+    STEMGNN_TRY(small.flush(s0));
+  } else {
+    STEMGNN_TRY(stemgnn_linear_fwd(s.zz, p->w_ts, 2 * D, nullptr, nullptr, 0, p->b_ts, k, D, s.h_ts, nullptr, nullptr, -1, s1));
+  }
   STEMGNN_TRY(stemgnn_mse_loss_fwd(s.h_ts, s.target, k * D, 1.0f, losses + 2, s.ws[0], s.ws_bytes, s1));
   if (fork) STEMGNN_HIP_TRY(hipEventRecord(ln->done[0], s1));
 
   // ---- lane C: the two heads on the seed rows q[:bs] (pt_model.py:42-43, 93-100)
-  STEMGNN_TRY(stemgnn_linear_fwd(q, p->w_feat, D, nullptr, nullptr, 0, p->b_feat, bs, p->in_dim, s.h_f, nullptr, nullptr,
-                                 -1, s2));
+  if (!direct)
+    STEMGNN_TRY(stemgnn_linear_fwd(q, p->w_feat, D, nullptr, nullptr, 0, p->b_feat, bs, p->in_dim, s.h_f, nullptr, nullptr,
+                                   -1, s2));
   STEMGNN_TRY(stemgnn_mse_loss_fwd(s.h_f, x_feat, bs * p->in_dim, 1.0f, losses + 0, s.ws[1], s.ws_bytes, s2));
-  STEMGNN_TRY(stemgnn_linear_fwd(q, p->w_sem, D, nullptr, nullptr, 0, p->b_sem, bs, D, s.h_s, nullptr, nullptr, -1, s2));
+  if (!direct)
+    STEMGNN_TRY(stemgnn_linear_fwd(q, p->w_sem, D, nullptr, nullptr, 0, p->b_sem, bs, D, s.h_s, nullptr, nullptr, -1, s2));
   STEMGNN_TRY(stemgnn_cosine_loss_fwd(z_teacher, s.h_s, bs, D, 1.0f, losses + 3, s.cos_save, s.ws[2], s.ws_bytes, s2));
   if (fork) {
     STEMGNN_HIP_TRY(hipEventRecord(ln->done[1], s2));
@@ -263,20 +278,31 @@ int stemgnn_heads_bwd(const stemgnn_heads_params* p, int64_t N, const float* q, 
     STEMGNN_HIP_TRY(hipStreamWaitEvent(s2, ln->fork, 0));
   }
 
+  const bool direct = !fork && stemgnn_linear_set_mode(-1) == 1 && linear_direct_ok(k, 2 * D, D) &&
+                      linear_direct_ok(bs, D, I) && linear_direct_ok(bs, D, D);
+  DirectBatch small;  // the three backward-data products over few rows, one launch (see stemgnn_heads_fwd)
+
   // ---- lane B: topo-sem head back to the gathered pairs
   STEMGNN_TRY(stemgnn_mse_loss_bwd(s.h_ts, s.target, k * D, 1.0f, g_losses + 2, g_hts, s1));
-  STEMGNN_TRY(stemgnn_linear_bwd_data(g_hts, p->w_ts, k, D, 2 * D, g_zz, s1));
+  if (!direct) STEMGNN_TRY(stemgnn_linear_bwd_data(g_hts, p->w_ts, k, D, 2 * D, g_zz, s1));
   STEMGNN_TRY(weight_grad(g_hts, s.zz, k, D, 2 * D, p->g_w_ts, p->b_ts ? p->g_b_ts : nullptr, ws_ts, wb_ts, s1));
   if (fork) STEMGNN_HIP_TRY(hipEventRecord(ln->done[0], s1));
 
   // ---- lane C: the two seed-row heads
   STEMGNN_TRY(stemgnn_mse_loss_bwd(s.h_f, x_feat, bs * I, 1.0f, g_losses + 0, g_hf, s2));
-  STEMGNN_TRY(stemgnn_linear_bwd_data(g_hf, p->w_feat, bs, I, D, g_head_f, s2));
+  if (!direct) STEMGNN_TRY(stemgnn_linear_bwd_data(g_hf, p->w_feat, bs, I, D, g_head_f, s2));
   STEMGNN_TRY(weight_grad(g_hf, q, bs, I, D, p->g_w_feat, p->b_feat ? p->g_b_feat : nullptr, ws_f, wb_f, s2));
   STEMGNN_TRY(stemgnn_cosine_loss_bwd(z_teacher, s.h_s, bs, D, 1.0f, g_losses + 3, s.cos_save, g_hs, s2));
-  STEMGNN_TRY(stemgnn_linear_bwd_data(g_hs, p->w_sem, bs, D, D, g_head_s, s2));
+  if (!direct) STEMGNN_TRY(stemgnn_linear_bwd_data(g_hs, p->w_sem, bs, D, D, g_head_s, s2));
   STEMGNN_TRY(weight_grad(g_hs, q, bs, D, D, p->g_w_sem, p->b_sem ? p->g_b_sem : nullptr, ws_s, wb_s, s2));
   if (fork) STEMGNN_HIP_TRY(hipEventRecord(ln->done[1], s2));
+  if (direct) {
+    // dx[M, K] = dy[M, N] w[N, K]: the weight as stored is the [contraction][output] layout
+    STEMGNN_TRY(small.add(g_hts, p->w_ts, nullptr, k, 2 * D, D, g_zz, true, s0));
+    STEMGNN_TRY(small.add(g_hf, p->w_feat, nullptr, bs, D, I, g_head_f, true, s0));
+    STEMGNN_TRY(small.add(g_hs, p->w_sem, nullptr, bs, D, D, g_head_s, true, s0));
+    STEMGNN_TRY(small.flush(s0));
+  }
 
   // ---- lane A: topology head; its backward-data product lays down the dense gradient the other lanes add into
   STEMGNN_TRY(zero_bytes(g_zl, static_cast<size_t>(N) * D * 4, s0));

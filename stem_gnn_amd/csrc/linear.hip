@@ -1120,6 +1120,17 @@ using namespace stemgnn;
 
 extern "C" {
 
+int stemgnn_linear_few_rows(const float* x, const float* w, const float* bias, int64_t M, int64_t N, int64_t K, float* y,
+                            int32_t weight_is_kn, void* stream_) {
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  if (M == 0) return STEMGNN_OK;
+  if (!gemm_x3() || !linear_direct_ok(M, N, K)) return STEMGNN_ERR_INVALID_ARG;
+  DirectBatch b;
+  const int rc = b.add(x, w, bias, M, N, K, y, weight_is_kn != 0, st);
+  if (rc != STEMGNN_OK) return rc;
+  return b.flush(st);
+}
+
 int stemgnn_linear_set_ws(int min_tiles) {
   const int prev = static_cast<int>(ws_min_tiles());
   if (min_tiles >= 0) g_ws_min_tiles.store(min_tiles, std::memory_order_relaxed);

@@ -282,3 +282,129 @@ int linear_ws_launch(const float* x, const float* w, const float* bias, int64_t 
 }
 
 }  // namespace stemgnn
+
+// ---------------------------------------------------------------------------------------------------------------
+// Products over FEW rows (the seed-row and sampled-pair heads of the pretraining step: 1 k - 10 k rows): a 128-row
+// tile kernel puts 8 blocks on 256 CUs and each walks its four k-chunks one memory latency after the other (12 us
+// for 8 tiles).  Here a WAVE owns a 32 x 32 output tile, reads its operand fragments straight from global memory --
+// all 32 loads of a 128-wide k block in flight at once, no LDS, no barrier -- cuts them in registers and multiplies;
+// several products (a table passed by value) share one launch.  Same k-step order and arithmetic as the tile kernel:
+// the same bits.
+// ---------------------------------------------------------------------------------------------------------------
+namespace stemgnn {
+namespace {
+
+constexpr int kDirectJobs = 4;
+struct DirectJob {
+  const float* x;     // [M][K]
+  const float* w;     // [N][K], or [K][N] when bt
+  const float* bias;  // [N] or null
+  float* y;           // [M][N]
+  int64_t M;
+  int N, K, wave_end;  // waves [wave_end of the job before, wave_end): one per 32 x 32 output tile
+};
+struct DirectTable {
+  DirectJob job[kDirectJobs];
+  int count;
+};
+
+template <bool BT>  // every job of a launch has its weight in the same layout ([K][N] when BT)
+__global__ void __launch_bounds__(256) k_linear_direct(const DirectTable tab) {
+  const int lane = threadIdx.x & 63, hi = lane >> 5, lj = lane & 31;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  int j = 0, begin = 0;
+  while (j + 1 < tab.count && wave >= tab.job[j].wave_end) { begin = tab.job[j].wave_end; ++j; }
+  const DirectJob& jb = tab.job[j];
+  if (wave >= jb.wave_end) return;  // the last block's spare waves
+  const int groups = jb.N / 32, local = wave - begin;
+  const int64_t m0 = static_cast<int64_t>(local / groups) * 32;
+  const int n0 = (local % groups) * 32;
+  const int K = jb.K, N = jb.N;
+  const int64_t M = jb.M;
+  const int64_t mr = m0 + lj < M ? m0 + lj : M - 1;  // a row past M repeats the last one; it is never stored
+  const float* __restrict__ xr = jb.x + mr * K + 8 * hi;
+  const float* __restrict__ wr = BT ? jb.w + static_cast<int64_t>(8 * hi) * N + n0 + lj
+                                    : jb.w + static_cast<int64_t>(n0 + lj) * K + 8 * hi;
+  floatx16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int kb = 0; kb < K; kb += 128) {
+    float4 xa[8][2], wb[8][2];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const int k = kb + 16 * ks < K ? kb + 16 * ks : kb;  // a short last block re-reads its first step (skipped below)
+      xa[ks][0] = ld4(xr + k);
+      xa[ks][1] = ld4(xr + k + 4);
+      if (BT) {
+        const float* p = wr + static_cast<int64_t>(k) * N;
+        const int64_t ld = N;
+        wb[ks][0] = make_float4(p[0], p[ld], p[2 * ld], p[3 * ld]);
+        wb[ks][1] = make_float4(p[4 * ld], p[5 * ld], p[6 * ld], p[7 * ld]);
+      } else {
+        wb[ks][0] = ld4(wr + k);
+        wb[ks][1] = ld4(wr + k + 4);
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      if (kb + 16 * ks >= K) break;
+      uint4 h, m, l;
+      bf16x8 a[3], b[3];
+      split8(xa[ks][0], xa[ks][1], h, m, l);
+      a[0] = as_bf16x8(h); a[1] = as_bf16x8(m); a[2] = as_bf16x8(l);
+      split8(wb[ks][0], wb[ks][1], h, m, l);
+      b[0] = as_bf16x8(h); b[1] = as_bf16x8(m); b[2] = as_bf16x8(l);
+      acc = mfma_x3(a, b, acc);
+    }
+  }
+  const float bv = jb.bias ? jb.bias[n0 + lj] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int64_t m = m0 + 4 * hi + (r & 3) + 8 * (r >> 2);
+    if (m < M) jb.y[m * N + n0 + lj] = acc[r] + bv;
+  }
+}
+
+}  // namespace
+
+bool linear_direct_ok(int64_t M, int64_t N, int64_t K) {
+  return M > 0 && M <= (1 << 16) && N > 0 && N % 32 == 0 && K > 0 && K % 16 == 0 && N <= 4096 && K <= 4096;
+}
+
+int DirectBatch::add(const float* x, const float* w, const float* bias, int64_t M, int64_t N, int64_t K, float* y, bool bt,
+                     hipStream_t st) {
+  if (!linear_direct_ok(M, N, K) || !x || !w || !y) return STEMGNN_ERR_INVALID_ARG;
+  if (count == kMax) {
+    const int rc = flush(st);
+    if (rc != STEMGNN_OK) return rc;
+  }
+  Job& j = jobs[count++];
+  j.x = x; j.w = w; j.bias = bias; j.y = y; j.M = M; j.N = N; j.K = K; j.bt = bt ? 1 : 0;
+  return STEMGNN_OK;
+}
+
+int DirectBatch::flush(hipStream_t st) {
+  if (count == 0) return STEMGNN_OK;
+  for (int bt = 0; bt < 2; ++bt) {
+    DirectTable tab;
+    tab.count = 0;
+    int waves = 0;
+    for (int i = 0; i < count; ++i) {
+      const Job& j = jobs[i];
+      if (j.bt != bt) continue;
+      DirectJob& t = tab.job[tab.count++];
+      t.x = j.x; t.w = j.w; t.bias = j.bias; t.y = j.y; t.M = j.M;
+      t.N = static_cast<int>(j.N); t.K = static_cast<int>(j.K);
+      waves += static_cast<int>((j.M + 31) / 32) * static_cast<int>(j.N / 32);
+      t.wave_end = waves;
+    }
+    if (tab.count == 0) continue;
+    if (bt) k_linear_direct<true><<<static_cast<unsigned>((waves + 3) / 4), 256, 0, st>>>(tab);
+    else k_linear_direct<false><<<static_cast<unsigned>((waves + 3) / 4), 256, 0, st>>>(tab);
+    STEMGNN_LAUNCH_CHECK();
+  }
+  count = 0;
+  return STEMGNN_OK;
+}
+
+}  // namespace stemgnn

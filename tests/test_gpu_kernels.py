@@ -867,6 +867,34 @@ def test_weight_stationary_product_returns_the_tile_kernels_bits(dev, m, k2, n, 
         assert torch.equal(d1, d0)
 
 
+@pytest.mark.parametrize("m,n,k", [(1024, 128, 128), (11000, 128, 256), (33, 96, 48), (1, 32, 16), (5000, 256, 128)])
+def test_few_row_product_returns_the_tile_kernels_bits(dev, m, n, k):
+    """stemgnn_linear_few_rows (one wave per 32 x 32 tile, operands straight from global memory) against the tile
+    kernel and torch: forward with bias, and the backward-data form through the weight as stored."""
+    from stem_gnn_amd import ops
+    from stem_gnn_amd._lib import lib, check
+    torch.manual_seed(m + n + k)
+    st = torch.cuda.current_stream().cuda_stream
+    x = torch.randn(m, k, device=dev) * (1 + 3 * torch.rand(m, 1, device=dev))
+    w = torch.randn(n, k, device=dev) * 0.2
+    b = torch.randn(n, device=dev)
+    prev = lib.stemgnn_linear_set_ws(0)
+    try:
+        y0 = ops.linear_fwd(x, w, None, None, b, False)[0]
+        dy = torch.randn(m, n, device=dev)
+        d0 = ops.linear_bwd_data(dy, w)
+    finally:
+        lib.stemgnn_linear_set_ws(prev)
+    y1 = torch.full((m, n), 7.0, device=dev)
+    check(lib.stemgnn_linear_few_rows(x.data_ptr(), w.data_ptr(), b.data_ptr(), m, n, k, y1.data_ptr(), 0, st))
+    assert torch.equal(y1, y0)
+    torch.testing.assert_close(y1, x @ w.t() + b, rtol=1e-4, atol=1e-3)
+    if k % 32 == 0 and n % 16 == 0:
+        d1 = torch.full((m, k), 7.0, device=dev)
+        check(lib.stemgnn_linear_few_rows(dy.data_ptr(), w.data_ptr(), None, m, k, n, d1.data_ptr(), 1, st))
+        assert torch.equal(d1, d0)
+
+
 def test_linear_row_limited_output(dev):
     """stemgnn_linear_fwd_rows: rows past store_rows feed the column statistics but are not written."""
     from stem_gnn_amd._lib import lib, check
