@@ -151,6 +151,52 @@ int linear_ws_launch(const float* x, const float* w, const float* bias, int64_t 
                      float* stats_partial, int64_t row_base, int64_t stats_block0, int64_t store_rows, bool bt,
                      hipStream_t st);
 
+// ---- "last block finishes": a reduction whose partials are written by many blocks and summed, in a fixed order, by
+// whichever block arrives last -- the sum does not depend on who that is, so the result stays bit-reproducible, and
+// the separate one-block finishing launch (5 us of launch floor for 256 additions) disappears.
+// No fences: on this part a device-scope fence writes back and invalidates the XCD's whole L2 (measured: the
+// arg-max kernel went from 121 to 345 us with one __threadfence() per block).  Instead the few words that cross
+// blocks bypass the caches: a partial is written with st_agent (device-scope store) and wait_stores() holds the
+// thread until memory has acknowledged it; then ticket_last() (all threads of the block) takes a ticket with a
+// relaxed device-scope atomic; the last block reads the partials with ld_agent.  The counter resets itself.
+// csrc/loss_ops.hip owns the counters: ticket_counter(key) returns one of 61 zero-initialised device words, chosen
+// by the key (the output pointer); distinct outputs on concurrently running streams should not share a key.
+unsigned int* ticket_counter(const void* key);
+__device__ __forceinline__ void st_agent(double* p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(float* p, float v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_agent(const double* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ld_agent(const float* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void wait_stores() {
+  __atomic_signal_fence(__ATOMIC_SEQ_CST);
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), nothing else: this thread's stores have been acknowledged
+  __atomic_signal_fence(__ATOMIC_SEQ_CST);
+}
+__device__ __forceinline__ bool ticket_last(unsigned int* counter) {
+  __shared__ int s_ticket_last;
+  __syncthreads();  // every writer of the block is past its wait_stores()
+  if (threadIdx.x == 0) {
+    const unsigned int t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = t == gridDim.x * gridDim.y * gridDim.z - 1u;
+    if (last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_ticket_last = last;
+  }
+  __syncthreads();
+  return s_ticket_last != 0;
+}
+
+// csrc/loss_ops.hip: stemgnn_ortho_loss_fwd that also writes total[0] = plus[0] + loss[0] (plus / total may be null)
+int ortho_loss_fwd_plus(const float* embed, const int64_t* ids, int64_t heads, int64_t codebook_size, int64_t code_dim,
+                        int64_t num_ids, float scale, float* loss, const float* plus, float* total, void* workspace,
+                        size_t workspace_bytes, void* stream);
+
 // csrc/wsgemm.hip: products over few rows ( y = x w^T + b, or y = x w with w given as [K][N] ), several per launch; one
 // wave per 32 x 32 output tile, operands straight from global memory.  Same bits as the tile kernel.
 bool linear_direct_ok(int64_t M, int64_t N, int64_t K);

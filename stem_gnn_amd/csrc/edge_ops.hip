@@ -121,13 +121,17 @@ k_gather_rows(const float* __restrict__ table, int64_t R, int D, const int64_t* 
 
 // topo_recon_loss terms (reference model/pt_model.py:62-65, EPS = 1e-15):
 //   loss = mean_{e < kp} -log(sigmoid(d_e) + EPS) + mean_{e >= kp} -log(1 - sigmoid(d_e) + EPS)
-// and coef[e] = d loss / d d_e (so the backward is one scaled edge-dot scatter).  One block.
-__global__ void __launch_bounds__(1024) k_edge_bce(const float* __restrict__ dots, int64_t kp, int64_t kn,
-                                                   float* __restrict__ loss, float* __restrict__ coef) {
-  __shared__ double red[2][1024];
+// and coef[e] = d loss / d d_e (so the backward is one scaled edge-dot scatter).
+__global__ void __launch_bounds__(256) k_edge_bce(const float* __restrict__ dots, int64_t kp, int64_t kn,
+                                                  float* __restrict__ loss, float* __restrict__ coef,
+                                                  double* __restrict__ partial /*[blocks][2]*/, unsigned int* counter) {
+  // grid-stride over the scores; the block that arrives last adds the partial sums in index order (common.h:
+  // ticket_last) -- one launch, and a few hundred thousand logs no longer run on a single block
+  __shared__ double red[2][256];
   const float eps = 1e-15f;
   double sp = 0.0, sn = 0.0;
-  for (int64_t e = threadIdx.x; e < kp + kn; e += 1024) {
+  for (int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; e < kp + kn;
+       e += static_cast<int64_t>(gridDim.x) * 256) {
     const float d = dots[e];
     const float sg = 1.0f / (1.0f + expf(-d));
     if (e < kp) {
@@ -142,7 +146,28 @@ __global__ void __launch_bounds__(1024) k_edge_bce(const float* __restrict__ dot
   red[0][threadIdx.x] = sp;
   red[1][threadIdx.x] = sn;
   __syncthreads();
-  for (int o = 512; o > 0; o >>= 1) {
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + o];
+      red[1][threadIdx.x] += red[1][threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    st_agent(partial + 2 * blockIdx.x, red[0][0]);
+    st_agent(partial + 2 * blockIdx.x + 1, red[1][0]);
+    wait_stores();
+  }
+  if (!ticket_last(counter)) return;
+  sp = sn = 0.0;
+  for (int i = threadIdx.x; i < static_cast<int>(gridDim.x); i += 256) {
+    sp += ld_agent(partial + 2 * i);
+    sn += ld_agent(partial + 2 * i + 1);
+  }
+  red[0][threadIdx.x] = sp;
+  red[1][threadIdx.x] = sn;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
     if (threadIdx.x < o) {
       red[0][threadIdx.x] += red[0][threadIdx.x + o];
       red[1][threadIdx.x] += red[1][threadIdx.x + o];
@@ -220,7 +245,17 @@ int stemgnn_edge_dot_bwd_scaled(const float* coef, const float* g_scalar, const 
 int stemgnn_edge_bce_loss(const float* dots, int64_t kp, int64_t kn, float* loss, float* coef, void* stream_) {
   if (kp < 0 || kn < 0 || !loss) return STEMGNN_ERR_INVALID_ARG;
   if (kp + kn > 0 && (!dots || !coef)) return STEMGNN_ERR_INVALID_ARG;
-  k_edge_bce<<<1, 1024, 0, static_cast<hipStream_t>(stream_)>>>(dots, kp, kn, loss, coef);
+  static double* partial = [] {  // [256 blocks][2], one call in flight per device (the step's stream order)
+    double* p = nullptr;
+    return hipMalloc(&p, 512 * sizeof(double)) == hipSuccess ? p : static_cast<double*>(nullptr);
+  }();
+  unsigned int* counter = ticket_counter(loss);
+  if (!partial || !counter) return STEMGNN_ERR_HIP;
+  int64_t blocks = (kp + kn + 1023) / 1024;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 256) blocks = 256;
+  k_edge_bce<<<static_cast<unsigned>(blocks), 256, 0, static_cast<hipStream_t>(stream_)>>>(dots, kp, kn, loss, coef,
+                                                                                          partial, counter);
   STEMGNN_LAUNCH_CHECK();
   return STEMGNN_OK;
 }

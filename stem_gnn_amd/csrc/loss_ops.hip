@@ -25,9 +25,23 @@ __device__ inline double block_sum(double v, double* red) {
   return r;
 }
 
+// loss[0] = (sum_i partial[i]) * mul + add, fixed order, by the 256 threads of the calling block (the last to arrive)
+__device__ inline void finish_sum_block(const double* partial, int n, double mul, double add, float* loss, double* red) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += ld_agent(partial + i);
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[0] = static_cast<float>(red[0] * mul + add);
+}
+
 // partial[b] = sum over the block's grid-stride share of (p - t)^2
 __global__ void __launch_bounds__(256) k_mse_partial(const float* __restrict__ p, const float* __restrict__ t, int64_t n,
-                                                     double* __restrict__ partial) {
+                                                     double* __restrict__ partial, unsigned int* counter, double mul,
+                                                     float* __restrict__ loss) {
   __shared__ double red[256];
   double s = 0.0;
   const int64_t n4 = n / 4;
@@ -47,12 +61,14 @@ __global__ void __launch_bounds__(256) k_mse_partial(const float* __restrict__ p
     if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+  if (threadIdx.x == 0) { st_agent(partial + blockIdx.x, red[0]); wait_stores(); }
+  if (ticket_last(counter)) finish_sum_block(partial, gridDim.x, mul, 0.0, loss, red);
 }
 
 // loss[0] = (sum_b partial[b]) * mul + add   (fixed order)
 __global__ void __launch_bounds__(256) k_finish_sum(const double* __restrict__ partial, int n, double mul, double add,
-                                                    float* __restrict__ loss) {
+                                                    float* __restrict__ loss, const float* __restrict__ plus = nullptr,
+                                                    float* __restrict__ total = nullptr) {
   __shared__ double red[256];
   double s = 0.0;
   for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
@@ -62,7 +78,11 @@ __global__ void __launch_bounds__(256) k_finish_sum(const double* __restrict__ p
     if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) loss[0] = static_cast<float>(red[0] * mul + add);
+  if (threadIdx.x == 0) {
+    const float v = static_cast<float>(red[0] * mul + add);
+    loss[0] = v;
+    if (total) total[0] = (plus ? plus[0] : 0.f) + v;  // a sum of two loss terms in the same launch (VQ: commit + ortho)
+  }
 }
 
 // g_p = g[0] * scale * 2 (p - t) / n
@@ -76,23 +96,28 @@ __global__ void __launch_bounds__(256) k_mse_bwd(const float* __restrict__ p, co
 // One wave per row: cos of the normalised rows (F.normalize eps clamp); save [rows][3] = (cos, 1/|z|, |h|),
 // row_loss[r] = 1 - cos.
 __global__ void __launch_bounds__(256) k_cos_rows(const float* __restrict__ z, const float* __restrict__ h, int64_t rows,
-                                                  int D, float* __restrict__ save, double* __restrict__ row_loss) {
+                                                  int D, float* __restrict__ save, double* __restrict__ row_loss,
+                                                  unsigned int* counter, double mul, float* __restrict__ loss) {
+  __shared__ double red[256];
   const int lane = threadIdx.x & 63;
   const int64_t r = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
-  if (r >= rows) return;
-  float zz = 0.f, hh = 0.f, zh = 0.f;
-  for (int c = lane; c < D; c += 64) {
-    const float a = z[r * D + c], b = h[r * D + c];
-    zz += a * a; hh += b * b; zh += a * b;
+  if (r < rows) {
+    float zz = 0.f, hh = 0.f, zh = 0.f;
+    for (int c = lane; c < D; c += 64) {
+      const float a = z[r * D + c], b = h[r * D + c];
+      zz += a * a; hh += b * b; zh += a * b;
+    }
+    zz = wave_sum(zz); hh = wave_sum(hh); zh = wave_sum(zh);
+    const float nz = sqrtf(zz), nh = sqrtf(hh);
+    const float cz = fmaxf(nz, kNormEps), ch = fmaxf(nh, kNormEps);
+    const float cosv = zh / (cz * ch);
+    if (lane == 0) {
+      save[r * 3 + 0] = cosv; save[r * 3 + 1] = 1.0f / cz; save[r * 3 + 2] = nh;
+      st_agent(row_loss + r, static_cast<double>(1.0f - cosv));
+      wait_stores();
+    }
   }
-  zz = wave_sum(zz); hh = wave_sum(hh); zh = wave_sum(zh);
-  const float nz = sqrtf(zz), nh = sqrtf(hh);
-  const float cz = fmaxf(nz, kNormEps), ch = fmaxf(nh, kNormEps);
-  const float cosv = zh / (cz * ch);
-  if (lane == 0) {
-    save[r * 3 + 0] = cosv; save[r * 3 + 1] = 1.0f / cz; save[r * 3 + 2] = nh;
-    row_loss[r] = static_cast<double>(1.0f - cosv);
-  }
+  if (ticket_last(counter)) finish_sum_block(row_loss, static_cast<int>(rows), mul, 0.0, loss, red);
 }
 
 // g_h[r] = -(g scale / rows) * d cos / d h,  cos = <zn, h / max(|h|, eps)>
@@ -232,6 +257,19 @@ __global__ void k_weighted_sum_bwd(ScalarTable t, const float* __restrict__ g, f
 }  // namespace
 }  // namespace stemgnn
 
+namespace stemgnn {
+unsigned int* ticket_counter(const void* key) {
+  static unsigned int* base = [] {
+    unsigned int* p = nullptr;
+    if (hipMalloc(&p, 64 * sizeof(unsigned int)) != hipSuccess) return static_cast<unsigned int*>(nullptr);
+    if (hipMemset(p, 0, 64 * sizeof(unsigned int)) != hipSuccess) return static_cast<unsigned int*>(nullptr);
+    return p;
+  }();
+  if (!base) return nullptr;
+  return base + (reinterpret_cast<uintptr_t>(key) >> 2) % 61;
+}
+}  // namespace stemgnn
+
 using namespace stemgnn;
 
 extern "C" {
@@ -275,10 +313,10 @@ int stemgnn_mse_loss_fwd(const float* pred, const float* target, int64_t n, floa
   int64_t blocks = (n / 4 + 255) / 256;
   if (blocks < 1) blocks = 1;
   if (blocks > 256) blocks = 256;
-  k_mse_partial<<<static_cast<unsigned>(blocks), 256, 0, st>>>(pred, target, n, partial);
-  STEMGNN_LAUNCH_CHECK();
-  k_finish_sum<<<1, 256, 0, st>>>(partial, static_cast<int>(blocks), static_cast<double>(scale) / (n > 0 ? n : 1), 0.0,
-                                  loss);
+  unsigned int* counter = ticket_counter(loss);
+  if (!counter) return STEMGNN_ERR_HIP;
+  k_mse_partial<<<static_cast<unsigned>(blocks), 256, 0, st>>>(pred, target, n, partial, counter,
+                                                               static_cast<double>(scale) / (n > 0 ? n : 1), loss);
   STEMGNN_LAUNCH_CHECK();
   return STEMGNN_OK;
 }
@@ -304,12 +342,15 @@ int stemgnn_cosine_loss_fwd(const float* z, const float* h, int64_t rows, int64_
   if (workspace_bytes < stemgnn_loss_workspace_bytes(rows)) return STEMGNN_ERR_WORKSPACE;
   double* row_loss = reinterpret_cast<double*>(align_up(reinterpret_cast<uintptr_t>(workspace), 256));
   if (rows > 0) {
-    k_cos_rows<<<static_cast<unsigned>((rows + 3) / 4), 256, 0, st>>>(z, h, rows, static_cast<int>(dim), save, row_loss);
+    unsigned int* counter = ticket_counter(loss);
+    if (!counter) return STEMGNN_ERR_HIP;
+    k_cos_rows<<<static_cast<unsigned>((rows + 3) / 4), 256, 0, st>>>(z, h, rows, static_cast<int>(dim), save, row_loss,
+                                                                      counter, static_cast<double>(scale) / rows, loss);
+    STEMGNN_LAUNCH_CHECK();
+  } else {
+    k_finish_sum<<<1, 256, 0, st>>>(row_loss, 0, 0.0, 0.0, loss);
     STEMGNN_LAUNCH_CHECK();
   }
-  k_finish_sum<<<1, 256, 0, st>>>(row_loss, static_cast<int>(rows), static_cast<double>(scale) / (rows > 0 ? rows : 1),
-                                  0.0, loss);
-  STEMGNN_LAUNCH_CHECK();
   return STEMGNN_OK;
 }
 
@@ -324,9 +365,12 @@ int stemgnn_cosine_loss_bwd(const float* z, const float* h, int64_t rows, int64_
   return STEMGNN_OK;
 }
 
-int stemgnn_ortho_loss_fwd(const float* embed, const int64_t* ids, int64_t heads, int64_t codebook_size,
-                           int64_t code_dim, int64_t num_ids, float scale, float* loss, void* workspace,
-                           size_t workspace_bytes, void* stream_) {
+}  // extern "C"
+
+// the regulariser, and optionally total[0] = plus[0] + loss[0] from the same finishing launch (csrc/phases.hip)
+int stemgnn::ortho_loss_fwd_plus(const float* embed, const int64_t* ids, int64_t heads, int64_t codebook_size,
+                                 int64_t code_dim, int64_t num_ids, float scale, float* loss, const float* plus,
+                                 float* total, void* workspace, size_t workspace_bytes, void* stream_) {
   hipStream_t st = static_cast<hipStream_t>(stream_);
   if (heads <= 0 || codebook_size <= 0 || code_dim <= 0 || code_dim > 64 * kOrthoMaxPerLane || num_ids <= 0 ||
       heads * num_ids > (1 << 20) || !embed || !ids || !loss || !workspace)
@@ -338,9 +382,18 @@ int stemgnn_ortho_loss_fwd(const float* embed, const int64_t* ids, int64_t heads
                       nullptr, partial, nullptr);
   STEMGNN_LAUNCH_CHECK();
   k_finish_sum<<<1, 256, 0, st>>>(partial, H * M, static_cast<double>(scale) / (static_cast<double>(H) * M * M),
-                                  -static_cast<double>(scale) / M, loss);
+                                  -static_cast<double>(scale) / M, loss, plus, total);
   STEMGNN_LAUNCH_CHECK();
   return STEMGNN_OK;
+}
+
+extern "C" {
+
+int stemgnn_ortho_loss_fwd(const float* embed, const int64_t* ids, int64_t heads, int64_t codebook_size,
+                           int64_t code_dim, int64_t num_ids, float scale, float* loss, void* workspace,
+                           size_t workspace_bytes, void* stream_) {
+  return ortho_loss_fwd_plus(embed, ids, heads, codebook_size, code_dim, num_ids, scale, loss, nullptr, nullptr, workspace,
+                             workspace_bytes, stream_);
 }
 
 int stemgnn_ortho_loss_bwd(const float* embed, const int64_t* ids, int64_t heads, int64_t codebook_size,

@@ -27,7 +27,11 @@ __device__ inline int find_tensor(const TensorTable& t, int b) {
   return i;
 }
 
-__global__ void __launch_bounds__(kBlock) k_sumsq_partial(TensorTable t, double* __restrict__ partial) {
+// ... and the block that arrives last turns the partials into (total norm, clipping factor): no finishing launch
+// (common.h: ticket_last).  The sum over the partials runs in index order whoever that block is.
+__global__ void __launch_bounds__(kBlock) k_sumsq_partial(TensorTable t, double* __restrict__ partial,
+                                                          unsigned int* counter, float max_norm,
+                                                          float* __restrict__ out /*[2]: total norm, coef*/) {
   __shared__ double red[kBlock];
   const int b = blockIdx.x, i = find_tensor(t, b);
   const int64_t beg = static_cast<int64_t>(b - t.first_block[i]) * kChunk;
@@ -44,7 +48,24 @@ __global__ void __launch_bounds__(kBlock) k_sumsq_partial(TensorTable t, double*
     if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) partial[b] = red[0];
+  if (threadIdx.x == 0) { st_agent(partial + b, red[0]); wait_stores(); }
+  if (!ticket_last(counter)) return;
+  double tot = 0.0;
+  const int n = gridDim.x;
+  for (int i = threadIdx.x; i < n; i += kBlock) tot += ld_agent(partial + i);
+  red[threadIdx.x] = tot;
+  __syncthreads();
+  for (int o = kBlock / 2; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float total = static_cast<float>(sqrt(red[0]));
+    float coef = max_norm / (total + 1e-6f);  // clip_grad.py: clip_coef = max_norm / (total_norm + 1e-6), clamped to 1
+    if (!(coef < 1.0f)) coef = 1.0f;
+    out[0] = total;
+    out[1] = coef;
+  }
 }
 
 __global__ void __launch_bounds__(kBlock) k_norm_finish(const double* __restrict__ partial, int n, float max_norm,
@@ -190,10 +211,12 @@ int stemgnn_grad_norm_coef(const float* const* grads, const int64_t* sizes, int3
   if (!workspace || workspace_bytes < stemgnn_clip_grad_workspace_bytes(total, count)) return STEMGNN_ERR_WORKSPACE;
   double* partial = reinterpret_cast<double*>(align_up(reinterpret_cast<uintptr_t>(workspace), 256));
   if (blocks > 0) {
-    k_sumsq_partial<<<static_cast<unsigned>(blocks), kBlock, 0, st>>>(t, partial);
-    STEMGNN_LAUNCH_CHECK();
+    unsigned int* counter = ticket_counter(out);
+    if (!counter) return STEMGNN_ERR_HIP;
+    k_sumsq_partial<<<static_cast<unsigned>(blocks), kBlock, 0, st>>>(t, partial, counter, max_norm, out);
+  } else {
+    k_norm_finish<<<1, kBlock, 0, st>>>(partial, 0, max_norm, out);
   }
-  k_norm_finish<<<1, kBlock, 0, st>>>(partial, static_cast<int>(blocks), max_norm, out);
   STEMGNN_LAUNCH_CHECK();
   return STEMGNN_OK;
 }
@@ -220,10 +243,12 @@ int stemgnn_clip_grad_norm(float* const* grads, const int64_t* sizes, int32_t co
   if (!workspace || workspace_bytes < stemgnn_clip_grad_workspace_bytes(total, count)) return STEMGNN_ERR_WORKSPACE;
   double* partial = reinterpret_cast<double*>(align_up(reinterpret_cast<uintptr_t>(workspace), 256));
   if (blocks > 0) {
-    k_sumsq_partial<<<static_cast<unsigned>(blocks), kBlock, 0, st>>>(t, partial);
-    STEMGNN_LAUNCH_CHECK();
+    unsigned int* counter = ticket_counter(out);
+    if (!counter) return STEMGNN_ERR_HIP;
+    k_sumsq_partial<<<static_cast<unsigned>(blocks), kBlock, 0, st>>>(t, partial, counter, max_norm, out);
+  } else {
+    k_norm_finish<<<1, kBlock, 0, st>>>(partial, 0, max_norm, out);
   }
-  k_norm_finish<<<1, kBlock, 0, st>>>(partial, static_cast<int>(blocks), max_norm, out);
   STEMGNN_LAUNCH_CHECK();
   if (blocks > 0) {
     k_scale_tensors<<<static_cast<unsigned>(blocks), kBlock, 0, st>>>(t, out);

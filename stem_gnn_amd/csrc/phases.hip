@@ -333,11 +333,14 @@ int stemgnn_vq_fwd(const stemgnn_vq_params* p, const float* z, int64_t N, int tr
   STEMGNN_TRY(stemgnn_vq_assign_lean(s.xp, N, H, Dc, p->embed, s.esq, K, s.norm, ind, s.terms, scale, s.assign_ws,
                                      s.assign_ws_bytes, stream));
   const bool ortho = training && p->ortho_weight > 0.f;
-  if (ortho)
-    STEMGNN_TRY(stemgnn_ortho_loss_fwd(p->embed, p->ortho_ids, H, K, Dc, p->num_ortho_ids, p->ortho_weight, s.terms + 1,
-                                       s.loss_ws, s.loss_ws_bytes, stream));
-  k_scalar_add<<<1, 64, 0, st>>>(commit ? s.terms : nullptr, ortho ? s.terms + 1 : nullptr, loss);
-  STEMGNN_LAUNCH_CHECK();
+  if (ortho) {
+    // the regulariser's finishing block also writes loss = commitment term + regulariser
+    STEMGNN_TRY(ortho_loss_fwd_plus(p->embed, p->ortho_ids, H, K, Dc, p->num_ortho_ids, p->ortho_weight, s.terms + 1,
+                                    commit ? s.terms : nullptr, loss, s.loss_ws, s.loss_ws_bytes, stream));
+  } else {
+    k_scalar_add<<<1, 64, 0, st>>>(commit ? s.terms : nullptr, nullptr, loss);
+    STEMGNN_LAUNCH_CHECK();
+  }
   // project_out of the quantised heads (vq.py:1041), read off the table
   STEMGNN_TRY(stemgnn_codes_project(s.table, ind, p->b_out, N, H, K, D, quantize, stream));
   return STEMGNN_OK;

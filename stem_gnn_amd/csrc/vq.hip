@@ -42,7 +42,8 @@ template <int CG, bool X3>
 __global__ void __launch_bounds__(kBlock, 2)
 k_vq_assign(const float* __restrict__ xp, int64_t N, int H, int Dc, const float* __restrict__ embed, int K,
             int training, float* __restrict__ xn_out, float* __restrict__ norm_out, int64_t* __restrict__ ind_out,
-            float* __restrict__ quant, float* __restrict__ sq_partial, const float* __restrict__ esq) {
+            float* __restrict__ quant, float* __restrict__ sq_partial, const float* __restrict__ esq,
+            unsigned int* counter, double sq_scale, float* __restrict__ sq_out) {
   constexpr int PA = 32 * CG * kLdP, PB = kRowsPerBlock * kLdP;  // bytes of one bf16 plane (X3)
   constexpr int kBytesA = X3 ? 3 * PA : 32 * CG * kLd * 4;
   constexpr int kBytesB = X3 ? 3 * PB : kRowsPerBlock * kLd * 4;
@@ -281,8 +282,22 @@ k_vq_assign(const float* __restrict__ xp, int64_t N, int H, int Dc, const float*
   if (tid == 0) {
     float t = 0.f;
     for (int w = 0; w < kBlock / kWave; ++w) t += s_red[w];
-    sq_partial[static_cast<int64_t>(blockIdx.y) * gridDim.x + blockIdx.x] = t;
+    st_agent(sq_partial + static_cast<int64_t>(blockIdx.y) * gridDim.x + blockIdx.x, t);
+    wait_stores();
   }
+  // the block that arrives last adds the blocks' sums in index order (common.h: ticket_last): no finishing launch
+  if (!ticket_last(counter)) return;
+  double* red = reinterpret_cast<double*>(sA_raw);  // the staging memory is free now (>= 256 doubles)
+  double tot = 0.0;
+  const int64_t nb = static_cast<int64_t>(gridDim.x) * gridDim.y;
+  for (int64_t i = tid; i < nb; i += kBlock) tot += ld_agent(sq_partial + i);
+  red[tid] = tot;
+  __syncthreads();
+  for (int o = kBlock / 2; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) sq_out[0] = static_cast<float>(red[0] * sq_scale);
 }
 
 // esq[c] = |embed[c]|^2, one wave per code row (the codebook drifts off the unit sphere under AdamW).
@@ -693,19 +708,20 @@ static int vq_assign_impl(const float* xp, int64_t N, int64_t H, int64_t Dc, con
   dim3 grid(static_cast<unsigned>(rb), static_cast<unsigned>(H));
   const int Hi = static_cast<int>(H), Dci = static_cast<int>(Dc), Ki = static_cast<int>(K);
   const bool x3 = stemgnn_linear_set_mode(-1) == 1;  // the mode of the dense products (csrc/linear.hip)
+  unsigned int* counter = ticket_counter(sqerr);
+  if (!counter) return STEMGNN_ERR_HIP;
+  const double sq_scale = static_cast<double>(sqerr_scale);
 #define STEMGNN_VQ_LAUNCH(CG)                                                                                         \
   do {                                                                                                                \
     if (x3) k_vq_assign<CG, true><<<grid, kBlock, 0, st>>>(xp, N, Hi, Dci, embed, Ki, training, xn, norm, ind, quant, \
-                                                            partial, esq);                                            \
+                                                            partial, esq, counter, sq_scale, sqerr);                  \
     else k_vq_assign<CG, false><<<grid, kBlock, 0, st>>>(xp, N, Hi, Dci, embed, Ki, training, xn, norm, ind, quant,   \
-                                                          partial, esq);                                              \
+                                                          partial, esq, counter, sq_scale, sqerr);                    \
   } while (0)
   if (K <= 32) STEMGNN_VQ_LAUNCH(1);
   else if (K <= 64) STEMGNN_VQ_LAUNCH(2);
   else STEMGNN_VQ_LAUNCH(4);
 #undef STEMGNN_VQ_LAUNCH
-  STEMGNN_LAUNCH_CHECK();
-  k_sum_partials<<<1, kBlock, 0, st>>>(partial, rb * H, static_cast<double>(sqerr_scale), sqerr);
   STEMGNN_LAUNCH_CHECK();
   return STEMGNN_OK;
 }
