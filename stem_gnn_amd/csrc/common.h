@@ -192,6 +192,13 @@ __device__ __forceinline__ bool ticket_last(unsigned int* counter) {
   return s_ticket_last != 0;
 }
 
+// csrc/wsgemm.hip: the quantiser's code assignment (lean form: indices, row norms, commitment sum) with the head's codes
+// as the register-resident operand; K = Dc = 128 and at least 16384 rows.  sq_partial: 2 * CUs floats.
+bool vq_assign_ws_ok(int64_t N, int64_t H, int64_t Dc, int64_t K);
+int vq_assign_ws_launch(const float* xp, int64_t N, int64_t H, const float* embed, const float* esq, float* norm,
+                        int64_t* ind, float* sq_partial, unsigned int* counter, double sq_scale, float* sq_out,
+                        hipStream_t st);
+
 // csrc/loss_ops.hip: stemgnn_ortho_loss_fwd that also writes total[0] = plus[0] + loss[0] (plus / total may be null)
 int ortho_loss_fwd_plus(const float* embed, const int64_t* ids, int64_t heads, int64_t codebook_size, int64_t code_dim,
                         int64_t num_ids, float scale, float* loss, const float* plus, float* total, void* workspace,

@@ -711,6 +711,10 @@ static int vq_assign_impl(const float* xp, int64_t N, int64_t H, int64_t Dc, con
   unsigned int* counter = ticket_counter(sqerr);
   if (!counter) return STEMGNN_ERR_HIP;
   const double sq_scale = static_cast<double>(sqerr_scale);
+  // lean form at K = Dc = 128: the weight-stationary kernel (csrc/wsgemm.hip), same results
+  if (x3 && !quant && esq && stemgnn_linear_set_ws(-1) > 0 && vq_assign_ws_ok(N, H, Dc, K) &&
+      rb * H >= 1024)  // its partials (at most two blocks per CU) fit the workspace
+    return vq_assign_ws_launch(xp, N, H, embed, esq, norm, ind, partial, counter, sq_scale, sqerr, st);
 #define STEMGNN_VQ_LAUNCH(CG)                                                                                         \
   do {                                                                                                                \
     if (x3) k_vq_assign<CG, true><<<grid, kBlock, 0, st>>>(xp, N, Hi, Dci, embed, Ki, training, xn, norm, ind, quant, \

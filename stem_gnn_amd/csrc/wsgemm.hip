@@ -408,3 +408,220 @@ int DirectBatch::flush(hipStream_t st) {
 }
 
 }  // namespace stemgnn
+
+// ---------------------------------------------------------------------------------------------------------------
+// Code assignment of the vector quantiser (reference model/vq.py:28-29,650-657: l2-normalise the head's rows, cosine
+// similarity with the head's codes, arg-max; commitment term vq.py:1007-1009) on the weight-stationary skeleton above:
+// the 128 codes of a head are the register-resident operand, the rows of xp stream through LDS, and the epilogue
+// takes the arg-max of a 64 x 128 similarity tile instead of storing it.  Same arithmetic as k_vq_assign (csrc/vq.hip)
+// -- the same six-product cut in the same k order, the same order of additions for the row norms -- so the same
+// indices, norms and commitment sum.  K = Dc = 128 (BASELINE configuration 4).
+// ---------------------------------------------------------------------------------------------------------------
+namespace stemgnn {
+namespace {
+
+constexpr size_t kVqLdsBytes = kRingBytes + kStageBytes + 2 * kTileM * sizeof(float);
+
+__global__ void __launch_bounds__(kThreads, 2)
+k_vq_assign_ws(const float* __restrict__ xp, int64_t N, int H, const float* __restrict__ embed,
+               const float* __restrict__ esq, float* __restrict__ norm_out, int64_t* __restrict__ ind_out,
+               float* __restrict__ sq_partial, unsigned int* counter, double sq_scale, float* __restrict__ sq_out) {
+  constexpr int KS = 4, K = 128, Dc = 128;
+  constexpr float kNormEps = 1e-12f;  // F.normalize eps
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const ring = smem;
+  float* const tile = reinterpret_cast<float*>(smem + kRingBytes);
+  float* const s_ssq = reinterpret_cast<float*>(smem + kRingBytes + kStageBytes);  // [64] squared row norms
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave, hi = lane >> 5, lj = lane & 31;
+  const int h = blockIdx.y;
+  const int64_t HD = static_cast<int64_t>(H) * Dc;
+  const float* const xh = xp + static_cast<int64_t>(h) * Dc;
+  const float* const emb = embed + static_cast<int64_t>(h) * K * Dc;
+  const int64_t tiles = (N + kTileM - 1) / kTileM;
+
+  bf16x8 bw[2 * KS][3];  // the head's codes 32 wn + lj, contraction steps 16 ks + 8 hi .. + 7, as bf16 pieces
+#pragma unroll
+  for (int ks = 0; ks < 2 * KS; ++ks) {
+    const int k = 16 * ks + 8 * hi;
+    const float4 lo = ld4(emb + static_cast<int64_t>(32 * wn + lj) * Dc + k);
+    const float4 up = ld4(emb + static_cast<int64_t>(32 * wn + lj) * Dc + k + 4);
+    uint4 ph, pm, pl;
+    split8(lo, up, ph, pm, pl);
+    bw[ks][0] = as_bf16x8(ph);
+    bw[ks][1] = as_bf16x8(pm);
+    bw[ks][2] = as_bf16x8(pl);
+  }
+
+  float4 ra[KS][2];
+  const int r0 = stage_row(tid), r1 = stage_row(kThreads + tid), c4s = 4 * (tid & 7);
+  auto fetch = [&](int64_t t, int s) {
+    const int64_t m0 = (t < tiles ? t : tiles - 1) * kTileM;
+    const int64_t ma = m0 + r0 < N ? m0 + r0 : N - 1, mb = m0 + r1 < N ? m0 + r1 : N - 1;  // past N: row N - 1 again
+    ra[s][0] = ld4(xh + ma * HD + s * kKC + c4s);
+    ra[s][1] = ld4(xh + mb * HD + s * kKC + c4s);
+  };
+  // squared norms of this thread's two rows, summed chunk by chunk as the chunks are cut (k_vq_assign's order); chunk 0
+  // of the NEXT tile is cut during this tile's last step, hence the second pair
+  float ssq[2] = {0.f, 0.f}, ssq_next[2] = {0.f, 0.f};
+  auto stash = [&](int s, int slot, float (&acc2)[2]) {
+    unsigned char* const base = ring + slot * kSlot;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int off = (i ? r1 : r0) * kLdP + 2 * c4s;
+      const float4 v = ra[s][i];
+      acc2[i] += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+      uint2 ph, pm, pl;
+      split3(v, ph, pm, pl);
+      *reinterpret_cast<uint2*>(base + off) = ph;
+      *reinterpret_cast<uint2*>(base + kPlane + off) = pm;
+      *reinterpret_cast<uint2*>(base + 2 * kPlane + off) = pl;
+    }
+  };
+
+  int64_t t = blockIdx.x;
+  if (t >= tiles) return;  // never: the grid has at most `tiles` blocks per head
+  const int64_t stride = gridDim.x;
+#pragma unroll
+  for (int s = 0; s < KS; ++s) fetch(t, s);
+  stash(0, 0, ssq);
+  fetch(t + stride, 0);
+  __syncthreads();
+
+  float sq_acc = 0.f;  // commitment terms of the rows this thread reports
+  for (; t < tiles; t += stride) {
+    const int64_t m0 = t * kTileM;
+    floatx16 acc[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const unsigned char* const slot = ring + (s & 1) * kSlot;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int ko = q * 32 + hi * 16;
+        bf16x8 a[2][3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+          for (int tm = 0; tm < 2; ++tm)
+            a[tm][p] = *reinterpret_cast<const bf16x8*>(slot + p * kPlane + (tm * 32 + lj) * kLdP + ko);
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) acc[tm] = mfma_x3(bw[2 * s + q], a[tm], acc[tm]);  // codes x rows, as k_vq_assign
+      }
+      if (s + 1 < KS) {
+        stash(s + 1, (s + 1) & 1, ssq);
+        fetch(t + stride, s + 1);
+      } else {
+        stash(0, 0, ssq_next);
+        fetch(t + 2 * stride, 0);
+      }
+      __syncthreads();
+    }
+    // ---- epilogue: similarities to the staging tile [row][code]; a lane holds code 32 wn + (its 16 register rows)
+    // of data row tm * 32 + lj (operands swapped relative to the product kernel: the accumulator's rows are codes)
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        tile[(tm * 32 + lj) * kLdT + 32 * wn + 4 * hi + (r & 3) + 8 * (r >> 2)] = acc[tm][r];
+    {
+      float v0 = ssq[0], v1 = ssq[1];
+      v0 += __shfl_xor(v0, 1, 64); v0 += __shfl_xor(v0, 2, 64); v0 += __shfl_xor(v0, 4, 64);
+      v1 += __shfl_xor(v1, 1, 64); v1 += __shfl_xor(v1, 2, 64); v1 += __shfl_xor(v1, 4, 64);
+      if ((tid & 7) == 0) { s_ssq[r0] = v0; s_ssq[r1] = v1; }
+      ssq[0] = ssq_next[0]; ssq[1] = ssq_next[1];
+      ssq_next[0] = ssq_next[1] = 0.f;
+    }
+    __syncthreads();
+    {
+      // four lanes per row, 32 codes each in ascending order; strict '>' keeps the lowest index, as torch.argmax does
+      const int row = tid >> 2, part = tid & 3;
+      float best = -INFINITY;
+      int bi = 0;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const float4 v = ld4(tile + row * kLdT + part * 32 + 4 * c);
+        const int code = part * 32 + 4 * c;
+        if (v.x > best) { best = v.x; bi = code; }
+        if (v.y > best) { best = v.y; bi = code + 1; }
+        if (v.z > best) { best = v.z; bi = code + 2; }
+        if (v.w > best) { best = v.w; bi = code + 3; }
+      }
+#pragma unroll
+      for (int o = 1; o < 4; o <<= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+      }
+      const float nrm = sqrtf(s_ssq[row]);
+      const float inv = 1.0f / fmaxf(nrm, kNormEps), xn2 = nrm * inv;
+      const int64_t m = m0 + row < N ? m0 + row : N - 1;  // a row past N is a copy of row N - 1: the same values again
+      if (part == 0) {
+        ind_out[m * H + h] = static_cast<int64_t>(bi);
+        norm_out[m * H + h] = nrm;
+        if (m0 + row < N) sq_acc += esq[static_cast<int64_t>(h) * K + bi] + xn2 * xn2 - 2.0f * best * inv;
+      }
+    }
+  }
+  // ---- the block's commitment sum; the last block to arrive adds all of them in index order (common.h: ticket_last)
+  __shared__ double red[kThreads];
+  __syncthreads();
+  red[tid] = static_cast<double>(sq_acc);
+  __syncthreads();
+  for (int o = kThreads / 2; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    st_agent(sq_partial + static_cast<int64_t>(blockIdx.y) * gridDim.x + blockIdx.x, static_cast<float>(red[0]));
+    wait_stores();
+  }
+  if (!ticket_last(counter)) return;
+  double tot = 0.0;
+  const int64_t nb = static_cast<int64_t>(gridDim.x) * gridDim.y;
+  for (int64_t i = tid; i < nb; i += kThreads) tot += ld_agent(sq_partial + i);
+  red[tid] = tot;
+  __syncthreads();
+  for (int o = kThreads / 2; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) sq_out[0] = static_cast<float>(red[0] * sq_scale);
+}
+
+}  // namespace
+
+bool vq_assign_ws_ok(int64_t N, int64_t H, int64_t Dc, int64_t K) {
+  return Dc == 128 && K == 128 && H >= 1 && H <= 64 && N >= 16384;
+}
+
+int vq_assign_ws_launch(const float* xp, int64_t N, int64_t H, const float* embed, const float* esq, float* norm,
+                        int64_t* ind, float* sq_partial, unsigned int* counter, double sq_scale, float* sq_out,
+                        hipStream_t st) {
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1)
+      n = 256;
+    return n;
+  }();
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_vq_assign_ws),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     static_cast<int>(kVqLdsBytes));
+  if (attr != hipSuccess) return STEMGNN_ERR_HIP;
+  const int64_t tiles = (N + kTileM - 1) / kTileM;
+  int64_t gx = 2 * cus / H;
+  if (gx < 1) gx = 1;
+  if (gx > tiles) gx = tiles;
+  dim3 grid(static_cast<unsigned>(gx), static_cast<unsigned>(H));
+  k_vq_assign_ws<<<grid, kThreads, kVqLdsBytes, st>>>(xp, N, static_cast<int>(H), embed, esq, norm, ind, sq_partial,
+                                                      counter, sq_scale, sq_out);
+  STEMGNN_LAUNCH_CHECK();
+  return STEMGNN_OK;
+}
+
+}  // namespace stemgnn

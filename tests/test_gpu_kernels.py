@@ -895,6 +895,49 @@ def test_few_row_product_returns_the_tile_kernels_bits(dev, m, n, k):
         assert torch.equal(d1, d0)
 
 
+@pytest.mark.parametrize("N,H", [(20000, 4), (16390, 2)])
+def test_vq_assign_weight_stationary_matches_the_tile_form(dev, N, H):
+    """The lean code assignment at K = Dc = 128 on the weight-stationary skeleton (csrc/wsgemm.hip: k_vq_assign_ws)
+    against k_vq_assign and against torch: indices, row norms, commitment sum; a zero row and a duplicated code (tie:
+    lowest index) included."""
+    from stem_gnn_amd._lib import lib, check
+    torch.manual_seed(N + H)
+    st = torch.cuda.current_stream().cuda_stream
+    K = Dc = 128
+    xp = torch.randn(N, H * Dc, device=dev) * (0.5 + torch.rand(N, 1, device=dev))
+    xp[7] = 0
+    embed = torch.nn.functional.normalize(torch.randn(H, K, Dc, device=dev), dim=-1) * (1 + 0.05 * torch.rand(H, K, 1, device=dev))
+    embed[:, 90] = embed[:, 17]  # a tie wherever code 17 wins
+    embed = embed.contiguous()
+    esq = (embed * embed).sum(-1).contiguous()
+
+    def run():
+        norm = torch.empty(N, H, device=dev)
+        ind = torch.empty(N, H, dtype=torch.int64, device=dev)
+        sq = torch.empty(1, device=dev)
+        ws = torch.empty(int(lib.stemgnn_vq_workspace_bytes(N, H, Dc, K)), dtype=torch.uint8, device=dev)
+        check(lib.stemgnn_vq_assign_lean(xp.data_ptr(), N, H, Dc, embed.data_ptr(), esq.data_ptr(), K, norm.data_ptr(),
+                                         ind.data_ptr(), sq.data_ptr(), 0.25, ws.data_ptr(), ws.numel(), st))
+        return norm, ind, sq
+
+    prev = lib.stemgnn_linear_set_ws(0)
+    try:
+        n0, i0, s0 = run()
+        lib.stemgnn_linear_set_ws(1)
+        n1, i1, s1 = run()
+    finally:
+        lib.stemgnn_linear_set_ws(prev)
+    assert torch.equal(i1, i0) and torch.equal(n1, n0)
+    torch.testing.assert_close(s1, s0, rtol=1e-5, atol=1e-6)
+    xh = xp.view(N, H, Dc)
+    torch.testing.assert_close(n1, xh.norm(dim=-1), rtol=1e-5, atol=1e-6)
+    sim = torch.einsum("nhd,hkd->nhk", torch.nn.functional.normalize(xh, dim=-1), embed)
+    ref = sim.argmax(-1)
+    agree = (ref == i1).float().mean().item()
+    assert agree > 0.999  # fp32 rounding differs in the last bit between the two products; exact ties go to the lowest index
+    assert int((i1 == 90).sum()) == 0 or bool(((i1 == 90) <= (ref != 17)).all())
+
+
 def test_linear_row_limited_output(dev):
     """stemgnn_linear_fwd_rows: rows past store_rows feed the column statistics but are not written."""
     from stem_gnn_amd._lib import lib, check
