@@ -292,6 +292,21 @@ int stemgnn_linear_set_mode(int mode);
  * sampled batch, whose edges all end in the leading, expanded nodes; x1 may be a [x1_rows, K1] buffer): row tiles
  * past them skip the x1 half of the contraction.  Pass -1 (or M) when x1 has M meaningful rows. */
 size_t stemgnn_linear_stats_partial_bytes(int64_t num_rows, int64_t out_dim);
+/* Deterministic forms of stemgnn_edge_dot_bwd_scaled / stemgnn_edge_concat_bwd (reference model/encoder.py:346-354
+ * InnerProductDecoder backward, model/pt_model.py:72-81 cat(z_u, z_v) backward; ATen scatters with atomics there too):
+ * the edge list is grouped by node (stable radix sort, twice: by each endpoint row) and one lane group per node adds
+ * its edges in that order.  _dot_: g_z[n] = g_scalar * sum_e coef[e] z[other endpoint of e]  (g_z is overwritten);
+ * _concat_: g_z[n] += sum_e g_out[e][:D] (n first endpoint) + g_out[e][D:] (n second).  workspace:
+ * stemgnn_edge_det_workspace_bytes(N, E).  stemgnn_set_deterministic(1) (or STEMGNN_DETERMINISTIC=1) makes the heads
+ * phase use them (0 = the atomic forms, the default; negative = query); returns the previous setting. */
+size_t stemgnn_edge_det_workspace_bytes(int64_t num_nodes, int64_t num_edges);
+int stemgnn_edge_dot_bwd_det(const float* coef, const float* g_scalar, const float* z, int64_t num_nodes, int64_t dim,
+                             const int64_t* edge_index, int64_t num_edges, float* g_z, void* workspace,
+                             size_t workspace_bytes, void* stream);
+int stemgnn_edge_concat_bwd_det(const float* g_out, int64_t num_nodes, int64_t dim, const int64_t* edge_index,
+                                int64_t num_edges, float* g_z, void* workspace, size_t workspace_bytes, void* stream);
+int stemgnn_set_deterministic(int on);
+
 /* y[M, N] = x[M, K] w^T + bias (w [N, K]), or y = x w with w given as [K, N] (weight_is_kn != 0: the backward-data
  * form dx = dy w), for products over FEW rows (M <= 65536, N % 32 == 0, K % 16 == 0; exact-bf16 mode only): one wave
  * per 32 x 32 output tile, operands read straight from global memory (csrc/wsgemm.hip).  Same bits as

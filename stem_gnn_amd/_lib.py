@@ -143,6 +143,10 @@ _SIGNATURES = {
     "stemgnn_linear_stats_partial_bytes": (c_size_t, [I64, I64]),
     "stemgnn_linear_stats_blocks": (I64, [I64, I64]),
     "stemgnn_linear_set_ws": (I32, [I32]),
+    "stemgnn_edge_det_workspace_bytes": (c_size_t, [I64, I64]),
+    "stemgnn_edge_dot_bwd_det": (c_int, [P, P, P, I64, I64, P, I64, P, P, c_size_t, P]),
+    "stemgnn_edge_concat_bwd_det": (c_int, [P, I64, I64, P, I64, P, P, c_size_t, P]),
+    "stemgnn_set_deterministic": (c_int, [c_int]),
     "stemgnn_linear_few_rows": (c_int, [P, P, P, I64, I64, I64, P, I32, P]),
     "stemgnn_clip_grad_max_tensors": (I32, []),
     "stemgnn_clip_grad_workspace_bytes": (c_size_t, [I64, I32]),

@@ -7,6 +7,9 @@
 // one G-lane group per edge / row, 16-byte loads.
 #include "common.h"
 
+#include <atomic>
+#include <cstdlib>
+
 namespace stemgnn {
 namespace {
 
@@ -194,11 +197,58 @@ inline unsigned groups_grid(int64_t items, int G) {
   return static_cast<unsigned>((items + per - 1) / per);
 }
 
+// Deterministic form of the two decoder backward scatters (the default ones above add with fp32 atomics, in whatever
+// order the memory system serves them): the edge list is grouped by node twice -- by its first and by its second
+// endpoint row (graph_build.hip: a stable radix sort) -- and ONE lane group per node adds its incident edges'
+// contributions in that order.  CONCAT = false: g_z[n] = g_scalar * sum_e coef[e] z[other endpoint] (overwrites: no
+// zero pass); CONCAT = true: g_z[n] += sum over edges with n first  g_out[e][:D]  + with n second  g_out[e][D:].
+template <int G, bool CONCAT>
+__global__ void __launch_bounds__(kBlock)
+k_edge_bwd_det(const float* __restrict__ src_rows /*coef-scaled z, or g_out*/, const float* __restrict__ coef,
+               const float* __restrict__ g_scalar, int64_t N, int D, const int32_t* __restrict__ rp0,
+               const int32_t* __restrict__ other0, const int32_t* __restrict__ eid0, const int32_t* __restrict__ rp1,
+               const int32_t* __restrict__ other1, const int32_t* __restrict__ eid1, float* __restrict__ g_z) {
+  const int lane = threadIdx.x % G;
+  const int64_t n = static_cast<int64_t>(blockIdx.x) * (kBlock / G) + threadIdx.x / G;
+  if (n >= N) return;
+  const int nvec = D / 4;
+  const float gs = (!CONCAT && g_scalar) ? g_scalar[0] : 1.f;
+  for (int c = lane; c < nvec; c += G) {
+    float4 acc = CONCAT ? ld4(g_z + n * D + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+      const int32_t* rp = side ? rp1 : rp0;
+      const int32_t* ot = side ? other1 : other0;
+      const int32_t* ei = side ? eid1 : eid0;
+      for (int j = rp[n]; j < rp[n + 1]; ++j) {
+        float4 v;
+        float w = 1.f;
+        if (CONCAT) {
+          v = ld4(src_rows + static_cast<int64_t>(ei[j]) * 2 * D + side * D + 4 * c);
+        } else {
+          v = ld4(src_rows + static_cast<int64_t>(ot[j]) * D + 4 * c);
+          w = coef[ei[j]] * gs;
+        }
+        acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
+      }
+    }
+    st4(g_z + n * D + 4 * c, acc);
+  }
+}
+
 #define STEMGNN_EDGE_DISPATCH(KERNEL, ITEMS, ...)                                                   \
   do {                                                                                             \
     if (D / 4 <= 16) KERNEL<16><<<groups_grid(ITEMS, 16), kBlock, 0, st>>>(__VA_ARGS__);            \
     else if (D / 4 <= 32) KERNEL<32><<<groups_grid(ITEMS, 32), kBlock, 0, st>>>(__VA_ARGS__);       \
     else KERNEL<64><<<groups_grid(ITEMS, 64), kBlock, 0, st>>>(__VA_ARGS__);                        \
+    STEMGNN_LAUNCH_CHECK();                                                                        \
+  } while (0)
+
+#define STEMGNN_EDGE_DISPATCH_T(KERNEL, FLAG, ITEMS, ...)                                           \
+  do {                                                                                             \
+    if (D / 4 <= 16) KERNEL<16, FLAG><<<groups_grid(ITEMS, 16), kBlock, 0, st>>>(__VA_ARGS__);      \
+    else if (D / 4 <= 32) KERNEL<32, FLAG><<<groups_grid(ITEMS, 32), kBlock, 0, st>>>(__VA_ARGS__); \
+    else KERNEL<64, FLAG><<<groups_grid(ITEMS, 64), kBlock, 0, st>>>(__VA_ARGS__);                  \
     STEMGNN_LAUNCH_CHECK();                                                                        \
   } while (0)
 
@@ -325,6 +375,76 @@ int stemgnn_ema_lerp(float* teacher, const float* student, int64_t n, float deca
   k_ema_lerp<<<static_cast<unsigned>(g), kBlock, 0, static_cast<hipStream_t>(stream_)>>>(teacher, student, n, decay);
   STEMGNN_LAUNCH_CHECK();
   return STEMGNN_OK;
+}
+
+
+static std::atomic<int> g_deterministic{-1};
+
+int stemgnn_set_deterministic(int on) {
+  int prev = g_deterministic.load(std::memory_order_relaxed);
+  if (prev < 0) {
+    const char* e = getenv("STEMGNN_DETERMINISTIC");
+    prev = (e && e[0] == '1') ? 1 : 0;
+    g_deterministic.store(prev, std::memory_order_relaxed);
+  }
+  if (on == 0 || on == 1) g_deterministic.store(on, std::memory_order_relaxed);
+  return prev;
+}
+
+size_t stemgnn_edge_det_workspace_bytes(int64_t N, int64_t E) {
+  if (N < 0 || E < 0) return 0;
+  const size_t n1 = static_cast<size_t>(N) + 1, e1 = static_cast<size_t>(E > 0 ? E : 1);
+  return 2 * ((n1 + 2 * e1) * sizeof(int32_t) + 1024) + stemgnn_csr_workspace_bytes(N, E) + 1024;
+}
+
+// mode 0: dot (coef, g_scalar, z -> g_z overwritten); mode 1: concat (g_out -> added into g_z)
+static int edge_bwd_det(int mode, const float* rows, const float* coef, const float* g_scalar, int64_t N, int64_t D,
+                        const int64_t* edge_index, int64_t E, float* g_z, void* workspace, size_t workspace_bytes,
+                        void* stream_) {
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  if (N < 0 || E < 0 || !dim_ok(D)) return STEMGNN_ERR_INVALID_ARG;
+  if (!fits_i32(E) || !fits_i32(N)) return STEMGNN_ERR_TOO_LARGE;
+  if (N == 0) return STEMGNN_OK;
+  if (!rows || !g_z || (E > 0 && !edge_index) || !workspace) return STEMGNN_ERR_INVALID_ARG;
+  if (workspace_bytes < stemgnn_edge_det_workspace_bytes(N, E)) return STEMGNN_ERR_WORKSPACE;
+  unsigned char* w = reinterpret_cast<unsigned char*>(align_up(reinterpret_cast<uintptr_t>(workspace), 256));
+  int32_t *rp[2], *other[2], *eid[2];
+  const size_t e1 = static_cast<size_t>(E > 0 ? E : 1);
+  for (int k = 0; k < 2; ++k) {
+    rp[k] = reinterpret_cast<int32_t*>(w);
+    w += align_up((static_cast<size_t>(N) + 1) * 4, 256);
+    other[k] = reinterpret_cast<int32_t*>(w);
+    w += align_up(e1 * 4, 256);
+    eid[k] = reinterpret_cast<int32_t*>(w);
+    w += align_up(e1 * 4, 256);
+  }
+  int32_t* bad = reinterpret_cast<int32_t*>(w);
+  w += 256;
+  const size_t sort_bytes = stemgnn_csr_workspace_bytes(N, E);
+  for (int k = 0; k < 2; ++k) {
+    const int rc = stemgnn_csr_build(edge_index, E, N, k, rp[k], other[k], eid[k], bad, w, sort_bytes, stream_);
+    if (rc != STEMGNN_OK) return rc;
+  }
+  const int Di = static_cast<int>(D);
+  if (mode == 0)
+    STEMGNN_EDGE_DISPATCH_T(k_edge_bwd_det, false, N, rows, coef, g_scalar, N, Di, rp[0], other[0], eid[0], rp[1], other[1],
+                            eid[1], g_z);
+  else
+    STEMGNN_EDGE_DISPATCH_T(k_edge_bwd_det, true, N, rows, nullptr, nullptr, N, Di, rp[0], other[0], eid[0], rp[1],
+                            other[1], eid[1], g_z);
+  return STEMGNN_OK;
+}
+
+int stemgnn_edge_dot_bwd_det(const float* coef, const float* g_scalar, const float* z, int64_t N, int64_t D,
+                             const int64_t* edge_index, int64_t E, float* g_z, void* workspace,
+                             size_t workspace_bytes, void* stream_) {
+  if (E > 0 && !coef) return STEMGNN_ERR_INVALID_ARG;
+  return edge_bwd_det(0, z, coef, g_scalar, N, D, edge_index, E, g_z, workspace, workspace_bytes, stream_);
+}
+
+int stemgnn_edge_concat_bwd_det(const float* g_out, int64_t N, int64_t D, const int64_t* edge_index, int64_t E,
+                                float* g_z, void* workspace, size_t workspace_bytes, void* stream_) {
+  return edge_bwd_det(1, g_out, nullptr, nullptr, N, D, edge_index, E, g_z, workspace, workspace_bytes, stream_);
 }
 
 }  // extern "C"

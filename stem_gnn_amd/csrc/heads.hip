@@ -228,7 +228,7 @@ size_t stemgnn_heads_bwd_scratch_bytes(const stemgnn_heads_params* p, int64_t N,
   return a256(n1 * D * 4) + a256(k1 * D * 4) + a256(k1 * 2 * D * 4) + a256(b1 * I * 4) + 3 * a256(b1 * D * 4) +
          a256(stemgnn_linear_bwd_weight_workspace_bytes(N, D, D)) + a256(stemgnn_linear_bwd_weight_workspace_bytes(k, D, 2 * D)) +
          a256(stemgnn_linear_bwd_weight_workspace_bytes(bs, I, D)) + a256(stemgnn_linear_bwd_weight_workspace_bytes(bs, D, D)) +
-         2048;
+         a256(stemgnn_edge_det_workspace_bytes(N, 2 * k)) + 2048;
 }
 
 int stemgnn_heads_bwd(const stemgnn_heads_params* p, int64_t N, const float* q, const float* x_feat,
@@ -262,6 +262,11 @@ int stemgnn_heads_bwd(const stemgnn_heads_params* p, int64_t N, const float* q, 
   void* ws_ts = c.take<unsigned char>(wb_ts);
   void* ws_f = c.take<unsigned char>(wb_f);
   void* ws_s = c.take<unsigned char>(wb_s);
+  const size_t det_bytes = stemgnn_edge_det_workspace_bytes(N, 2 * k);
+  void* det_ws = c.take<unsigned char>(det_bytes);
+  // STEMGNN_DETERMINISTIC=1 / stemgnn_set_deterministic(1): the two scatters over sampled edges add in a fixed order
+  // (edges grouped by node, two sorts each) instead of with fp32 atomics -- bit-reproducible steps, ~0.15 ms slower
+  const bool det = stemgnn_set_deterministic(-1) == 1;
 
   const bool fork = lanes_on();
   hipStream_t s1 = fork ? ln->side[0] : s0, s2 = fork ? ln->side[1] : s0;
@@ -305,12 +310,17 @@ int stemgnn_heads_bwd(const stemgnn_heads_params* p, int64_t N, const float* q, 
   }
 
   // ---- lane A: topology head; its backward-data product lays down the dense gradient the other lanes add into
-  STEMGNN_TRY(zero_bytes(g_zl, static_cast<size_t>(N) * D * 4, s0));
-  STEMGNN_TRY(stemgnn_edge_dot_bwd_scaled(s.coef, g_losses + 1, s.zl, N, D, topo_edges, 2 * k, g_zl, s0));
+  if (det) {
+    STEMGNN_TRY(stemgnn_edge_dot_bwd_det(s.coef, g_losses + 1, s.zl, N, D, topo_edges, 2 * k, g_zl, det_ws, det_bytes, s0));
+  } else {
+    STEMGNN_TRY(zero_bytes(g_zl, static_cast<size_t>(N) * D * 4, s0));
+    STEMGNN_TRY(stemgnn_edge_dot_bwd_scaled(s.coef, g_losses + 1, s.zl, N, D, topo_edges, 2 * k, g_zl, s0));
+  }
   STEMGNN_TRY(stemgnn_linear_bwd_data(g_zl, p->w_topo, N, D, D, g_q, s0));
   STEMGNN_TRY(weight_grad(g_zl, q, N, D, D, p->g_w_topo, p->b_topo ? p->g_b_topo : nullptr, ws_t, wb_t, s0));
   if (fork) STEMGNN_HIP_TRY(hipStreamWaitEvent(s0, ln->done[0], 0));
-  STEMGNN_TRY(stemgnn_edge_concat_bwd(g_zz, N, D, ts_edges, k, g_q, s0));
+  if (det) STEMGNN_TRY(stemgnn_edge_concat_bwd_det(g_zz, N, D, ts_edges, k, g_q, det_ws, det_bytes, s0));
+  else STEMGNN_TRY(stemgnn_edge_concat_bwd(g_zz, N, D, ts_edges, k, g_q, s0));
   if (fork) STEMGNN_HIP_TRY(hipStreamWaitEvent(s0, ln->done[1], 0));
   {
     const int64_t n4 = bs * D / 4;

@@ -938,6 +938,45 @@ def test_vq_assign_weight_stationary_matches_the_tile_form(dev, N, H):
     assert int((i1 == 90).sum()) == 0 or bool(((i1 == 90) <= (ref != 17)).all())
 
 
+@pytest.mark.parametrize("n,e,d", [(300, 2000, 64), (1000, 9000, 128), (50, 0, 32), (40, 300, 256)])
+def test_deterministic_decoder_scatters_match_the_atomic_ones(dev, n, e, d):
+    """stemgnn_edge_dot_bwd_det / stemgnn_edge_concat_bwd_det (edges grouped by node, fixed order) against the atomic
+    scatters and torch; two runs return the same bits."""
+    from stem_gnn_amd._lib import lib, check
+    torch.manual_seed(n + e)
+    st = torch.cuda.current_stream().cuda_stream
+    ei = torch.randint(0, n, (2, e), device=dev)
+    z = torch.randn(n, d, device=dev)
+    coef, gs = torch.randn(max(e, 1), device=dev), torch.tensor([0.7], device=dev)
+    ws = torch.empty(int(lib.stemgnn_edge_det_workspace_bytes(n, e)), dtype=torch.uint8, device=dev)
+    outs = []
+    for _ in range(2):
+        g = torch.full((n, d), 7.0, device=dev)
+        check(lib.stemgnn_edge_dot_bwd_det(coef.data_ptr(), gs.data_ptr(), z.data_ptr(), n, d, ei.data_ptr(), e, g.data_ptr(),
+                                           ws.data_ptr(), ws.numel(), st))
+        outs.append(g)
+    assert torch.equal(outs[0], outs[1])
+    ref = torch.zeros(n, d, device=dev)
+    if e:
+        w = (coef[:e] * gs)[:, None]
+        ref.index_add_(0, ei[0], w * z[ei[1]])
+        ref.index_add_(0, ei[1], w * z[ei[0]])
+    torch.testing.assert_close(outs[0], ref, rtol=1e-4, atol=1e-4)
+    go = torch.randn(max(e, 1), 2 * d, device=dev)
+    base = torch.randn(n, d, device=dev)
+    outs = []
+    for _ in range(2):
+        g = base.clone()
+        check(lib.stemgnn_edge_concat_bwd_det(go.data_ptr(), n, d, ei.data_ptr(), e, g.data_ptr(), ws.data_ptr(), ws.numel(), st))
+        outs.append(g)
+    assert torch.equal(outs[0], outs[1])
+    ref = base.clone()
+    if e:
+        ref.index_add_(0, ei[0], go[:e, :d])
+        ref.index_add_(0, ei[1], go[:e, d:])
+    torch.testing.assert_close(outs[0], ref, rtol=1e-4, atol=1e-4)
+
+
 def test_linear_row_limited_output(dev):
     """stemgnn_linear_fwd_rows: rows past store_rows feed the column statistics but are not written."""
     from stem_gnn_amd._lib import lib, check
