@@ -542,6 +542,110 @@ k_linear_bwd_weight(const float* __restrict__ dy, const float* __restrict__ x, i
 // and a v_mfma_f32_32x32x16_bf16 lane wants 8 consecutive m: each thread stages a 4 (m) x 4 (n or k) micro-tile,
 // splits it and stores it transposed, so the LDS planes are [n][32 m] / [k][32 m] and the fragment reads are the
 // forward kernel's.  db comes from the staged registers (shuffle over the 8 lanes that share a column group).
+// The same segment sums with the work cut the other way (the form the step runs): a block owns 32 FEATURE columns and
+// four 128-code tiles (one per wave), so a chunk of g is read, cut and transposed ONCE per 32 columns instead of once
+// per code tile (four times at H = 4), and the one-hot operand never touches LDS -- a lane compares the eight row
+// assignments of its k-step (staged as int32 [head][rows]) with its own code and packs the result.  Same order of
+// additions within a split (the splits are cut at multiples of 128 rows here).
+__global__ void __launch_bounds__(kBlock, 2)
+k_code_segment_sums_cols(const int64_t* __restrict__ ind, int H, int K, const float* __restrict__ g, int64_t M, int D,
+                         int64_t rows_per_split, float* __restrict__ partial /*[S][H*K][D]*/) {
+  // a step is 128 rows: every wave cuts and transposes ITS 32-row chunk of g (four plane sets), then every wave
+  // multiplies all four chunks with its own code tile -- one pair of barriers per 128 rows
+  constexpr int PL = 32 * kLdP, kStep = 128;
+  __shared__ __attribute__((aligned(16))) unsigned char sB[4 * 3 * PL];  // [chunk][plane] g^T [32 d][32 m]
+  __shared__ __attribute__((aligned(16))) int s_ind[16 * kStep];         // [head][128 rows], H <= 16
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, lj = lane & 31;
+  const int split = blockIdx.x, d0 = blockIdx.y * 32;
+  const int NC = H * K;
+  const int cb = (blockIdx.z * 4 + wave) * 128;  // this wave's code tile
+  const int64_t mbeg = split * rows_per_split;
+  const int64_t mend = min(M, mbeg + rows_per_split);
+  const int steps = mend > mbeg ? static_cast<int>((mend - mbeg + kStep - 1) / kStep) : 0;
+  int ch[4], ck[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int c = cb + t * 32 + lj;
+    ch[t] = c < NC ? c / K : 0;
+    ck[t] = c < NC ? c % K : -7;  // never matches
+  }
+  const int mq = lane & 7, cq = lane >> 3;  // within the wave's chunk: rows 4 mq .. + 3, columns d0 + 4 cq .. + 3
+  float4 rb[4];
+  int ri[8];  // 128 H assignments per step over 256 threads: H / 2 each
+  auto fetch = [&](int step) {
+    const int64_t mm = mbeg + static_cast<int64_t>(step) * kStep;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t m = mm + 32 * wave + 4 * mq + i;
+      rb[i] = m < mend ? ld4(g + m * D + d0 + 4 * cq) : zero4();
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int idx = q * kBlock + tid;
+      ri[q] = -1;
+      if (idx < kStep * H) {
+        const int64_t m = mm + idx / H;
+        if (m < mend) ri[q] = static_cast<int>(ind[m * H + idx % H]);
+      }
+    }
+  };
+  floatx16 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  if (steps > 0) fetch(0);
+  for (int step = 0; step < steps; ++step) {
+    stash_transposed(rb, sB + wave * 3 * PL, PL, lane);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int idx = q * kBlock + tid;
+      if (idx < kStep * H) s_ind[(idx % H) * kStep + idx / H] = ri[q];
+    }
+    __syncthreads();
+    if (step + 1 < steps) fetch(step + 1);
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) {
+#pragma unroll
+      for (int ks = 0; ks < kKC / 16; ++ks) {
+        const int ko = ks * 32 + hi * 16;
+        bf16x8 b[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          b[p] = *reinterpret_cast<const bf16x8*>(sB + (c4 * 3 + p) * PL + lj * kLdP + ko);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int* iv = s_ind + ch[t] * kStep + c4 * 32 + ks * 16 + hi * 8;
+          const int4 i0 = *reinterpret_cast<const int4*>(iv);
+          const int4 i1 = *reinterpret_cast<const int4*>(iv + 4);
+          const uint32_t one = 0x3F80u;  // bf16 1.0
+          const int kk = ck[t];
+          const uint4 av = make_uint4((i0.x == kk ? one : 0u) | (i0.y == kk ? one << 16 : 0u),
+                                      (i0.z == kk ? one : 0u) | (i0.w == kk ? one << 16 : 0u),
+                                      (i1.x == kk ? one : 0u) | (i1.y == kk ? one << 16 : 0u),
+                                      (i1.z == kk ? one : 0u) | (i1.w == kk ? one << 16 : 0u));
+          const bf16x8 a = __builtin_bit_cast(bf16x8, av);
+          floatx16 c = acc[t];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[2], c, 0, 0, 0);  // small pieces first
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[0], c, 0, 0, 0);
+          acc[t] = c;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float* pw = partial + static_cast<int64_t>(split) * NC * D;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = cb + t * 32 + acc_row(r, hi);
+      if (n < NC) pw[static_cast<int64_t>(n) * D + d0 + lj] = acc[t][r];
+    }
+}
+
 // One launch serves several products (a phase's weight gradients): a block finds its job in a table passed by value.
 constexpr int kDwJobs = 8;
 struct DwJob {
@@ -1316,9 +1420,16 @@ int stemgnn_code_segment_sums(const int64_t* ind, int64_t H, int64_t K, const fl
   int64_t rows = (M + S - 1) / S;
   rows = (rows + kKC - 1) / kKC * kKC;
   float* pw = reinterpret_cast<float*>(align_up(reinterpret_cast<uintptr_t>(workspace), 256));
-  dim3 grid(static_cast<unsigned>(S), static_cast<unsigned>((NC + kBN - 1) / kBN), static_cast<unsigned>((D + kBN - 1) / kBN));
-  k_code_segment_sums<<<grid, kBlock, 0, st>>>(ind, static_cast<int>(H), static_cast<int>(K), g, M, static_cast<int>(D),
-                                               rows, pw);
+  if (D % 32 == 0 && H <= 16) {
+    rows = (rows + 127) / 128 * 128;  // its steps are 128 rows
+    dim3 grid(static_cast<unsigned>(S), static_cast<unsigned>(D / 32), static_cast<unsigned>((NC + 511) / 512));
+    k_code_segment_sums_cols<<<grid, kBlock, 0, st>>>(ind, static_cast<int>(H), static_cast<int>(K), g, M,
+                                                      static_cast<int>(D), rows, pw);
+  } else {
+    dim3 grid(static_cast<unsigned>(S), static_cast<unsigned>((NC + kBN - 1) / kBN), static_cast<unsigned>((D + kBN - 1) / kBN));
+    k_code_segment_sums<<<grid, kBlock, 0, st>>>(ind, static_cast<int>(H), static_cast<int>(K), g, M, static_cast<int>(D),
+                                                 rows, pw);
+  }
   STEMGNN_LAUNCH_CHECK();
   const int64_t nk = NC * D;
   const int blocks1 = static_cast<int>((nk / 4 + 15) / 16);
