@@ -224,6 +224,106 @@ k_ortho(const float* __restrict__ embed, const int64_t* __restrict__ ids, int H,
   }
 }
 
+// The same regulariser for the usual small selection (M <= 32 codes, Dc <= 256): ONE block per head keeps the
+// normalised selected rows in LDS, forms the M x M Gram matrix with all its threads and -- backward -- pushes
+// G C through the normalisation; it also clears the head's slice of the dense codebook gradient itself (no memset
+// launch).  The wave-per-row kernel above walks 32 dependent row pairs per wave: 15 us forward and backward; this one
+// is a few microseconds.  forward: partial[h] = sum_ij g_ij^2.
+template <bool BWD>
+__global__ void __launch_bounds__(256)
+k_ortho_block(const float* __restrict__ embed, const int64_t* __restrict__ ids, int H, int K, int Dc, int M, float scale,
+              const float* __restrict__ g, double* __restrict__ partial /*[H]*/, float* __restrict__ g_embed) {
+  constexpr int kMaxM = 32, kMaxD = 256;
+  __shared__ __attribute__((aligned(16))) float cs[kMaxM][kMaxD + 4];  // normalised rows
+  __shared__ float gm[kMaxM][kMaxM + 1];
+  __shared__ float s_inv[kMaxM];
+  __shared__ double red[256];
+  const int h = blockIdx.x, tid = threadIdx.x;
+  const float* eh = embed + static_cast<int64_t>(h) * K * Dc;
+  const int i = tid >> 3, part = tid & 7;  // 8 threads per row; thread covers columns part * 4 + 32 * v
+  const int nv = Dc / 4;                   // float4 per row
+  if (BWD) {  // clear the head's slice of the dense gradient (rows not selected stay zero)
+    float4* gz = reinterpret_cast<float4*>(g_embed + static_cast<int64_t>(h) * K * Dc);
+    for (int64_t q = tid; q < static_cast<int64_t>(K) * nv; q += 256) gz[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float ss = 0.f;
+  if (i < M) {
+    const float* er = eh + ids[i] * Dc;
+    for (int v = part; v < nv; v += 8) {
+      const float4 a = *reinterpret_cast<const float4*>(er + 4 * v);
+      *reinterpret_cast<float4*>(&cs[i][4 * v]) = a;
+      ss += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+    }
+  }
+  ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64);
+  const float inv_i = 1.0f / fmaxf(sqrtf(ss), kNormEps);
+  if (i < M) {
+    if (part == 0) s_inv[i] = inv_i;
+    for (int v = part; v < nv; v += 8) {
+      float4 a = *reinterpret_cast<float4*>(&cs[i][4 * v]);
+      a.x *= inv_i; a.y *= inv_i; a.z *= inv_i; a.w *= inv_i;
+      *reinterpret_cast<float4*>(&cs[i][4 * v]) = a;
+    }
+  }
+  __syncthreads();
+  // Gram entries (i, j = part * 4 + u), fixed order over the columns
+  double acc = 0.0;
+  if (i < M) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = part * 4 + u;
+      if (j < M) {
+        float d = 0.f;
+        for (int v = 0; v < nv; ++v) {
+          const float4 a = *reinterpret_cast<const float4*>(&cs[i][4 * v]);
+          const float4 b = *reinterpret_cast<const float4*>(&cs[j][4 * v]);
+          d += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+        }
+        gm[i][j] = d;
+        acc += static_cast<double>(d) * d;
+      }
+    }
+  }
+  if (!BWD) {
+    red[tid] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (tid < o) red[tid] += red[tid + o];
+      __syncthreads();
+    }
+    if (tid == 0) partial[h] = red[0];
+    return;
+  }
+  __syncthreads();
+  if (i >= M) return;
+  // d loss / d c_i = 4 scale / (H M^2) sum_j g_ij c_j, through c_i = e_i / |e_i|
+  const float coef = g[0] * scale * 4.0f / (static_cast<float>(H) * M * M);
+  float dotp = 0.f;
+  float* ge = g_embed + (static_cast<int64_t>(h) * K + ids[i]) * Dc;
+  for (int v = part; v < nv; v += 8) {
+    float4 gc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < M; ++j) {
+      const float w = gm[i][j];
+      const float4 b = *reinterpret_cast<const float4*>(&cs[j][4 * v]);
+      gc.x += w * b.x; gc.y += w * b.y; gc.z += w * b.z; gc.w += w * b.w;
+    }
+    const float4 c = *reinterpret_cast<const float4*>(&cs[i][4 * v]);
+    dotp += gc.x * c.x + gc.y * c.y + gc.z * c.z + gc.w * c.w;
+    *reinterpret_cast<float4*>(ge + 4 * v) = gc;  // parked; finished below (the thread re-reads its own stores)
+  }
+  dotp += __shfl_xor(dotp, 1, 64); dotp += __shfl_xor(dotp, 2, 64); dotp += __shfl_xor(dotp, 4, 64);
+  const float inv = s_inv[i];
+  for (int v = part; v < nv; v += 8) {
+    const float4 gc = *reinterpret_cast<const float4*>(ge + 4 * v);
+    const float4 c = *reinterpret_cast<const float4*>(&cs[i][4 * v]);
+    *reinterpret_cast<float4*>(ge + 4 * v) =
+        make_float4(coef * (gc.x - c.x * dotp) * inv, coef * (gc.y - c.y * dotp) * inv, coef * (gc.z - c.z * dotp) * inv,
+                    coef * (gc.w - c.w * dotp) * inv);
+  }
+}
+
+inline bool ortho_block_ok(int M, int Dc) { return M <= 32 && Dc <= 256 && Dc % 4 == 0; }
+
 template <bool BWD>
 void launch_ortho(int grid, hipStream_t st, const float* embed, const int64_t* ids, int H, int K, int Dc, int M,
                   float scale, const float* g, double* partial, float* g_embed) {
@@ -378,10 +478,17 @@ int stemgnn::ortho_loss_fwd_plus(const float* embed, const int64_t* ids, int64_t
   if (workspace_bytes < stemgnn_loss_workspace_bytes(heads * num_ids)) return STEMGNN_ERR_WORKSPACE;
   double* partial = reinterpret_cast<double*>(align_up(reinterpret_cast<uintptr_t>(workspace), 256));
   const int H = static_cast<int>(heads), M = static_cast<int>(num_ids);
-  launch_ortho<false>(H * M, st, embed, ids, H, static_cast<int>(codebook_size), static_cast<int>(code_dim), M, scale,
-                      nullptr, partial, nullptr);
+  int nparts = H * M;
+  if (ortho_block_ok(M, static_cast<int>(code_dim))) {
+    nparts = H;
+    k_ortho_block<false><<<H, 256, 0, st>>>(embed, ids, H, static_cast<int>(codebook_size), static_cast<int>(code_dim), M,
+                                            scale, nullptr, partial, nullptr);
+  } else {
+    launch_ortho<false>(H * M, st, embed, ids, H, static_cast<int>(codebook_size), static_cast<int>(code_dim), M, scale,
+                        nullptr, partial, nullptr);
+  }
   STEMGNN_LAUNCH_CHECK();
-  k_finish_sum<<<1, 256, 0, st>>>(partial, H * M, static_cast<double>(scale) / (static_cast<double>(H) * M * M),
+  k_finish_sum<<<1, 256, 0, st>>>(partial, nparts, static_cast<double>(scale) / (static_cast<double>(H) * M * M),
                                   -static_cast<double>(scale) / M, loss, plus, total);
   STEMGNN_LAUNCH_CHECK();
   return STEMGNN_OK;
@@ -403,8 +510,14 @@ int stemgnn_ortho_loss_bwd(const float* embed, const int64_t* ids, int64_t heads
   if (heads <= 0 || codebook_size <= 0 || code_dim <= 0 || code_dim > 64 * kOrthoMaxPerLane || num_ids <= 0 ||
       !embed || !ids || !g_loss || !g_embed)
     return STEMGNN_ERR_INVALID_ARG;
-  STEMGNN_HIP_TRY(hipMemsetAsync(g_embed, 0, sizeof(float) * heads * codebook_size * code_dim, st));
   const int H = static_cast<int>(heads), M = static_cast<int>(num_ids);
+  if (ortho_block_ok(M, static_cast<int>(code_dim))) {
+    k_ortho_block<true><<<H, 256, 0, st>>>(embed, ids, H, static_cast<int>(codebook_size), static_cast<int>(code_dim), M,
+                                           scale, g_loss, nullptr, g_embed);
+    STEMGNN_LAUNCH_CHECK();
+    return STEMGNN_OK;
+  }
+  STEMGNN_HIP_TRY(hipMemsetAsync(g_embed, 0, sizeof(float) * heads * codebook_size * code_dim, st));
   launch_ortho<true>(H * M, st, embed, ids, H, static_cast<int>(codebook_size), static_cast<int>(code_dim), M, scale,
                      g_loss, nullptr, g_embed);
   STEMGNN_LAUNCH_CHECK();
