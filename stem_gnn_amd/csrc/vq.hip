@@ -321,19 +321,42 @@ template <int G>
 __global__ void __launch_bounds__(kBlock)
 k_codes_project(const float* __restrict__ table, const int64_t* __restrict__ ind, const float* __restrict__ bias,
                 int64_t N, int H, int K, int D, float* __restrict__ out) {
+  // a lane group takes kRows rows (H <= 4: every code and every table row of the four in flight together; the walk
+  // row by row and head by head is a chain of two memory latencies per head); the sum runs in head order either way
+  constexpr int kRows = 4;
   const int lane = threadIdx.x % G;
-  const int64_t row = static_cast<int64_t>(blockIdx.x) * (kBlock / G) + threadIdx.x / G;
-  if (row >= N) return;
+  const int64_t row0 = (static_cast<int64_t>(blockIdx.x) * (kBlock / G) + threadIdx.x / G) * kRows;
+  if (row0 >= N) return;
   const int nvec = D / 4;
   for (int c = lane; c < nvec; c += G) {
-    float4 a = bias ? ld4(bias + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int h = 0; h < H; ++h) {
-      int64_t code = ind[row * H + h];
-      if (code < 0 || code >= K) code = 0;
-      const float4 v = ld4(table + (static_cast<int64_t>(h) * K + code) * D + 4 * c);
-      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    const float4 bv = bias ? ld4(bias + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 a[kRows];
+#pragma unroll
+    for (int r = 0; r < kRows; ++r) a[r] = bv;
+    for (int h0 = 0; h0 < H; h0 += 4) {
+      int64_t code[kRows][4];
+      float4 v[kRows][4];
+#pragma unroll
+      for (int r = 0; r < kRows; ++r)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) code[r][u] = (row0 + r < N && h0 + u < H) ? ind[(row0 + r) * H + h0 + u] : 0;
+#pragma unroll
+      for (int r = 0; r < kRows; ++r)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (code[r][u] < 0 || code[r][u] >= K) code[r][u] = 0;
+          v[r][u] = h0 + u < H ? ld4(table + (static_cast<int64_t>(h0 + u) * K + code[r][u]) * D + 4 * c)
+                               : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+      for (int r = 0; r < kRows; ++r)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (h0 + u < H) { a[r].x += v[r][u].x; a[r].y += v[r][u].y; a[r].z += v[r][u].z; a[r].w += v[r][u].w; }
     }
-    st4(out + row * D + 4 * c, a);
+#pragma unroll
+    for (int r = 0; r < kRows; ++r)
+      if (row0 + r < N) st4(out + (row0 + r) * D + 4 * c, a[r]);
   }
 }
 
@@ -675,9 +698,9 @@ int stemgnn_codes_project(const float* table, const int64_t* ind, const float* b
   if (N == 0) return STEMGNN_OK;
   if (!table || !ind || !out) return STEMGNN_ERR_INVALID_ARG;
   const int Hi = static_cast<int>(H), Ki = static_cast<int>(K), Di = static_cast<int>(D);
-  if (D / 4 <= 16) k_codes_project<16><<<static_cast<unsigned>((N + 15) / 16), kBlock, 0, st>>>(table, ind, bias, N, Hi, Ki, Di, out);
-  else if (D / 4 <= 32) k_codes_project<32><<<static_cast<unsigned>((N + 7) / 8), kBlock, 0, st>>>(table, ind, bias, N, Hi, Ki, Di, out);
-  else k_codes_project<64><<<static_cast<unsigned>((N + 3) / 4), kBlock, 0, st>>>(table, ind, bias, N, Hi, Ki, Di, out);
+  if (D / 4 <= 16) k_codes_project<16><<<static_cast<unsigned>((N + 63) / 64), kBlock, 0, st>>>(table, ind, bias, N, Hi, Ki, Di, out);
+  else if (D / 4 <= 32) k_codes_project<32><<<static_cast<unsigned>((N + 31) / 32), kBlock, 0, st>>>(table, ind, bias, N, Hi, Ki, Di, out);
+  else k_codes_project<64><<<static_cast<unsigned>((N + 15) / 16), kBlock, 0, st>>>(table, ind, bias, N, Hi, Ki, Di, out);
   STEMGNN_LAUNCH_CHECK();
   return STEMGNN_OK;
 }
