@@ -228,61 +228,70 @@ k_ortho(const float* __restrict__ embed, const int64_t* __restrict__ ids, int H,
 // normalised selected rows in LDS, forms the M x M Gram matrix with all its threads and -- backward -- pushes
 // G C through the normalisation; it also clears the head's slice of the dense codebook gradient itself (no memset
 // launch).  The wave-per-row kernel above walks 32 dependent row pairs per wave: 15 us forward and backward; this one
-// is a few microseconds.  forward: partial[h] = sum_ij g_ij^2.
+// is a few microseconds.  forward: partial[h][b] = sum over the block's rows i and all j of g_ij^2.
 template <bool BWD>
 __global__ void __launch_bounds__(256)
 k_ortho_block(const float* __restrict__ embed, const int64_t* __restrict__ ids, int H, int K, int Dc, int M, float scale,
-              const float* __restrict__ g, double* __restrict__ partial /*[H]*/, float* __restrict__ g_embed) {
+              const float* __restrict__ g, double* __restrict__ partial /*[H][4]*/, float* __restrict__ g_embed) {
+  // grid (heads, 4): block (h, b) owns selected rows 8 b .. 8 b + 7 -- a row per 32 lanes -- against all M rows
   constexpr int kMaxM = 32, kMaxD = 256;
   __shared__ __attribute__((aligned(16))) float cs[kMaxM][kMaxD + 4];  // normalised rows
-  __shared__ float gm[kMaxM][kMaxM + 1];
-  __shared__ float s_inv[kMaxM];
+  __shared__ float gm[8][kMaxM + 1];
   __shared__ double red[256];
   const int h = blockIdx.x, tid = threadIdx.x;
   const float* eh = embed + static_cast<int64_t>(h) * K * Dc;
-  const int i = tid >> 3, part = tid & 7;  // 8 threads per row; thread covers columns part * 4 + 32 * v
-  const int nv = Dc / 4;                   // float4 per row
-  if (BWD) {  // clear the head's slice of the dense gradient (rows not selected stay zero)
+  const int nv = Dc / 4;  // float4 per row (<= 64)
+  if (BWD) {
+    // clear this block's quarter of the head's slice of the dense gradient -- except the selected rows, which some
+    // block of the head writes (no order between blocks: a cleared row must never be a written one)
+    __shared__ int s_ids[kMaxM];
+    if (tid < M) s_ids[tid] = static_cast<int>(ids[tid]);
+    __syncthreads();
     float4* gz = reinterpret_cast<float4*>(g_embed + static_cast<int64_t>(h) * K * Dc);
-    for (int64_t q = tid; q < static_cast<int64_t>(K) * nv; q += 256) gz[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  float ss = 0.f;
-  if (i < M) {
-    const float* er = eh + ids[i] * Dc;
-    for (int v = part; v < nv; v += 8) {
-      const float4 a = *reinterpret_cast<const float4*>(er + 4 * v);
-      *reinterpret_cast<float4*>(&cs[i][4 * v]) = a;
-      ss += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+    const int64_t total = static_cast<int64_t>(K) * nv, q0 = total * blockIdx.y / 4, q1 = total * (blockIdx.y + 1) / 4;
+    for (int64_t q = q0 + tid; q < q1; q += 256) {
+      const int row = static_cast<int>(q / nv);
+      bool selected = false;
+      for (int j = 0; j < M; ++j) selected |= s_ids[j] == row;
+      if (!selected) gz[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
-  ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64);
-  const float inv_i = 1.0f / fmaxf(sqrtf(ss), kNormEps);
-  if (i < M) {
-    if (part == 0) s_inv[i] = inv_i;
-    for (int v = part; v < nv; v += 8) {
-      float4 a = *reinterpret_cast<float4*>(&cs[i][4 * v]);
-      a.x *= inv_i; a.y *= inv_i; a.z *= inv_i; a.w *= inv_i;
-      *reinterpret_cast<float4*>(&cs[i][4 * v]) = a;
+  {  // all M rows, normalised: 8 threads per row
+    const int r = tid >> 3, part = tid & 7;
+    float ss = 0.f;
+    if (r < M) {
+      const float* er = eh + ids[r] * Dc;
+      for (int v = part; v < nv; v += 8) {
+        const float4 a = *reinterpret_cast<const float4*>(er + 4 * v);
+        *reinterpret_cast<float4*>(&cs[r][4 * v]) = a;
+        ss += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+      }
+    }
+    ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64);
+    const float inv = 1.0f / fmaxf(sqrtf(ss), kNormEps);
+    if (r < M) {
+      for (int v = part; v < nv; v += 8) {
+        float4 a = *reinterpret_cast<float4*>(&cs[r][4 * v]);
+        a.x *= inv; a.y *= inv; a.z *= inv; a.w *= inv;
+        *reinterpret_cast<float4*>(&cs[r][4 * v]) = a;
+      }
+      if (part == 0) cs[r][kMaxD] = inv;  // the spare column keeps 1 / |e_r|
     }
   }
   __syncthreads();
-  // Gram entries (i, j = part * 4 + u), fixed order over the columns
+  const int il = tid >> 5, lane = tid & 31;  // local row, lane of the row's 32
+  const int i = blockIdx.y * 8 + il;
+  // Gram entry (i, j = lane), fixed order over the columns
   double acc = 0.0;
-  if (i < M) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int j = part * 4 + u;
-      if (j < M) {
-        float d = 0.f;
-        for (int v = 0; v < nv; ++v) {
-          const float4 a = *reinterpret_cast<const float4*>(&cs[i][4 * v]);
-          const float4 b = *reinterpret_cast<const float4*>(&cs[j][4 * v]);
-          d += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
-        }
-        gm[i][j] = d;
-        acc += static_cast<double>(d) * d;
-      }
+  if (i < M && lane < M) {
+    float d = 0.f;
+    for (int v = 0; v < nv; ++v) {
+      const float4 a = *reinterpret_cast<const float4*>(&cs[i][4 * v]);
+      const float4 b = *reinterpret_cast<const float4*>(&cs[lane][4 * v]);
+      d += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
     }
+    gm[il][lane] = d;
+    acc = static_cast<double>(d) * d;
   }
   if (!BWD) {
     red[tid] = acc;
@@ -291,38 +300,45 @@ k_ortho_block(const float* __restrict__ embed, const int64_t* __restrict__ ids, 
       if (tid < o) red[tid] += red[tid + o];
       __syncthreads();
     }
-    if (tid == 0) partial[h] = red[0];
+    if (tid == 0) partial[h * 4 + blockIdx.y] = red[0];
     return;
   }
   __syncthreads();
   if (i >= M) return;
-  // d loss / d c_i = 4 scale / (H M^2) sum_j g_ij c_j, through c_i = e_i / |e_i|
+  // d loss / d c_i = 4 scale / (H M^2) sum_j g_ij c_j, through c_i = e_i / |e_i|; a lane holds columns 4 lane (+ 128)
   const float coef = g[0] * scale * 4.0f / (static_cast<float>(H) * M * M);
+  float4 gc[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
   float dotp = 0.f;
-  float* ge = g_embed + (static_cast<int64_t>(h) * K + ids[i]) * Dc;
-  for (int v = part; v < nv; v += 8) {
-    float4 gc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int j = 0; j < M; ++j) {
-      const float w = gm[i][j];
-      const float4 b = *reinterpret_cast<const float4*>(&cs[j][4 * v]);
-      gc.x += w * b.x; gc.y += w * b.y; gc.z += w * b.z; gc.w += w * b.w;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int v = lane + 32 * u;
+    if (v < nv) {
+      for (int j = 0; j < M; ++j) {
+        const float w = gm[il][j];
+        const float4 b = *reinterpret_cast<const float4*>(&cs[j][4 * v]);
+        gc[u].x += w * b.x; gc[u].y += w * b.y; gc[u].z += w * b.z; gc[u].w += w * b.w;
+      }
+      const float4 c = *reinterpret_cast<const float4*>(&cs[i][4 * v]);
+      dotp += gc[u].x * c.x + gc[u].y * c.y + gc[u].z * c.z + gc[u].w * c.w;
     }
-    const float4 c = *reinterpret_cast<const float4*>(&cs[i][4 * v]);
-    dotp += gc.x * c.x + gc.y * c.y + gc.z * c.z + gc.w * c.w;
-    *reinterpret_cast<float4*>(ge + 4 * v) = gc;  // parked; finished below (the thread re-reads its own stores)
   }
-  dotp += __shfl_xor(dotp, 1, 64); dotp += __shfl_xor(dotp, 2, 64); dotp += __shfl_xor(dotp, 4, 64);
-  const float inv = s_inv[i];
-  for (int v = part; v < nv; v += 8) {
-    const float4 gc = *reinterpret_cast<const float4*>(ge + 4 * v);
-    const float4 c = *reinterpret_cast<const float4*>(&cs[i][4 * v]);
-    *reinterpret_cast<float4*>(ge + 4 * v) =
-        make_float4(coef * (gc.x - c.x * dotp) * inv, coef * (gc.y - c.y * dotp) * inv, coef * (gc.z - c.z * dotp) * inv,
-                    coef * (gc.w - c.w * dotp) * inv);
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) dotp += __shfl_xor(dotp, o, 64);
+  const float inv = cs[i][kMaxD];
+  float* ge = g_embed + (static_cast<int64_t>(h) * K + ids[i]) * Dc;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int v = lane + 32 * u;
+    if (v < nv) {
+      const float4 c = *reinterpret_cast<const float4*>(&cs[i][4 * v]);
+      *reinterpret_cast<float4*>(ge + 4 * v) =
+          make_float4(coef * (gc[u].x - c.x * dotp) * inv, coef * (gc[u].y - c.y * dotp) * inv,
+                      coef * (gc[u].z - c.z * dotp) * inv, coef * (gc[u].w - c.w * dotp) * inv);
+    }
   }
 }
 
-inline bool ortho_block_ok(int M, int Dc) { return M <= 32 && Dc <= 256 && Dc % 4 == 0; }
+inline bool ortho_block_ok(int M, int Dc) { return M >= 4 && M <= 32 && Dc <= 256 && Dc % 4 == 0; }
 
 template <bool BWD>
 void launch_ortho(int grid, hipStream_t st, const float* embed, const int64_t* ids, int H, int K, int Dc, int M,
@@ -480,8 +496,8 @@ int stemgnn::ortho_loss_fwd_plus(const float* embed, const int64_t* ids, int64_t
   const int H = static_cast<int>(heads), M = static_cast<int>(num_ids);
   int nparts = H * M;
   if (ortho_block_ok(M, static_cast<int>(code_dim))) {
-    nparts = H;
-    k_ortho_block<false><<<H, 256, 0, st>>>(embed, ids, H, static_cast<int>(codebook_size), static_cast<int>(code_dim), M,
+    nparts = 4 * H;
+    k_ortho_block<false><<<dim3(H, 4), 256, 0, st>>>(embed, ids, H, static_cast<int>(codebook_size), static_cast<int>(code_dim), M,
                                             scale, nullptr, partial, nullptr);
   } else {
     launch_ortho<false>(H * M, st, embed, ids, H, static_cast<int>(codebook_size), static_cast<int>(code_dim), M, scale,
@@ -512,7 +528,7 @@ int stemgnn_ortho_loss_bwd(const float* embed, const int64_t* ids, int64_t heads
     return STEMGNN_ERR_INVALID_ARG;
   const int H = static_cast<int>(heads), M = static_cast<int>(num_ids);
   if (ortho_block_ok(M, static_cast<int>(code_dim))) {
-    k_ortho_block<true><<<H, 256, 0, st>>>(embed, ids, H, static_cast<int>(codebook_size), static_cast<int>(code_dim), M,
+    k_ortho_block<true><<<dim3(H, 4), 256, 0, st>>>(embed, ids, H, static_cast<int>(codebook_size), static_cast<int>(code_dim), M,
                                            scale, g_loss, nullptr, g_embed);
     STEMGNN_LAUNCH_CHECK();
     return STEMGNN_OK;
