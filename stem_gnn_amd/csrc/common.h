@@ -144,6 +144,21 @@ __device__ __forceinline__ floatx16 mfma_x3(const bf16x8 (&a)[3], const bf16x8 (
   return c;
 }
 
+// the same when one operand IS a bf16 value (bf16 feature storage): its m and l pieces are zero, three products remain
+// (the skipped ones would add exact zeros)
+__device__ __forceinline__ floatx16 mfma_x3_a1(const bf16x8& ah, const bf16x8 (&b)[3], floatx16 c) {
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b[2], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b[1], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b[0], c, 0, 0, 0);
+  return c;
+}
+__device__ __forceinline__ floatx16 mfma_x3_b1(const bf16x8 (&a)[3], const bf16x8& bh, floatx16 c) {
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], bh, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bh, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bh, c, 0, 0, 0);
+  return c;
+}
+
 // csrc/wsgemm.hip: the weight-stationary dense product (K == 128): rows row_base.. of  y = x w^T + b  (bt: y = x w with w
 // given as [K][N]); stats_partial[stats_block0 + tile][2][N] takes the column sums / sums of squares per 128-row tile
 bool linear_ws_ok(int64_t M, int64_t N, int64_t K);

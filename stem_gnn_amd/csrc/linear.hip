@@ -280,12 +280,12 @@ k_linear_fwd_x3(const float* __restrict__ x1, const float* __restrict__ w1, int 
         *reinterpret_cast<uint2*>(sB + 2 * PB + off) = l;
       }
       if (t < FA) {
-        if (X2K == kBF16 && held_bf16) {  // four bf16 values ARE the h plane of their fp32 widening; m = l = 0
-          h = make_uint2(__float_as_uint(ra[t].x), __float_as_uint(ra[t].y));
-          m = l = make_uint2(0u, 0u);
-        } else {
-          split3(ra[t], h, m, l);
+        if (X2K == kBF16 && held_bf16) {  // four bf16 values ARE the h plane of their fp32 widening; m = l = 0 and
+          // never read (the matrix loop takes the one-piece form for these chunks)
+          *reinterpret_cast<uint2*>(sA + off) = make_uint2(__float_as_uint(ra[t].x), __float_as_uint(ra[t].y));
+          continue;
         }
+        split3(ra[t], h, m, l);
         *reinterpret_cast<uint2*>(sA + off) = h;
         *reinterpret_cast<uint2*>(sA + PA + off) = m;
         *reinterpret_cast<uint2*>(sA + 2 * PA + off) = l;
@@ -320,19 +320,30 @@ k_linear_fwd_x3(const float* __restrict__ x1, const float* __restrict__ w1, int 
     for (int ks = 0; ks < kKC / 16; ++ks) {
       const int ko = ks * 32 + hi * 16;  // bytes: lane half 0 takes k 0..7, half 1 k 8..15 of the 16-wide step
       bf16x8 a[TM][3], b[TN][3];
+      // chunks of a bf16-stored second operand carry one piece (stash() left the m / l planes alone): three products
+      const bool one_piece = X2K == kBF16 && step >= c1;  // block-uniform
 #pragma unroll
       for (int p = 0; p < 3; ++p) {
+        if (!(one_piece && p > 0)) {
 #pragma unroll
-        for (int t = 0; t < TM; ++t)
-          a[t][p] = *reinterpret_cast<const bf16x8*>(sA + p * PA + (wm * 32 * TM + t * 32 + lj) * kLdP + ko);
+          for (int t = 0; t < TM; ++t)
+            a[t][p] = *reinterpret_cast<const bf16x8*>(sA + p * PA + (wm * 32 * TM + t * 32 + lj) * kLdP + ko);
+        }
 #pragma unroll
         for (int t = 0; t < TN; ++t)
           b[t][p] = *reinterpret_cast<const bf16x8*>(sB + p * PB + (wn * 32 * TN + t * 32 + lj) * kLdP + ko);
       }
+      if (one_piece) {
 #pragma unroll
-      for (int tm = 0; tm < TM; ++tm)
+        for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma_x3(a[tm], b[tn], acc[tm][tn]);
+          for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma_x3_a1(a[tm][0], b[tn], acc[tm][tn]);
+      } else {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma_x3(a[tm], b[tn], acc[tm][tn]);
+      }
     }
     __syncthreads();
   }
@@ -749,7 +760,9 @@ k_linear_bwd_weight_x3(const DwTable tab) {
 #pragma unroll
       for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
-        for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = mfma_x3(a[ti], b[tj], acc[ti][tj]);
+        for (int tj = 0; tj < 2; ++tj)
+          acc[ti][tj] = XK == kBF16 ? mfma_x3_b1(a[ti], b[tj][0], acc[ti][tj])  // a bf16-stored x is its own h piece
+                                    : mfma_x3(a[ti], b[tj], acc[ti][tj]);
     }
     __syncthreads();
   }
