@@ -432,6 +432,10 @@ k_vq_assign_bwd(const float* __restrict__ g_quant, const float* __restrict__ g_l
   }
 }
 
+// LDS of k_vq_assign_bwd_fused: six operand planes of a chunk (61 440 B) during the product, then the whole 128 x 128
+// fp32 tile, rows padded by four floats (67 584 B); two blocks per CU either way
+constexpr int kFusedLds = 128 * (128 + 4) * 4;
+
 // staging row of float4 slot idx (8 slots per row): the rows of every group of eight in the order 0 4 1 5 2 6 3 7, so
 // that the two rows one ds_write_b64 group covers share no LDS bank (as in csrc/linear.hip)
 __device__ __forceinline__ int stage_row8(int idx) {
@@ -450,16 +454,22 @@ __global__ void __launch_bounds__(kBlock, 2)
 k_vq_assign_bwd_fused(const float* __restrict__ g_out, int D, const float* __restrict__ w_out /*[D][H*Dc]*/,
                       const float* __restrict__ g_loss, float coef, const float* __restrict__ xp,
                       const float* __restrict__ norm, const int64_t* __restrict__ ind, const float* __restrict__ embed,
-                      int64_t N, int H, int Dc, int K, float* __restrict__ g_xp, int hpt) {
+                      int64_t N, int H, int Dc, int K, float* __restrict__ g_xp, int hpt, int col_tiles) {
   constexpr int BM = 128, BN = 128;
   constexpr int PA = BM * kLdP, PB = BN * kLdP;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[3 * PA + 3 * PB];
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // kFusedLds bytes: planes, then the fp32 tile
   unsigned char* const sA = smem;
   unsigned char* const sB = smem + 3 * PA;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, hi = lane >> 5, lj = lane & 31;
-  const int h0 = blockIdx.y * hpt;  // first head of the tile
-  const int64_t m0 = static_cast<int64_t>(blockIdx.x) * BM;
+  // 1-D grid, XCD-aware: blocks are dealt round-robin over the 8 XCDs (b and b + 8 share one and its L2), so the column
+  // tiles of ONE row tile are made blocks b, b + 8, b + 16, ... -- the row tile of g_out is fetched into that L2 once
+  // instead of once per head from memory (447 MB read per launch for 262 algorithmic before)
+  const int b = blockIdx.x, bgrp = b / (8 * col_tiles), r = b % (8 * col_tiles);
+  const int64_t row_tile = static_cast<int64_t>(bgrp) * 8 + (r % 8);
+  if (row_tile * BM >= N) return;  // the grid is rounded up to whole groups
+  const int h0 = (r / 8) * hpt;  // first head of the tile
+  const int64_t m0 = row_tile * BM;
   const int64_t HD = static_cast<int64_t>(H) * Dc;
   const int c0 = h0 * Dc;                                    // first column of the tile
   const int ncols = min(hpt * Dc, static_cast<int>(HD) - c0);  // live columns of the tile
@@ -538,6 +548,63 @@ k_vq_assign_bwd_fused(const float* __restrict__ g_out, int D, const float* __res
   const int hl = col_ok ? h0 + (4 * l32) / Dc : h0;  // the head of this lane's four columns
   const int cl = 4 * l32 - (hl - h0) * Dc;           // ... and their place in the head
   const int lph = hpt > 1 ? Dc / 4 : 32;             // lanes that share a head (a power of two when hpt > 1)
+  if (m0 + BM <= N && ncols == BN) {
+    // ---- whole tiles (all but the last row tile): every load and store unconditional, so the waits are counted
+    // (one predicated operation between a load and its use makes every wait a vmcnt(0), csrc/wsgemm.hip), and
+    // everything the 16 rows of a lane group need -- codes, norms, xp rows, code rows -- is in flight before the one
+    // barrier: the whole 128-row tile is staged at once (the accumulators' registers go to the operands), the memory
+    // being sized for it.  (SQ counters before: 0.48 of the wave cycles at a s_waitcnt.)
+    int code[16];
+    float nrm[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int64_t m = m0 + (i >> 3) * 64 + (i & 7) * 8 + grp;
+      code[i] = static_cast<int>(ind[m * H + hl]);
+      nrm[i] = norm[m * H + hl];
+    }
+    float4 xv[16], qv[16];
+    const float* xrow = xp + (m0 + grp) * HD + c0 + 4 * l32;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) xv[i] = ld4(xrow + static_cast<int64_t>((i >> 3) * 64 + (i & 7) * 8) * HD);
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          tile[(wm * 64 + tm * 32 + 4 * hi + (r & 3) + 8 * (r >> 2)) * kLdT + wn * 64 + tn * 32 + lj] = acc[tm][tn][r];
+    const float* erow = embed + static_cast<int64_t>(hl) * K * Dc + cl;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      int c = code[i];
+      if (c < 0 || c >= K) c = 0;
+      qv[i] = ld4(erow + static_cast<int64_t>(c) * Dc);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int rl = (i >> 3) * 64 + (i & 7) * 8 + grp;
+      const float nr = nrm[i];
+      const bool clamped = nr < kNormEps;
+      const float inv = 1.0f / fmaxf(nr, kNormEps);
+      const float4 gq = ld4(tile + rl * kLdT + 4 * l32);
+      const float4 xq = xv[i], q = qv[i];
+      const float4 n = make_float4(xq.x * inv, xq.y * inv, xq.z * inv, xq.w * inv);
+      const float4 gx = make_float4(gq.x + s * (n.x - q.x), gq.y + s * (n.y - q.y), gq.z + s * (n.z - q.z),
+                                    gq.w + s * (n.w - q.w));
+      float dot = gx.x * n.x + gx.y * n.y + gx.z * n.z + gx.w * n.w;
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) {
+        const float other = __shfl_xor(dot, o, 32);
+        if (o < lph) dot += other;
+      }
+      if (clamped) dot = 0.f;
+      st4(g_xp + (m0 + rl) * HD + c0 + 4 * l32,
+          make_float4((gx.x - n.x * dot) * inv, (gx.y - n.y * dot) * inv, (gx.z - n.z * dot) * inv,
+                      (gx.w - n.w * dot) * inv));
+    }
+    return;
+  }
   int64_t code[16];
   float nrm[16];
 #pragma unroll
@@ -791,9 +858,15 @@ int stemgnn_vq_assign_bwd_fused(const float* g_out, int64_t D, const float* w_ou
   const float coef = commit_weight * 2.0f / static_cast<float>(static_cast<double>(N) * H * Dc);
   // heads per 128-column tile: whole heads when Dc divides 128 (then Dc / 4 lanes per head is a power of two)
   const int hpt = (128 % Dc == 0) ? static_cast<int>(std::min<int64_t>(H, 128 / Dc)) : 1;
-  dim3 grid(static_cast<unsigned>(row_blocks(N)), static_cast<unsigned>((H + hpt - 1) / hpt));
-  k_vq_assign_bwd_fused<<<grid, kBlock, 0, st>>>(g_out, static_cast<int>(D), w_out, g_loss, coef, xp, norm, ind, embed, N,
-                                                 static_cast<int>(H), static_cast<int>(Dc), static_cast<int>(K), g_xp, hpt);
+  const int col_tiles = static_cast<int>((H + hpt - 1) / hpt);
+  const int64_t groups = (row_blocks(N) + 7) / 8;  // 8 row tiles (one per XCD) x col_tiles blocks each
+  if (groups * 8 * col_tiles >= (1ll << 31)) return STEMGNN_ERR_TOO_LARGE;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_vq_assign_bwd_fused),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, kFusedLds);
+  if (attr != hipSuccess) return STEMGNN_ERR_HIP;
+  k_vq_assign_bwd_fused<<<static_cast<unsigned>(groups * 8 * col_tiles), kBlock, kFusedLds, st>>>(
+      g_out, static_cast<int>(D), w_out, g_loss, coef, xp, norm, ind, embed, N, static_cast<int>(H), static_cast<int>(Dc),
+      static_cast<int>(K), g_xp, hpt, col_tiles);
   STEMGNN_LAUNCH_CHECK();
   return STEMGNN_OK;
 }
