@@ -204,8 +204,36 @@ k_mask_columns(const float* __restrict__ x, int64_t N, int D, float p, uint64_t 
                float* __restrict__ out, int kind) {
   const int nvec = D / 4;
   const int64_t total = N * nvec;
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < total;
-       i += static_cast<int64_t>(gridDim.x) * kThreads) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kThreads;
+  const int64_t i0 = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+  if (stride % nvec == 0) {
+    // the mask is a function of the COLUMN, and with this stride a thread stays on one column group: one Philox block
+    // per thread instead of one per element (the generator was most of the kernel's instructions)
+    uint32_t r[4];
+    Philox::gen(seed, offset, static_cast<uint64_t>(i0 % nvec), r);
+    const bool z0 = Philox::to_unit(r[0]) < p, z1 = Philox::to_unit(r[1]) < p, z2 = Philox::to_unit(r[2]) < p,
+               z3 = Philox::to_unit(r[3]) < p;
+    int64_t i = i0;
+    for (; i + stride < total; i += 2 * stride) {  // two rows in flight
+      float4 v = ld4_kind(x, 4 * i, kind), w = ld4_kind(x, 4 * (i + stride), kind);
+      if (z0) v.x = w.x = 0.f;
+      if (z1) v.y = w.y = 0.f;
+      if (z2) v.z = w.z = 0.f;
+      if (z3) v.w = w.w = 0.f;
+      st4_kind(out, 4 * i, kind, v);  // a bf16 value masked or kept is still a bf16 value: no rounding happens
+      st4_kind(out, 4 * (i + stride), kind, w);
+    }
+    if (i < total) {
+      float4 v = ld4_kind(x, 4 * i, kind);
+      if (z0) v.x = 0.f;
+      if (z1) v.y = 0.f;
+      if (z2) v.z = 0.f;
+      if (z3) v.w = 0.f;
+      st4_kind(out, 4 * i, kind, v);
+    }
+    return;
+  }
+  for (int64_t i = i0; i < total; i += stride) {
     const int c = static_cast<int>(i % nvec);
     uint32_t r[4];
     Philox::gen(seed, offset, static_cast<uint64_t>(c), r);
@@ -300,6 +328,12 @@ int stemgnn_mask_columns(const float* x, int64_t N, int64_t D, float p, uint64_t
   if (!x || !out) return STEMGNN_ERR_INVALID_ARG;
   int64_t g = (N * (D / 4) + kThreads - 1) / kThreads;
   if (g > 4096) g = 4096;
+  {  // a grid stride that is a multiple of the row length keeps a thread on one column group (see the kernel)
+    int64_t a = D / 4, b = kThreads;
+    while (b) { const int64_t t = a % b; a = b; b = t; }
+    const int64_t m = (D / 4) / a;
+    if (g >= m) g = g / m * m;
+  }
   k_mask_columns<<<static_cast<unsigned>(g), kThreads, 0, static_cast<hipStream_t>(stream_)>>>(
       x, N, static_cast<int>(D), p, seed, offset, out, kF32);
   STEMGNN_LAUNCH_CHECK();
@@ -313,6 +347,12 @@ int stemgnn_mask_columns_k(const void* x, int32_t kind, int64_t N, int64_t D, fl
   if (!x || !out) return STEMGNN_ERR_INVALID_ARG;
   int64_t g = (N * (D / 4) + kThreads - 1) / kThreads;
   if (g > 4096) g = 4096;
+  {  // a grid stride that is a multiple of the row length keeps a thread on one column group (see the kernel)
+    int64_t a = D / 4, b = kThreads;
+    while (b) { const int64_t t = a % b; a = b; b = t; }
+    const int64_t m = (D / 4) / a;
+    if (g >= m) g = g / m * m;
+  }
   k_mask_columns<<<static_cast<unsigned>(g), kThreads, 0, static_cast<hipStream_t>(stream_)>>>(
       static_cast<const float*>(x), N, static_cast<int>(D), p, seed, offset, static_cast<float*>(out), kind);
   STEMGNN_LAUNCH_CHECK();
