@@ -13,7 +13,7 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kMaxPartialBlocks = 512;
-constexpr int kFinCols = 4;     // finalize: 4 columns x 64 partial slices per 256-thread block
+constexpr int kFinCols = 1;     // finalize: 1 column x 256 partial slices per 256-thread block
 constexpr int kFinSlices = kBlock / kFinCols;
 
 __device__ inline float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
