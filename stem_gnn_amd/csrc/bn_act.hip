@@ -221,13 +221,26 @@ k_apply(const float* __restrict__ y, const float* __restrict__ g_out, int64_t N,
   const int nvec = D / 4;
   const int64_t total = N * nvec;
   const float inv_n = 1.0f / static_cast<float>(N);
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < total;
-       i += static_cast<int64_t>(gridDim.x) * kBlock) {
-    const int c = static_cast<int>(i % nvec);
-    const float4 v = ld4(y + 4 * i);
-    float4 m = make_float4(0.f, 0.f, 0.f, 0.f), rs = make_float4(1.f, 1.f, 1.f, 1.f), ga = rs, be = m;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  const int64_t i0 = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  // with a stride that is a multiple of the row length (elementwise_grid) a thread stays on one column group: its
+  // per-column parameters are loaded once, not once per element (and no 64-bit modulo per element)
+  const bool fixed_col = stride % nvec == 0;
+  int c = static_cast<int>(i0 % nvec);
+  float4 m = make_float4(0.f, 0.f, 0.f, 0.f), rs = make_float4(1.f, 1.f, 1.f, 1.f), ga = rs, be = m;
+  float4 s1 = m, s2 = m;
+  auto load_params = [&]() {
     if (mean) { m = ld4(mean + 4 * c); rs = ld4(rstd + 4 * c); }
     if (gamma) { ga = ld4(gamma + 4 * c); be = ld4(beta + 4 * c); }
+    if (BWD && mean) { s1 = ld4(sum_gb + 4 * c); s2 = ld4(sum_gbx + 4 * c); }
+  };
+  if (i0 < total) load_params();
+  for (int64_t i = i0; i < total; i += stride) {
+    if (!fixed_col) {
+      c = static_cast<int>(i % nvec);
+      load_params();
+    }
+    const float4 v = ld4(y + 4 * i);
     bool keep[4];
     keep4(ep, static_cast<uint64_t>(i), keep);
     const float vv[4] = {v.x, v.y, v.z, v.w};
@@ -244,12 +257,7 @@ k_apply(const float* __restrict__ y, const float* __restrict__ g_out, int64_t N,
     } else {
       const float4 g = ld4(g_out + 4 * i);
       const float gg[4] = {g.x, g.y, g.z, g.w};
-      float sb[4] = {0.f, 0.f, 0.f, 0.f}, sx[4] = {0.f, 0.f, 0.f, 0.f};
-      if (mean) {
-        const float4 s1 = ld4(sum_gb + 4 * c), s2 = ld4(sum_gbx + 4 * c);
-        sb[0] = s1.x; sb[1] = s1.y; sb[2] = s1.z; sb[3] = s1.w;
-        sx[0] = s2.x; sx[1] = s2.y; sx[2] = s2.z; sx[3] = s2.w;
-      }
+      const float sb[4] = {s1.x, s1.y, s1.z, s1.w}, sx[4] = {s2.x, s2.y, s2.z, s2.w};
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const float xh = (vv[k] - mm[k]) * rr[k];
@@ -282,9 +290,15 @@ inline Epilogue make_epilogue(int act, float slope, float p, uint64_t seed, uint
   return ep;
 }
 
-inline int elementwise_grid(int64_t nvec_total) {
+inline int elementwise_grid(int64_t nvec_total, int64_t nvec_row = 1) {
   int64_t g = (nvec_total + kBlock - 1) / kBlock;
   if (g > 256 * 16) g = 256 * 16;
+  // a grid stride that is a multiple of the row length keeps a thread on one column group: k_apply then loads the
+  // per-column parameters once instead of once per element
+  int64_t a = nvec_row, b = kBlock;
+  while (b) { const int64_t t = a % b; a = b; b = t; }
+  const int64_t m = nvec_row / a;
+  if (g >= m) g = g / m * m;
   return static_cast<int>(g < 1 ? 1 : g);
 }
 
@@ -345,7 +359,7 @@ int stemgnn_bn_act_drop_fwd(const float* y, int64_t N, int64_t D, const float* m
   if (N == 0) return STEMGNN_OK;
   if (!y || !out) return STEMGNN_ERR_INVALID_ARG;
   Epilogue ep = make_epilogue(act, negative_slope, p, seed, offset);
-  k_apply<false><<<elementwise_grid(N * (D / 4)), kBlock, 0, st>>>(y, nullptr, N, static_cast<int>(D), mean, rstd,
+  k_apply<false><<<elementwise_grid(N * (D / 4), D / 4), kBlock, 0, st>>>(y, nullptr, N, static_cast<int>(D), mean, rstd,
                                                                   gamma, beta, nullptr, nullptr, ep, out, kF32);
   STEMGNN_LAUNCH_CHECK();
   return STEMGNN_OK;
@@ -361,7 +375,7 @@ int stemgnn_bn_act_drop_fwd_k(const float* y, int64_t N, int64_t D, const float*
   if (N == 0) return STEMGNN_OK;
   if (!y || !out) return STEMGNN_ERR_INVALID_ARG;
   Epilogue ep = make_epilogue(act, negative_slope, p, seed, offset);
-  k_apply<false><<<elementwise_grid(N * (D / 4)), kBlock, 0, st>>>(y, nullptr, N, static_cast<int>(D), mean, rstd,
+  k_apply<false><<<elementwise_grid(N * (D / 4), D / 4), kBlock, 0, st>>>(y, nullptr, N, static_cast<int>(D), mean, rstd,
                                                                   gamma, beta, nullptr, nullptr, ep,
                                                                   static_cast<float*>(out), out_kind);
   STEMGNN_LAUNCH_CHECK();
@@ -397,7 +411,7 @@ int stemgnn_bn_act_drop_bwd(const float* g_out, const float* y, int64_t N, int64
     sum_gb = gb;
     sum_gbx = gg;
   }
-  k_apply<true><<<elementwise_grid(N * (D / 4)), kBlock, 0, st>>>(y, g_out, N, static_cast<int>(D), mean, rstd, gamma,
+  k_apply<true><<<elementwise_grid(N * (D / 4), D / 4), kBlock, 0, st>>>(y, g_out, N, static_cast<int>(D), mean, rstd, gamma,
                                                                  beta, sum_gb, sum_gbx, ep, g_y, kF32);
   STEMGNN_LAUNCH_CHECK();
   return STEMGNN_OK;
