@@ -762,3 +762,29 @@ def test_deterministic_mode_makes_steps_bit_reproducible(dev):
         seen += 1
         torch.testing.assert_close(g1, g2, rtol=1e-3, atol=1e-5 * max(float(g2.abs().max()), 1e-3))
     assert seen > 10
+
+
+def test_encoder_five_layers_queue_more_weight_gradients_than_a_batch_holds(dev):
+    """Five SAGE layers queue ten weight-gradient products in the encoder's backward: more than one DwBatch table (8),
+    so the batch flushes itself part-way.  Gradients against the CPU oracle as in test_encoder_fwd_bwd_vs_oracle."""
+    from stem_gnn_amd import ops
+    N, E, D, L = 700, 6000, 32, 5
+    om, gm = make_models(D, L, 2, 16, D, dev)
+    torch.manual_seed(9)
+    x = torch.randn(N, D)
+    ei = torch.randint(0, N, (2, E))
+    oe, ge = om.encoder, gm.encoder
+    oe.train(); ge.train()
+    xg = x.to(dev).requires_grad_(True)
+    zg = ge(xg, ei.to(dev), None)
+    masks = [ops.dropout_keep_mask(N * D, 0.15, s, o, dev).view(N, D).cpu() for (s, o) in ge.last_dropout_keys]
+    xr = x.clone().requires_grad_(True)
+    zr = oe(xr, ei, None, dropout_masks=masks)
+    torch.testing.assert_close(zg.detach().cpu(), zr.detach(), rtol=1e-4, atol=1e-4)
+    w = torch.randn(N, D)
+    (zr * w).sum().backward()
+    (zg * w.to(dev)).sum().backward()
+    torch.testing.assert_close(xg.grad.cpu(), xr.grad, rtol=2e-3, atol=2e-4)
+    for (n1, p1), (n2, p2) in zip(oe.named_parameters(), ge.named_parameters()):
+        assert n1 == n2
+        torch.testing.assert_close(p2.grad.cpu(), p1.grad, rtol=2e-3, atol=5e-4, msg=lambda m: f"{n1}: {m}")
