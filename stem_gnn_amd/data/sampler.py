@@ -63,7 +63,7 @@ class HipNeighborSampler:
                                                                  seeds.contiguous(), self.fanouts, self.seed,
                                                                  self.calls * 64, self.local_of)
         n_id64 = n_id.long()
-        b = Batch(batch_size=seeds.numel(), n_id=n_id64, x=self.x[n_id64], edge_index=coo, xe=etype.long(),
+        b = Batch(batch_size=seeds.numel(), n_id=n_id64, x=self.x.index_select(0, n_id64), edge_index=coo, xe=etype.long(),
                   node_text_feat=self.ntf, edge_text_feat=self.etf)
         b.graph = GraphStructure.from_csr(rowptr, src, coo, nb, etype_slot=etype,
                                           max_in_degree=self.batch_max_in_degree,
