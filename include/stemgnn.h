@@ -292,6 +292,13 @@ int stemgnn_linear_set_mode(int mode);
  * sampled batch, whose edges all end in the leading, expanded nodes; x1 may be a [x1_rows, K1] buffer): row tiles
  * past them skip the x1 half of the contraction.  Pass -1 (or M) when x1 has M meaningful rows. */
 size_t stemgnn_linear_stats_partial_bytes(int64_t num_rows, int64_t out_dim);
+/* stemgnn_edge_dot_fwd + stemgnn_edge_bce_loss in one launch (reference model/encoder.py:364-366 + model/pt_model.py:62-65):
+ * scores of kp positive then kn negative edges, loss[0] = mean -log(sigmoid + EPS) + mean -log(1 - sigmoid + EPS),
+ * coef[e] = d loss / d score_e.  The scores are not kept.  workspace: stemgnn_edge_dot_bce_workspace_bytes(kp + kn). */
+size_t stemgnn_edge_dot_bce_workspace_bytes(int64_t num_edges);
+int stemgnn_edge_dot_bce(const float* z, int64_t num_nodes, int64_t dim, const int64_t* edge_index, int64_t kp, int64_t kn,
+                         float* loss, float* coef, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Deterministic forms of stemgnn_edge_dot_bwd_scaled / stemgnn_edge_concat_bwd (reference model/encoder.py:346-354
  * InnerProductDecoder backward, model/pt_model.py:72-81 cat(z_u, z_v) backward; ATen scatters with atomics there too):
  * the edge list is grouped by node (stable radix sort, twice: by each endpoint row) and one lane group per node adds

@@ -143,6 +143,8 @@ _SIGNATURES = {
     "stemgnn_linear_stats_partial_bytes": (c_size_t, [I64, I64]),
     "stemgnn_linear_stats_blocks": (I64, [I64, I64]),
     "stemgnn_linear_set_ws": (I32, [I32]),
+    "stemgnn_edge_dot_bce_workspace_bytes": (c_size_t, [I64]),
+    "stemgnn_edge_dot_bce": (c_int, [P, I64, I64, P, I64, I64, P, P, P, c_size_t, P]),
     "stemgnn_edge_det_workspace_bytes": (c_size_t, [I64, I64]),
     "stemgnn_edge_dot_bwd_det": (c_int, [P, P, P, I64, I64, P, I64, P, P, c_size_t, P]),
     "stemgnn_edge_concat_bwd_det": (c_int, [P, I64, I64, P, I64, P, P, c_size_t, P]),

@@ -194,17 +194,22 @@ __device__ __forceinline__ void wait_stores() {
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), nothing else: this thread's stores have been acknowledged
   __atomic_signal_fence(__ATOMIC_SEQ_CST);
 }
-__device__ __forceinline__ bool ticket_last(unsigned int* counter) {
+// `total`: the number of blocks that take a ticket on this counter (a launch that serves several reductions gives
+// each its own counter and block count)
+__device__ __forceinline__ bool ticket_last(unsigned int* counter, unsigned int total) {
   __shared__ int s_ticket_last;
   __syncthreads();  // every writer of the block is past its wait_stores()
   if (threadIdx.x == 0) {
     const unsigned int t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int last = t == gridDim.x * gridDim.y * gridDim.z - 1u;
+    const int last = t == total - 1u;
     if (last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_ticket_last = last;
   }
   __syncthreads();
   return s_ticket_last != 0;
+}
+__device__ __forceinline__ bool ticket_last(unsigned int* counter) {
+  return ticket_last(counter, gridDim.x * gridDim.y * gridDim.z);
 }
 
 // csrc/wsgemm.hip: the quantiser's code assignment (lean form: indices, row norms, commitment sum) with the head's codes
@@ -213,6 +218,25 @@ bool vq_assign_ws_ok(int64_t N, int64_t H, int64_t Dc, int64_t K);
 int vq_assign_ws_launch(const float* xp, int64_t N, int64_t H, const float* embed, const float* esq, float* norm,
                         int64_t* ind, float* sq_partial, unsigned int* counter, double sq_scale, float* sq_out,
                         hipStream_t st);
+
+// csrc/loss_ops.hip: the three row / element losses of the heads phase (two mean squared errors, one mean of 1 - cos) in
+// ONE launch each way; the same arithmetic and summation order as stemgnn_mse_loss_* / stemgnn_cosine_loss_*.
+// Workspaces as for those calls (stemgnn_loss_workspace_bytes(256) for an mse, (rows) for the cosine term).
+struct HeadLossJobs {
+  const float *pred_a, *tgt_a;  // mse over n_a elements
+  int64_t n_a;
+  const float *pred_b, *tgt_b;  // mse over n_b elements
+  int64_t n_b;
+  const float *z, *h;  // mean(1 - cos(z_r, h_r)) over `rows` rows of width D
+  int64_t rows, D;
+  float *loss_a, *loss_b, *loss_c;  // forward: outputs
+  float* cos_save;                  // [rows][3]
+  void *ws_a, *ws_b, *ws_c;         // forward workspaces
+  const float *g_a, *g_b, *g_c;     // backward: upstream gradients of the three losses
+  float *gp_a, *gp_b, *gh;          // backward: gradients w.r.t. pred_a, pred_b, h
+};
+int head_losses_fwd(const HeadLossJobs& j, hipStream_t st);
+int head_losses_bwd(const HeadLossJobs& j, hipStream_t st);
 
 // csrc/loss_ops.hip: stemgnn_ortho_loss_fwd that also writes total[0] = plus[0] + loss[0] (plus / total may be null)
 int ortho_loss_fwd_plus(const float* embed, const int64_t* ids, int64_t heads, int64_t codebook_size, int64_t code_dim,

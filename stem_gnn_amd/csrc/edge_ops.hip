@@ -47,6 +47,79 @@ k_edge_dot_fwd(const float* __restrict__ z, int64_t N, int D, const int64_t* __r
   if (lane == 0) out[e] = acc;
 }
 
+// k_edge_dot_fwd and k_edge_bce in one launch (the heads phase): a lane group scores its edge and turns the score into
+// its loss term and its gradient coefficient at once; block sums -> the block that arrives last adds them in index
+// order (common.h: ticket_last).  The scores themselves are not kept (the backward needs the coefficients only).
+template <int G>
+__global__ void __launch_bounds__(kBlock)
+k_edge_dot_bce(const float* __restrict__ z, int64_t N, int D, const int64_t* __restrict__ ei, int64_t kp, int64_t kn,
+               float* __restrict__ loss, float* __restrict__ coef, double* __restrict__ partial /*[blocks][2]*/,
+               unsigned int* counter) {
+  constexpr int kGroups = kBlock / G;
+  __shared__ double s_terms[2][kGroups];
+  __shared__ double red[2][kBlock];
+  const int lane = threadIdx.x % G, grp = threadIdx.x / G;
+  const int64_t E = kp + kn;
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * kGroups + grp;
+  float acc = 0.f;
+  if (e < E) {
+    int64_t u, v;
+    if (load_edge(ei, E, e, N, &u, &v)) {
+      const int nvec = D / 4;
+      for (int c = lane; c < nvec; c += G) {
+        const float4 a = ld4(z + u * D + 4 * c), b = ld4(z + v * D + 4 * c);
+        acc += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, G);
+  if (lane == 0) {
+    double tp = 0.0, tn = 0.0;
+    if (e < E) {
+      const float eps = 1e-15f;
+      const float sg = 1.0f / (1.0f + expf(-acc));
+      if (e < kp) {
+        tp = static_cast<double>(-logf(sg + eps));
+        coef[e] = -(sg * (1.0f - sg)) / (sg + eps) / static_cast<float>(kp);
+      } else {
+        const float q = 1.0f - sg + eps;
+        tn = static_cast<double>(-logf(q));
+        coef[e] = (sg * (1.0f - sg)) / q / static_cast<float>(kn);
+      }
+    }
+    s_terms[0][grp] = tp;
+    s_terms[1][grp] = tn;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double sp = 0.0, sn = 0.0;
+    for (int i = 0; i < kGroups; ++i) { sp += s_terms[0][i]; sn += s_terms[1][i]; }
+    st_agent(partial + 2 * blockIdx.x, sp);
+    st_agent(partial + 2 * blockIdx.x + 1, sn);
+    wait_stores();
+  }
+  if (!ticket_last(counter)) return;
+  double sp = 0.0, sn = 0.0;
+  for (int i = threadIdx.x; i < static_cast<int>(gridDim.x); i += kBlock) {
+    sp += ld_agent(partial + 2 * i);
+    sn += ld_agent(partial + 2 * i + 1);
+  }
+  red[0][threadIdx.x] = sp;
+  red[1][threadIdx.x] = sn;
+  __syncthreads();
+  for (int o = kBlock / 2; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + o];
+      red[1][threadIdx.x] += red[1][threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0)
+    loss[0] = static_cast<float>(red[0][0] / static_cast<double>(kp > 0 ? kp : 1) +
+                                 red[1][0] / static_cast<double>(kn > 0 ? kn : 1));
+}
+
 __device__ inline void atomic_add4(float* p, float4 v) {
   atomicAdd(p + 0, v.x);
   atomicAdd(p + 1, v.y);
@@ -316,6 +389,26 @@ int stemgnn_edge_dot_bwd_scaled(const float* coef, const float* g_scalar, const 
   if (E == 0) return STEMGNN_OK;
   if (!coef || !g_scalar || !z || !edge_index || !g_z) return STEMGNN_ERR_INVALID_ARG;
   STEMGNN_EDGE_DISPATCH(k_edge_dot_bwd, E, coef, g_scalar, z, N, static_cast<int>(D), edge_index, E, g_z);
+  return STEMGNN_OK;
+}
+
+size_t stemgnn_edge_dot_bce_workspace_bytes(int64_t num_edges) {
+  if (num_edges < 0) return 0;
+  return static_cast<size_t>(num_edges / 4 + 2) * 2 * sizeof(double) + 256;  // two sums per block, >= 4 edges per block
+}
+
+int stemgnn_edge_dot_bce(const float* z, int64_t N, int64_t D, const int64_t* edge_index, int64_t kp, int64_t kn,
+                         float* loss, float* coef, void* workspace, size_t workspace_bytes, void* stream_) {
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  const int64_t E = kp + kn;
+  if (N < 0 || kp < 0 || kn < 0 || E <= 0 || !dim_ok(D) || !loss) return STEMGNN_ERR_INVALID_ARG;
+  if (!fits_i32(E)) return STEMGNN_ERR_TOO_LARGE;
+  if (!z || !edge_index || !coef || !workspace) return STEMGNN_ERR_INVALID_ARG;
+  if (workspace_bytes < stemgnn_edge_dot_bce_workspace_bytes(E)) return STEMGNN_ERR_WORKSPACE;
+  double* partial = reinterpret_cast<double*>(align_up(reinterpret_cast<uintptr_t>(workspace), 256));
+  unsigned int* counter = ticket_counter(loss);
+  if (!counter) return STEMGNN_ERR_HIP;
+  STEMGNN_EDGE_DISPATCH(k_edge_dot_bce, E, z, N, static_cast<int>(D), edge_index, kp, kn, loss, coef, partial, counter);
   return STEMGNN_OK;
 }
 

@@ -107,6 +107,8 @@ struct HeadsSave {
   uint8_t* selected;
   void* ws[3];
   size_t ws_bytes;
+  void* bce_ws;
+  size_t bce_bytes;
   size_t bytes;
 };
 
@@ -132,6 +134,8 @@ inline HeadsSave plan_heads(const void* save, const stemgnn_heads_params* p, int
   s.selected = c.take<uint8_t>(std::max<int64_t>(E, 1) + 16);
   s.ws_bytes = stemgnn_loss_workspace_bytes(std::max<int64_t>(bs, 256));
   for (int i = 0; i < 3; ++i) s.ws[i] = c.take<unsigned char>(s.ws_bytes);
+  s.bce_bytes = stemgnn_edge_dot_bce_workspace_bytes(2 * k1);
+  s.bce_ws = c.take<unsigned char>(s.bce_bytes);
   s.bytes = c.off + 256;
   return s;
 }
@@ -180,8 +184,8 @@ int stemgnn_heads_fwd(const stemgnn_heads_params* p, const stemgnn_graph_view* g
   STEMGNN_TRY(stemgnn_negative_sample_into(g->rowptr, g->src, g->eid, s.selected, N, k, seed, off_neg, topo_edges + k,
                                            2 * k, s0));
   STEMGNN_TRY(stemgnn_linear_fwd(q, p->w_topo, D, nullptr, nullptr, 0, p->b_topo, N, D, s.zl, nullptr, nullptr, -1, s0));
-  STEMGNN_TRY(stemgnn_edge_dot_fwd(s.zl, N, D, topo_edges, 2 * k, s.dots, s0));
-  STEMGNN_TRY(stemgnn_edge_bce_loss(s.dots, k, k, losses + 1, s.coef, s0));
+  // edge scores and the BCE terms / coefficients in one launch
+  STEMGNN_TRY(stemgnn_edge_dot_bce(s.zl, N, D, topo_edges, k, k, losses + 1, s.coef, s.bce_ws, s.bce_bytes, s0));
 
   // The three products over few rows (sampled pairs, seed rows) share one launch when everything runs on one
   // stream (DirectBatch, csrc/wsgemm.hip): on their own they are 8 - 90 tiles on 256 CUs, 12 - 20 us each.
@@ -202,17 +206,29 @@ int stemgnn_heads_fwd(const stemgnn_heads_params* p, const stemgnn_graph_view* g
   } else {
     STEMGNN_TRY(stemgnn_linear_fwd(s.zz, p->w_ts, 2 * D, nullptr, nullptr, 0, p->b_ts, k, D, s.h_ts, nullptr, nullptr, -1, s1));
   }
-  STEMGNN_TRY(stemgnn_mse_loss_fwd(s.h_ts, s.target, k * D, 1.0f, losses + 2, s.ws[0], s.ws_bytes, s1));
-  if (fork) STEMGNN_HIP_TRY(hipEventRecord(ln->done[0], s1));
+  if (fork) {
+    STEMGNN_TRY(stemgnn_mse_loss_fwd(s.h_ts, s.target, k * D, 1.0f, losses + 2, s.ws[0], s.ws_bytes, s1));
+    STEMGNN_HIP_TRY(hipEventRecord(ln->done[0], s1));
+  }
 
   // ---- lane C: the two heads on the seed rows q[:bs] (pt_model.py:42-43, 93-100)
   if (!direct)
     STEMGNN_TRY(stemgnn_linear_fwd(q, p->w_feat, D, nullptr, nullptr, 0, p->b_feat, bs, p->in_dim, s.h_f, nullptr, nullptr,
                                    -1, s2));
-  STEMGNN_TRY(stemgnn_mse_loss_fwd(s.h_f, x_feat, bs * p->in_dim, 1.0f, losses + 0, s.ws[1], s.ws_bytes, s2));
+  if (fork) STEMGNN_TRY(stemgnn_mse_loss_fwd(s.h_f, x_feat, bs * p->in_dim, 1.0f, losses + 0, s.ws[1], s.ws_bytes, s2));
   if (!direct)
     STEMGNN_TRY(stemgnn_linear_fwd(q, p->w_sem, D, nullptr, nullptr, 0, p->b_sem, bs, D, s.h_s, nullptr, nullptr, -1, s2));
-  STEMGNN_TRY(stemgnn_cosine_loss_fwd(z_teacher, s.h_s, bs, D, 1.0f, losses + 3, s.cos_save, s.ws[2], s.ws_bytes, s2));
+  if (fork) {
+    STEMGNN_TRY(stemgnn_cosine_loss_fwd(z_teacher, s.h_s, bs, D, 1.0f, losses + 3, s.cos_save, s.ws[2], s.ws_bytes, s2));
+  } else {
+    // one stream: the three losses of these heads in one launch (csrc/loss_ops.hip: same sums, same order)
+    HeadLossJobs lj{};
+    lj.pred_a = s.h_ts; lj.tgt_a = s.target; lj.n_a = k * D; lj.loss_a = losses + 2; lj.ws_a = s.ws[0];
+    lj.pred_b = s.h_f; lj.tgt_b = x_feat; lj.n_b = bs * p->in_dim; lj.loss_b = losses + 0; lj.ws_b = s.ws[1];
+    lj.z = z_teacher; lj.h = s.h_s; lj.rows = bs; lj.D = D; lj.loss_c = losses + 3; lj.cos_save = s.cos_save;
+    lj.ws_c = s.ws[2];
+    STEMGNN_TRY(head_losses_fwd(lj, s0));
+  }
   if (fork) {
     STEMGNN_HIP_TRY(hipEventRecord(ln->done[1], s2));
     STEMGNN_HIP_TRY(hipStreamWaitEvent(s0, ln->done[0], 0));
@@ -288,16 +304,24 @@ int stemgnn_heads_bwd(const stemgnn_heads_params* p, int64_t N, const float* q, 
   DirectBatch small;  // the three backward-data products over few rows, one launch (see stemgnn_heads_fwd)
 
   // ---- lane B: topo-sem head back to the gathered pairs
-  STEMGNN_TRY(stemgnn_mse_loss_bwd(s.h_ts, s.target, k * D, 1.0f, g_losses + 2, g_hts, s1));
+  if (fork) {
+    STEMGNN_TRY(stemgnn_mse_loss_bwd(s.h_ts, s.target, k * D, 1.0f, g_losses + 2, g_hts, s1));
+  } else {
+    HeadLossJobs lj{};  // the three loss gradients in one launch
+    lj.pred_a = s.h_ts; lj.tgt_a = s.target; lj.n_a = k * D; lj.g_a = g_losses + 2; lj.gp_a = g_hts;
+    lj.pred_b = s.h_f; lj.tgt_b = x_feat; lj.n_b = bs * I; lj.g_b = g_losses + 0; lj.gp_b = g_hf;
+    lj.z = z_teacher; lj.h = s.h_s; lj.rows = bs; lj.D = D; lj.g_c = g_losses + 3; lj.cos_save = s.cos_save; lj.gh = g_hs;
+    STEMGNN_TRY(head_losses_bwd(lj, s0));
+  }
   if (!direct) STEMGNN_TRY(stemgnn_linear_bwd_data(g_hts, p->w_ts, k, D, 2 * D, g_zz, s1));
   STEMGNN_TRY(weight_grad(g_hts, s.zz, k, D, 2 * D, p->g_w_ts, p->b_ts ? p->g_b_ts : nullptr, ws_ts, wb_ts, s1));
   if (fork) STEMGNN_HIP_TRY(hipEventRecord(ln->done[0], s1));
 
   // ---- lane C: the two seed-row heads
-  STEMGNN_TRY(stemgnn_mse_loss_bwd(s.h_f, x_feat, bs * I, 1.0f, g_losses + 0, g_hf, s2));
+  if (fork) STEMGNN_TRY(stemgnn_mse_loss_bwd(s.h_f, x_feat, bs * I, 1.0f, g_losses + 0, g_hf, s2));
   if (!direct) STEMGNN_TRY(stemgnn_linear_bwd_data(g_hf, p->w_feat, bs, I, D, g_head_f, s2));
   STEMGNN_TRY(weight_grad(g_hf, q, bs, I, D, p->g_w_feat, p->b_feat ? p->g_b_feat : nullptr, ws_f, wb_f, s2));
-  STEMGNN_TRY(stemgnn_cosine_loss_bwd(z_teacher, s.h_s, bs, D, 1.0f, g_losses + 3, s.cos_save, g_hs, s2));
+  if (fork) STEMGNN_TRY(stemgnn_cosine_loss_bwd(z_teacher, s.h_s, bs, D, 1.0f, g_losses + 3, s.cos_save, g_hs, s2));
   if (!direct) STEMGNN_TRY(stemgnn_linear_bwd_data(g_hs, p->w_sem, bs, D, D, g_head_s, s2));
   STEMGNN_TRY(weight_grad(g_hs, q, bs, D, D, p->g_w_sem, p->b_sem ? p->g_b_sem : nullptr, ws_s, wb_s, s2));
   if (fork) STEMGNN_HIP_TRY(hipEventRecord(ln->done[1], s2));

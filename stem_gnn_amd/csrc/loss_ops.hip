@@ -38,19 +38,18 @@ __device__ inline void finish_sum_block(const double* partial, int n, double mul
   if (threadIdx.x == 0) loss[0] = static_cast<float>(red[0] * mul + add);
 }
 
-// partial[b] = sum over the block's grid-stride share of (p - t)^2
-__global__ void __launch_bounds__(256) k_mse_partial(const float* __restrict__ p, const float* __restrict__ t, int64_t n,
-                                                     double* __restrict__ partial, unsigned int* counter, double mul,
-                                                     float* __restrict__ loss) {
-  __shared__ double red[256];
+// partial[b] = sum over block b's grid-stride share of (p - t)^2 (nb blocks); the last block to arrive finishes
+__device__ inline void mse_partial_body(const float* __restrict__ p, const float* __restrict__ t, int64_t n,
+                                        double* __restrict__ partial, unsigned int* counter, double mul,
+                                        float* __restrict__ loss, int b, int nb, double* red) {
   double s = 0.0;
   const int64_t n4 = n / 4;
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n4; i += static_cast<int64_t>(gridDim.x) * 256) {
-    const float4 a = *reinterpret_cast<const float4*>(p + 4 * i), b = *reinterpret_cast<const float4*>(t + 4 * i);
-    const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z, dw = a.w - b.w;
+  for (int64_t i = static_cast<int64_t>(b) * 256 + threadIdx.x; i < n4; i += static_cast<int64_t>(nb) * 256) {
+    const float4 a = *reinterpret_cast<const float4*>(p + 4 * i), c = *reinterpret_cast<const float4*>(t + 4 * i);
+    const float dx = a.x - c.x, dy = a.y - c.y, dz = a.z - c.z, dw = a.w - c.w;
     s += static_cast<double>(dx * dx + dy * dy + dz * dz + dw * dw);
   }
-  if (blockIdx.x == 0)
+  if (b == 0)
     for (int64_t i = 4 * n4 + threadIdx.x; i < n; i += 256) {
       const float d = p[i] - t[i];
       s += static_cast<double>(d * d);
@@ -61,8 +60,15 @@ __global__ void __launch_bounds__(256) k_mse_partial(const float* __restrict__ p
     if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) { st_agent(partial + blockIdx.x, red[0]); wait_stores(); }
-  if (ticket_last(counter)) finish_sum_block(partial, gridDim.x, mul, 0.0, loss, red);
+  if (threadIdx.x == 0) { st_agent(partial + b, red[0]); wait_stores(); }
+  if (ticket_last(counter, nb)) finish_sum_block(partial, nb, mul, 0.0, loss, red);
+}
+
+__global__ void __launch_bounds__(256) k_mse_partial(const float* __restrict__ p, const float* __restrict__ t, int64_t n,
+                                                     double* __restrict__ partial, unsigned int* counter, double mul,
+                                                     float* __restrict__ loss) {
+  __shared__ double red[256];
+  mse_partial_body(p, t, n, partial, counter, mul, loss, blockIdx.x, gridDim.x, red);
 }
 
 // loss[0] = (sum_b partial[b]) * mul + add   (fixed order)
@@ -86,26 +92,29 @@ __global__ void __launch_bounds__(256) k_finish_sum(const double* __restrict__ p
 }
 
 // g_p = g[0] * scale * 2 (p - t) / n
+__device__ inline void mse_bwd_body(const float* __restrict__ p, const float* __restrict__ t, int64_t n, float scale,
+                                    const float* __restrict__ g, float* __restrict__ gp, int b, int nb) {
+  const float c = g[0] * scale * 2.0f / static_cast<float>(n);
+  for (int64_t i = static_cast<int64_t>(b) * 256 + threadIdx.x; i < n; i += static_cast<int64_t>(nb) * 256)
+    gp[i] = c * (p[i] - t[i]);
+}
 __global__ void __launch_bounds__(256) k_mse_bwd(const float* __restrict__ p, const float* __restrict__ t, int64_t n,
                                                  float scale, const float* __restrict__ g, float* __restrict__ gp) {
-  const float c = g[0] * scale * 2.0f / static_cast<float>(n);
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * 256)
-    gp[i] = c * (p[i] - t[i]);
+  mse_bwd_body(p, t, n, scale, g, gp, blockIdx.x, gridDim.x);
 }
 
 // One wave per row: cos of the normalised rows (F.normalize eps clamp); save [rows][3] = (cos, 1/|z|, |h|),
 // row_loss[r] = 1 - cos.
-__global__ void __launch_bounds__(256) k_cos_rows(const float* __restrict__ z, const float* __restrict__ h, int64_t rows,
-                                                  int D, float* __restrict__ save, double* __restrict__ row_loss,
-                                                  unsigned int* counter, double mul, float* __restrict__ loss) {
-  __shared__ double red[256];
+__device__ inline void cos_rows_body(const float* __restrict__ z, const float* __restrict__ h, int64_t rows, int D,
+                                     float* __restrict__ save, double* __restrict__ row_loss, unsigned int* counter,
+                                     double mul, float* __restrict__ loss, int b, int nb, double* red) {
   const int lane = threadIdx.x & 63;
-  const int64_t r = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  const int64_t r = static_cast<int64_t>(b) * 4 + (threadIdx.x >> 6);
   if (r < rows) {
     float zz = 0.f, hh = 0.f, zh = 0.f;
     for (int c = lane; c < D; c += 64) {
-      const float a = z[r * D + c], b = h[r * D + c];
-      zz += a * a; hh += b * b; zh += a * b;
+      const float a = z[r * D + c], bb = h[r * D + c];
+      zz += a * a; hh += bb * bb; zh += a * bb;
     }
     zz = wave_sum(zz); hh = wave_sum(hh); zh = wave_sum(zh);
     const float nz = sqrtf(zz), nh = sqrtf(hh);
@@ -117,15 +126,21 @@ __global__ void __launch_bounds__(256) k_cos_rows(const float* __restrict__ z, c
       wait_stores();
     }
   }
-  if (ticket_last(counter)) finish_sum_block(row_loss, static_cast<int>(rows), mul, 0.0, loss, red);
+  if (ticket_last(counter, nb)) finish_sum_block(row_loss, static_cast<int>(rows), mul, 0.0, loss, red);
+}
+__global__ void __launch_bounds__(256) k_cos_rows(const float* __restrict__ z, const float* __restrict__ h, int64_t rows,
+                                                  int D, float* __restrict__ save, double* __restrict__ row_loss,
+                                                  unsigned int* counter, double mul, float* __restrict__ loss) {
+  __shared__ double red[256];
+  cos_rows_body(z, h, rows, D, save, row_loss, counter, mul, loss, blockIdx.x, gridDim.x, red);
 }
 
 // g_h[r] = -(g scale / rows) * d cos / d h,  cos = <zn, h / max(|h|, eps)>
-__global__ void __launch_bounds__(256) k_cos_bwd(const float* __restrict__ z, const float* __restrict__ h, int64_t rows,
-                                                 int D, float scale, const float* __restrict__ g,
-                                                 const float* __restrict__ save, float* __restrict__ gh) {
+__device__ inline void cos_bwd_body(const float* __restrict__ z, const float* __restrict__ h, int64_t rows, int D,
+                                    float scale, const float* __restrict__ g, const float* __restrict__ save,
+                                    float* __restrict__ gh, int b) {
   const int lane = threadIdx.x & 63;
-  const int64_t r = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  const int64_t r = static_cast<int64_t>(b) * 4 + (threadIdx.x >> 6);
   if (r >= rows) return;
   const float c = -g[0] * scale / static_cast<float>(rows);
   const float cosv = save[r * 3 + 0], inv_z = save[r * 3 + 1], nh = save[r * 3 + 2];
@@ -136,6 +151,39 @@ __global__ void __launch_bounds__(256) k_cos_bwd(const float* __restrict__ z, co
     // d/dh of <zn, h/|h|> = (zn - cos * hn) / |h|; in the eps-clamped branch h/eps is linear: zn / eps
     gh[r * D + col] = c * (clamped ? zn * inv_h : (zn - cosv * hn) * inv_h);
   }
+}
+__global__ void __launch_bounds__(256) k_cos_bwd(const float* __restrict__ z, const float* __restrict__ h, int64_t rows,
+                                                 int D, float scale, const float* __restrict__ g,
+                                                 const float* __restrict__ save, float* __restrict__ gh) {
+  cos_bwd_body(z, h, rows, D, scale, g, save, gh, blockIdx.x);
+}
+
+// The heads phase's three losses in one launch each way: blocks [0, ba) the first mean squared error, [ba, ba + bb)
+// the second, the rest the cosine rows; every reduction keeps its own partials, ticket and summation order.
+struct HeadLossTable {
+  HeadLossJobs j;
+  double *part_a, *part_b, *part_c;
+  unsigned int *cnt_a, *cnt_b, *cnt_c;
+  int ba, bb, bc;
+};
+__global__ void __launch_bounds__(256) k_head_losses_fwd(const HeadLossTable t) {
+  __shared__ double red[256];
+  const int b = blockIdx.x;
+  if (b < t.ba)
+    mse_partial_body(t.j.pred_a, t.j.tgt_a, t.j.n_a, t.part_a, t.cnt_a, 1.0 / static_cast<double>(t.j.n_a), t.j.loss_a, b,
+                     t.ba, red);
+  else if (b < t.ba + t.bb)
+    mse_partial_body(t.j.pred_b, t.j.tgt_b, t.j.n_b, t.part_b, t.cnt_b, 1.0 / static_cast<double>(t.j.n_b), t.j.loss_b,
+                     b - t.ba, t.bb, red);
+  else
+    cos_rows_body(t.j.z, t.j.h, t.j.rows, static_cast<int>(t.j.D), t.j.cos_save, t.part_c, t.cnt_c,
+                  1.0 / static_cast<double>(t.j.rows), t.j.loss_c, b - t.ba - t.bb, t.bc, red);
+}
+__global__ void __launch_bounds__(256) k_head_losses_bwd(const HeadLossTable t) {
+  const int b = blockIdx.x;
+  if (b < t.ba) mse_bwd_body(t.j.pred_a, t.j.tgt_a, t.j.n_a, 1.0f, t.j.g_a, t.j.gp_a, b, t.ba);
+  else if (b < t.ba + t.bb) mse_bwd_body(t.j.pred_b, t.j.tgt_b, t.j.n_b, 1.0f, t.j.g_b, t.j.gp_b, b - t.ba, t.bb);
+  else cos_bwd_body(t.j.z, t.j.h, t.j.rows, static_cast<int>(t.j.D), 1.0f, t.j.g_c, t.j.cos_save, t.j.gh, b - t.ba - t.bb);
 }
 
 // Orthogonal regulariser on embed[:, ids] ([H, M, Dc] selected codes).  One WAVE per (head, i):
@@ -383,6 +431,46 @@ unsigned int* ticket_counter(const void* key) {
   }();
   if (!base) return nullptr;
   return base + (reinterpret_cast<uintptr_t>(key) >> 2) % 61;
+}
+static inline int mse_blocks(int64_t n) {
+  int64_t b = (n / 4 + 255) / 256;
+  return static_cast<int>(b < 1 ? 1 : (b > 256 ? 256 : b));
+}
+static inline int mse_bwd_blocks(int64_t n) {
+  int64_t b = (n + 255) / 256;
+  return static_cast<int>(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+int head_losses_fwd(const HeadLossJobs& j, hipStream_t st) {
+  if (j.n_a <= 0 || j.n_b <= 0 || j.rows <= 0 || j.D <= 0 || j.rows >= (1 << 30)) return STEMGNN_ERR_INVALID_ARG;
+  HeadLossTable t;
+  t.j = j;
+  t.part_a = reinterpret_cast<double*>(align_up(reinterpret_cast<uintptr_t>(j.ws_a), 256));
+  t.part_b = reinterpret_cast<double*>(align_up(reinterpret_cast<uintptr_t>(j.ws_b), 256));
+  t.part_c = reinterpret_cast<double*>(align_up(reinterpret_cast<uintptr_t>(j.ws_c), 256));
+  t.cnt_a = ticket_counter(j.loss_a);
+  t.cnt_b = ticket_counter(j.loss_b);
+  t.cnt_c = ticket_counter(j.loss_c);
+  if (!t.cnt_a || !t.cnt_b || !t.cnt_c) return STEMGNN_ERR_HIP;
+  if (t.cnt_a == t.cnt_b || t.cnt_a == t.cnt_c || t.cnt_b == t.cnt_c) return STEMGNN_ERR_INVALID_ARG;  // one launch
+  t.ba = mse_blocks(j.n_a);
+  t.bb = mse_blocks(j.n_b);
+  t.bc = static_cast<int>((j.rows + 3) / 4);
+  k_head_losses_fwd<<<static_cast<unsigned>(t.ba + t.bb + t.bc), 256, 0, st>>>(t);
+  STEMGNN_LAUNCH_CHECK();
+  return STEMGNN_OK;
+}
+int head_losses_bwd(const HeadLossJobs& j, hipStream_t st) {
+  if (j.n_a <= 0 || j.n_b <= 0 || j.rows <= 0 || j.D <= 0) return STEMGNN_ERR_INVALID_ARG;
+  HeadLossTable t;
+  t.j = j;
+  t.part_a = t.part_b = t.part_c = nullptr;
+  t.cnt_a = t.cnt_b = t.cnt_c = nullptr;
+  t.ba = mse_bwd_blocks(j.n_a);
+  t.bb = mse_bwd_blocks(j.n_b);
+  t.bc = static_cast<int>((j.rows + 3) / 4);
+  k_head_losses_bwd<<<static_cast<unsigned>(t.ba + t.bb + t.bc), 256, 0, st>>>(t);
+  STEMGNN_LAUNCH_CHECK();
+  return STEMGNN_OK;
 }
 }  // namespace stemgnn
 

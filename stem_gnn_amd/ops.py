@@ -943,6 +943,7 @@ class VqFn(torch.autograd.Function):
         ctx.cfg = cfg
         ctx.save_for_backward(z, ind, save, embed, w_in, b_in, w_out, b_out)
         ctx.mark_non_differentiable(ind)
+        ctx.set_materialize_grads(False)  # no zeros_like(ind) launch per backward; None gradients are handled below
         return quantize, ind, loss
 
     @staticmethod
