@@ -292,6 +292,26 @@ int stemgnn_linear_set_mode(int mode);
  * sampled batch, whose edges all end in the leading, expanded nodes; x1 may be a [x1_rows, K1] buffer): row tiles
  * past them skip the x1 half of the contraction.  Pass -1 (or M) when x1 has M meaningful rows. */
 size_t stemgnn_linear_stats_partial_bytes(int64_t num_rows, int64_t out_dim);
+/* Two stemgnn_sample_edges draws over the same edge list in one launch (same picks as two separate calls with
+ * (seed, offset_a) and (seed, offset_b)): sample a marks its picks in selected_a (cleared first; may be NULL), sample b
+ * also returns the picked edges' types (sel_type_b may be NULL). */
+int stemgnn_sample_edges2(const int64_t* edge_index, const int64_t* edge_type, int64_t num_edges, uint64_t seed,
+                          int64_t k_a, uint64_t offset_a, int64_t* perm_a, int64_t* sel_index_a, int64_t sel_stride_a,
+                          uint8_t* selected_a, int64_t k_b, uint64_t offset_b, int64_t* perm_b, int64_t* sel_index_b,
+                          int64_t sel_stride_b, int64_t* sel_type_b, void* stream);
+
+/* stemgnn_edge_concat_fwd (out[e] = [z[u_e], z[v_e]]) and target[e] = table[type[e]] (a row gather; an id outside
+ * [0, T) gives a zero row) in one launch: the inputs and targets of the topo-sem head (reference pt_model.py:72-81). */
+int stemgnn_edge_concat_gather(const float* z, int64_t num_nodes, int64_t dim, const int64_t* edge_index,
+                               int64_t num_edges, float* out, const float* table, int64_t table_rows,
+                               const int64_t* type, float* target, void* stream);
+
+/* stemgnn_edge_concat_bwd, and in the same launch g_z[i] += add_a[i] + add_b[i] for the first add_n elements (the heads
+ * phase: the gradients of the two seed-row heads join the query's gradient there). */
+int stemgnn_edge_concat_bwd_add(const float* g_out, int64_t num_nodes, int64_t dim, const int64_t* edge_index,
+                                int64_t num_edges, float* g_z, const float* add_a, const float* add_b, int64_t add_n,
+                                void* stream);
+
 /* stemgnn_edge_dot_fwd + stemgnn_edge_bce_loss in one launch (reference model/encoder.py:364-366 + model/pt_model.py:62-65):
  * scores of kp positive then kn negative edges, loss[0] = mean -log(sigmoid + EPS) + mean -log(1 - sigmoid + EPS),
  * coef[e] = d loss / d score_e.  The scores are not kept.  workspace: stemgnn_edge_dot_bce_workspace_bytes(kp + kn). */

@@ -234,6 +234,8 @@ struct HeadLossJobs {
   void *ws_a, *ws_b, *ws_c;         // forward workspaces
   const float *g_a, *g_b, *g_c;     // backward: upstream gradients of the three losses
   float *gp_a, *gp_b, *gh;          // backward: gradients w.r.t. pred_a, pred_b, h
+  void* zero_ptr;                   // backward, optional: a 16-byte aligned buffer cleared by the same launch
+  int64_t zero_bytes;               //   (the scatter target of the topology head), size a multiple of 16
 };
 int head_losses_fwd(const HeadLossJobs& j, hipStream_t st);
 int head_losses_bwd(const HeadLossJobs& j, hipStream_t st);

@@ -178,10 +178,44 @@ k_edge_concat_fwd(const float* __restrict__ z, int64_t N, int D, const int64_t* 
   }
 }
 
+// k_edge_concat_fwd and the gather of the pairs' target rows (table[type[e]]) in one launch (the topo-sem head)
+template <int G>
+__global__ void __launch_bounds__(kBlock)
+k_edge_concat_gather(const float* __restrict__ z, int64_t N, int D, const int64_t* __restrict__ ei, int64_t E,
+                     float* __restrict__ out, const float* __restrict__ table, int64_t T,
+                     const int64_t* __restrict__ type, float* __restrict__ target) {
+  const int lane = threadIdx.x % G;
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * (kBlock / G) + threadIdx.x / G;
+  if (e >= E) return;
+  int64_t u, v;
+  const bool ok = load_edge(ei, E, e, N, &u, &v);
+  const int64_t ty = type[e];
+  const bool tok = ty >= 0 && ty < T;
+  const int nvec = D / 4;
+  float* o = out + e * 2 * D;
+  for (int c = lane; c < nvec; c += G) {
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 a = ok ? ld4(z + u * D + 4 * c) : zero, b = ok ? ld4(z + v * D + 4 * c) : zero;
+    const float4 t = tok ? ld4(table + ty * D + 4 * c) : zero;
+    st4(o + 4 * c, a);
+    st4(o + D + 4 * c, b);
+    st4(target + e * D + 4 * c, t);
+  }
+}
+
 template <int G>
 __global__ void __launch_bounds__(kBlock)
 k_edge_concat_bwd(const float* __restrict__ g_out, int64_t N, int D, const int64_t* __restrict__ ei, int64_t E,
-                  float* __restrict__ g_z) {
+                  float* __restrict__ g_z, const float* __restrict__ add_a = nullptr,
+                  const float* __restrict__ add_b = nullptr, int64_t add_n = 0, int edge_blocks = 0) {
+  if (add_n > 0 && static_cast<int>(blockIdx.x) >= edge_blocks) {
+    // extra blocks of the same launch: g_z[i] += add_a[i] + add_b[i] for the leading add_n elements (the two seed-row
+    // heads' gradients), as atomics because the scatter below may hit the same rows concurrently
+    for (int64_t i = static_cast<int64_t>(blockIdx.x - edge_blocks) * kBlock + threadIdx.x; i < add_n;
+         i += static_cast<int64_t>(gridDim.x - edge_blocks) * kBlock)
+      atomicAdd(g_z + i, add_a[i] + add_b[i]);
+    return;
+  }
   const int lane = threadIdx.x % G;
   const int64_t e = static_cast<int64_t>(blockIdx.x) * (kBlock / G) + threadIdx.x / G;
   if (e >= E) return;
@@ -438,6 +472,36 @@ int stemgnn_edge_concat_fwd(const float* z, int64_t N, int64_t D, const int64_t*
   if (E == 0) return STEMGNN_OK;
   if (!z || !edge_index || !out) return STEMGNN_ERR_INVALID_ARG;
   STEMGNN_EDGE_DISPATCH(k_edge_concat_fwd, E, z, N, static_cast<int>(D), edge_index, E, out);
+  return STEMGNN_OK;
+}
+
+int stemgnn_edge_concat_gather(const float* z, int64_t N, int64_t D, const int64_t* edge_index, int64_t E, float* out,
+                               const float* table, int64_t T, const int64_t* type, float* target, void* stream_) {
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  if (N < 0 || E < 0 || T <= 0 || !dim_ok(D)) return STEMGNN_ERR_INVALID_ARG;
+  if (!fits_i32(E)) return STEMGNN_ERR_TOO_LARGE;
+  if (E == 0) return STEMGNN_OK;
+  if (!z || !edge_index || !out || !table || !type || !target) return STEMGNN_ERR_INVALID_ARG;
+  STEMGNN_EDGE_DISPATCH(k_edge_concat_gather, E, z, N, static_cast<int>(D), edge_index, E, out, table, T, type, target);
+  return STEMGNN_OK;
+}
+
+int stemgnn_edge_concat_bwd_add(const float* g_out, int64_t N, int64_t D, const int64_t* edge_index, int64_t E,
+                                float* g_z, const float* add_a, const float* add_b, int64_t add_n, void* stream_) {
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  if (N < 0 || E <= 0 || !dim_ok(D) || add_n <= 0 || add_n > N * D) return STEMGNN_ERR_INVALID_ARG;
+  if (!fits_i32(E)) return STEMGNN_ERR_TOO_LARGE;
+  if (!g_out || !edge_index || !g_z || !add_a || !add_b) return STEMGNN_ERR_INVALID_ARG;
+  const int G = D / 4 <= 16 ? 16 : (D / 4 <= 32 ? 32 : 64);
+  const int eb = static_cast<int>(groups_grid(E, G));
+  int64_t ab = (add_n + kBlock - 1) / kBlock;
+  if (ab > 512) ab = 512;
+  const unsigned grid = static_cast<unsigned>(eb + ab);
+  const int Di = static_cast<int>(D);
+  if (G == 16) k_edge_concat_bwd<16><<<grid, kBlock, 0, st>>>(g_out, N, Di, edge_index, E, g_z, add_a, add_b, add_n, eb);
+  else if (G == 32) k_edge_concat_bwd<32><<<grid, kBlock, 0, st>>>(g_out, N, Di, edge_index, E, g_z, add_a, add_b, add_n, eb);
+  else k_edge_concat_bwd<64><<<grid, kBlock, 0, st>>>(g_out, N, Di, edge_index, E, g_z, add_a, add_b, add_n, eb);
+  STEMGNN_LAUNCH_CHECK();
   return STEMGNN_OK;
 }
 

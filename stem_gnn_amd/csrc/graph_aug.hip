@@ -197,6 +197,31 @@ k_sample_edges(const int64_t* __restrict__ edge_index, const int64_t* __restrict
   if (selected) selected[e] = 1;
 }
 
+// two edge samples of the same graph in one launch (the heads phase: topology positives, marked in `selected`, and the
+// topo-sem pairs with their types); blocks [0, blocks_a) serve the first
+__global__ void __launch_bounds__(kThreads)
+k_sample_edges2(const int64_t* __restrict__ edge_index, const int64_t* __restrict__ edge_type, int64_t E, int half_bits,
+                uint64_t seed, int blocks_a, int64_t k_a, uint64_t offset_a, int64_t* __restrict__ perm_a,
+                int64_t* __restrict__ sel_a, int64_t stride_a, uint8_t* __restrict__ selected_a, int64_t k_b,
+                uint64_t offset_b, int64_t* __restrict__ perm_b, int64_t* __restrict__ sel_b, int64_t stride_b,
+                int64_t* __restrict__ type_b) {
+  const bool first = static_cast<int>(blockIdx.x) < blocks_a;
+  const int64_t i = static_cast<int64_t>(first ? blockIdx.x : blockIdx.x - blocks_a) * kThreads + threadIdx.x;
+  if (i >= (first ? k_a : k_b)) return;
+  const int64_t e = feistel_pick(i, E, half_bits, seed, first ? offset_a : offset_b);
+  if (first) {
+    perm_a[i] = e;
+    sel_a[i] = edge_index[e];
+    sel_a[stride_a + i] = edge_index[E + e];
+    if (selected_a) selected_a[e] = 1;
+  } else {
+    perm_b[i] = e;
+    sel_b[i] = edge_index[e];
+    sel_b[stride_b + i] = edge_index[E + e];
+    if (type_b) type_b[i] = edge_type[e];
+  }
+}
+
 // mask_feature(x, p, mode='col') (reference pretrain.py:41): out = x with column c zeroed when
 // philox(seed, offset)[c] < p  (the keep mask of stemgnn_dropout_keep_mask(D, p, seed, offset)).
 __global__ void __launch_bounds__(kThreads)
@@ -294,6 +319,8 @@ int stemgnn_graph_dropout_undirected(const int32_t* rowptr, const int32_t* src, 
   const unsigned grid = static_cast<unsigned>((N + kThreads - 1) / kThreads);
   k_aug_count<<<grid, kThreads, 0, st>>>(rowptr, src, eid, rowptr_t, dst_t, eid_t, N, p, seed, offset, keep, cnt_a, deg);
   STEMGNN_LAUNCH_CHECK();
+  // (a single-block scan in one launch was measured: one CU cannot stream the 400 KB of counts -- 33-56 us against
+  // 10 us for rocPRIM's two launches)
   size_t need = 0;
   STEMGNN_HIP_TRY(rocprim::exclusive_scan(nullptr, need, deg, a_rowptr, 0, static_cast<size_t>(N),
                                           rocprim::plus<int32_t>(), st, false));
@@ -377,6 +404,33 @@ int stemgnn_sample_edges(const int64_t* edge_index, const int64_t* edge_type, in
   if (bits & 1) ++bits;
   k_sample_edges<<<static_cast<unsigned>((k + kThreads - 1) / kThreads), kThreads, 0, st>>>(
       edge_index, edge_type, E, k, bits / 2, seed, offset, perm, sel_index, sel_stride, sel_type, selected);
+  STEMGNN_LAUNCH_CHECK();
+  return STEMGNN_OK;
+}
+
+int stemgnn_sample_edges2(const int64_t* edge_index, const int64_t* edge_type, int64_t E, uint64_t seed, int64_t k_a,
+                          uint64_t offset_a, int64_t* perm_a, int64_t* sel_index_a, int64_t sel_stride_a,
+                          uint8_t* selected_a, int64_t k_b, uint64_t offset_b, int64_t* perm_b, int64_t* sel_index_b,
+                          int64_t sel_stride_b, int64_t* sel_type_b, void* stream_) {
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  if (E <= 0 || k_a <= 0 || k_b <= 0 || k_a > E || k_b > E || sel_stride_a < k_a || sel_stride_b < k_b)
+    return STEMGNN_ERR_INVALID_ARG;
+  if (!edge_index || !perm_a || !perm_b || !sel_index_a || !sel_index_b || (sel_type_b && !edge_type) ||
+      E >= (1ll << 60))
+    return STEMGNN_ERR_INVALID_ARG;
+  if (selected_a) {
+    k_zero_u8<<<static_cast<unsigned>(std::min<int64_t>((E + kThreads * 16 - 1) / (kThreads * 16), 1024)), kThreads, 0, st>>>(
+        selected_a, E);
+    STEMGNN_LAUNCH_CHECK();
+  }
+  int bits = 2;
+  while ((1ll << bits) < E) ++bits;
+  if (bits & 1) ++bits;
+  const int ba = static_cast<int>((k_a + kThreads - 1) / kThreads), bb = static_cast<int>((k_b + kThreads - 1) / kThreads);
+  k_sample_edges2<<<static_cast<unsigned>(ba + bb), kThreads, 0, st>>>(edge_index, edge_type, E, bits / 2, seed, ba, k_a,
+                                                                     offset_a, perm_a, sel_index_a, sel_stride_a,
+                                                                     selected_a, k_b, offset_b, perm_b, sel_index_b,
+                                                                     sel_stride_b, sel_type_b);
   STEMGNN_LAUNCH_CHECK();
   return STEMGNN_OK;
 }

@@ -179,8 +179,12 @@ int stemgnn_heads_fwd(const stemgnn_heads_params* p, const stemgnn_graph_view* g
 
   // ---- lane A (caller's stream): topology head.  Sampled positives into the left half of the [2, 2k] edge buffer
   // and flagged, negatives that avoid them into the right half (pt_model.py:53-60); edge scores on lin(q); BCE.
-  STEMGNN_TRY(stemgnn_sample_edges(edge_index, nullptr, E, k, seed, off_topo, topo_perm, topo_edges, 2 * k, nullptr,
-                                   s.selected, s0));
+  if (fork)
+    STEMGNN_TRY(stemgnn_sample_edges(edge_index, nullptr, E, k, seed, off_topo, topo_perm, topo_edges, 2 * k, nullptr,
+                                     s.selected, s0));
+  else  // one stream: both edge samples of the phase in one launch
+    STEMGNN_TRY(stemgnn_sample_edges2(edge_index, edge_type, E, seed, k, off_topo, topo_perm, topo_edges, 2 * k, s.selected,
+                                      k, off_ts, ts_perm, ts_edges, k, ts_type, s0));
   STEMGNN_TRY(stemgnn_negative_sample_into(g->rowptr, g->src, g->eid, s.selected, N, k, seed, off_neg, topo_edges + k,
                                            2 * k, s0));
   STEMGNN_TRY(stemgnn_linear_fwd(q, p->w_topo, D, nullptr, nullptr, 0, p->b_topo, N, D, s.zl, nullptr, nullptr, -1, s0));
@@ -195,9 +199,9 @@ int stemgnn_heads_fwd(const stemgnn_heads_params* p, const stemgnn_graph_view* g
 
   // ---- lane B: topo-sem head.  10 % of the edges, their endpoints and types in one launch; the target rows are the
   // type table's; cat(q_u, q_v) -> Linear -> mse (pt_model.py:72-81)
-  STEMGNN_TRY(stemgnn_sample_edges(edge_index, edge_type, E, k, seed, off_ts, ts_perm, ts_edges, k, ts_type, nullptr, s1));
-  STEMGNN_TRY(stemgnn_gather_rows(etab, T, D, ts_type, k, s.target, s1));
-  STEMGNN_TRY(stemgnn_edge_concat_fwd(q, N, D, ts_edges, k, s.zz, s1));
+  if (fork)
+    STEMGNN_TRY(stemgnn_sample_edges(edge_index, edge_type, E, k, seed, off_ts, ts_perm, ts_edges, k, ts_type, nullptr, s1));
+  STEMGNN_TRY(stemgnn_edge_concat_gather(q, N, D, ts_edges, k, s.zz, etab, T, ts_type, s.target, s1));
   if (direct) {
     STEMGNN_TRY(small.add(s.zz, p->w_ts, p->b_ts, k, D, 2 * D, s.h_ts, false, s0));
     STEMGNN_TRY(small.add(q, p->w_feat, p->b_feat, bs, p->in_dim, D, s.h_f, false, s0));
@@ -283,6 +287,7 @@ int stemgnn_heads_bwd(const stemgnn_heads_params* p, int64_t N, const float* q, 
   // STEMGNN_DETERMINISTIC=1 / stemgnn_set_deterministic(1): the two scatters over sampled edges add in a fixed order
   // (edges grouped by node, two sorts each) instead of with fp32 atomics -- bit-reproducible steps, ~0.15 ms slower
   const bool det = stemgnn_set_deterministic(-1) == 1;
+  bool zeroed = false;  // g_zl already cleared (by the loss-gradient launch)
 
   const bool fork = lanes_on();
   hipStream_t s1 = fork ? ln->side[0] : s0, s2 = fork ? ln->side[1] : s0;
@@ -311,6 +316,11 @@ int stemgnn_heads_bwd(const stemgnn_heads_params* p, int64_t N, const float* q, 
     lj.pred_a = s.h_ts; lj.tgt_a = s.target; lj.n_a = k * D; lj.g_a = g_losses + 2; lj.gp_a = g_hts;
     lj.pred_b = s.h_f; lj.tgt_b = x_feat; lj.n_b = bs * I; lj.g_b = g_losses + 0; lj.gp_b = g_hf;
     lj.z = z_teacher; lj.h = s.h_s; lj.rows = bs; lj.D = D; lj.g_c = g_losses + 3; lj.cos_save = s.cos_save; lj.gh = g_hs;
+    if (!det) {  // the same launch clears the topology head's scatter target
+      lj.zero_ptr = g_zl;
+      lj.zero_bytes = (static_cast<int64_t>(N) * D * 4 + 15) / 16 * 16;
+      zeroed = true;
+    }
     STEMGNN_TRY(head_losses_bwd(lj, s0));
   }
   if (!direct) STEMGNN_TRY(stemgnn_linear_bwd_data(g_hts, p->w_ts, k, D, 2 * D, g_zz, s1));
@@ -337,16 +347,19 @@ int stemgnn_heads_bwd(const stemgnn_heads_params* p, int64_t N, const float* q, 
   if (det) {
     STEMGNN_TRY(stemgnn_edge_dot_bwd_det(s.coef, g_losses + 1, s.zl, N, D, topo_edges, 2 * k, g_zl, det_ws, det_bytes, s0));
   } else {
-    STEMGNN_TRY(zero_bytes(g_zl, static_cast<size_t>(N) * D * 4, s0));
+    if (!zeroed) STEMGNN_TRY(zero_bytes(g_zl, static_cast<size_t>(N) * D * 4, s0));
     STEMGNN_TRY(stemgnn_edge_dot_bwd_scaled(s.coef, g_losses + 1, s.zl, N, D, topo_edges, 2 * k, g_zl, s0));
   }
   STEMGNN_TRY(stemgnn_linear_bwd_data(g_zl, p->w_topo, N, D, D, g_q, s0));
   STEMGNN_TRY(weight_grad(g_zl, q, N, D, D, p->g_w_topo, p->b_topo ? p->g_b_topo : nullptr, ws_t, wb_t, s0));
   if (fork) STEMGNN_HIP_TRY(hipStreamWaitEvent(s0, ln->done[0], 0));
-  if (det) STEMGNN_TRY(stemgnn_edge_concat_bwd_det(g_zz, N, D, ts_edges, k, g_q, det_ws, det_bytes, s0));
-  else STEMGNN_TRY(stemgnn_edge_concat_bwd(g_zz, N, D, ts_edges, k, g_q, s0));
-  if (fork) STEMGNN_HIP_TRY(hipStreamWaitEvent(s0, ln->done[1], 0));
-  {
+  if (!det && !fork) {
+    // the scatter of the sampled pairs' gradients and the two seed-row heads' gradients, one launch
+    STEMGNN_TRY(stemgnn_edge_concat_bwd_add(g_zz, N, D, ts_edges, k, g_q, g_head_f, g_head_s, bs * D, s0));
+  } else {
+    if (det) STEMGNN_TRY(stemgnn_edge_concat_bwd_det(g_zz, N, D, ts_edges, k, g_q, det_ws, det_bytes, s0));
+    else STEMGNN_TRY(stemgnn_edge_concat_bwd(g_zz, N, D, ts_edges, k, g_q, s0));
+    if (fork) STEMGNN_HIP_TRY(hipStreamWaitEvent(s0, ln->done[1], 0));
     const int64_t n4 = bs * D / 4;
     int64_t grid = (n4 + kBlock - 1) / kBlock;
     if (grid > 2048) grid = 2048;

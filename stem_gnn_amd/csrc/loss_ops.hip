@@ -164,7 +164,7 @@ struct HeadLossTable {
   HeadLossJobs j;
   double *part_a, *part_b, *part_c;
   unsigned int *cnt_a, *cnt_b, *cnt_c;
-  int ba, bb, bc;
+  int ba, bb, bc, bz;
 };
 __global__ void __launch_bounds__(256) k_head_losses_fwd(const HeadLossTable t) {
   __shared__ double red[256];
@@ -183,7 +183,15 @@ __global__ void __launch_bounds__(256) k_head_losses_bwd(const HeadLossTable t) 
   const int b = blockIdx.x;
   if (b < t.ba) mse_bwd_body(t.j.pred_a, t.j.tgt_a, t.j.n_a, 1.0f, t.j.g_a, t.j.gp_a, b, t.ba);
   else if (b < t.ba + t.bb) mse_bwd_body(t.j.pred_b, t.j.tgt_b, t.j.n_b, 1.0f, t.j.g_b, t.j.gp_b, b - t.ba, t.bb);
-  else cos_bwd_body(t.j.z, t.j.h, t.j.rows, static_cast<int>(t.j.D), 1.0f, t.j.g_c, t.j.cos_save, t.j.gh, b - t.ba - t.bb);
+  else if (b < t.ba + t.bb + t.bc)
+    cos_bwd_body(t.j.z, t.j.h, t.j.rows, static_cast<int>(t.j.D), 1.0f, t.j.g_c, t.j.cos_save, t.j.gh, b - t.ba - t.bb);
+  else {  // the clearing job: plain 16-byte stores, grid-stride over its bz blocks
+    uint4* zp = reinterpret_cast<uint4*>(t.j.zero_ptr);
+    const int64_t n16 = t.j.zero_bytes / 16;
+    for (int64_t i = static_cast<int64_t>(b - t.ba - t.bb - t.bc) * 256 + threadIdx.x; i < n16;
+         i += static_cast<int64_t>(t.bz) * 256)
+      zp[i] = make_uint4(0u, 0u, 0u, 0u);
+  }
 }
 
 // Orthogonal regulariser on embed[:, ids] ([H, M, Dc] selected codes).  One WAVE per (head, i):
@@ -280,7 +288,9 @@ k_ortho(const float* __restrict__ embed, const int64_t* __restrict__ ids, int H,
 template <bool BWD>
 __global__ void __launch_bounds__(256)
 k_ortho_block(const float* __restrict__ embed, const int64_t* __restrict__ ids, int H, int K, int Dc, int M, float scale,
-              const float* __restrict__ g, double* __restrict__ partial /*[H][4]*/, float* __restrict__ g_embed) {
+              const float* __restrict__ g, double* __restrict__ partial /*[H][4]*/, float* __restrict__ g_embed,
+              unsigned int* counter = nullptr, double mul = 0.0, double add = 0.0, float* __restrict__ loss = nullptr,
+              const float* __restrict__ plus = nullptr, float* __restrict__ total = nullptr) {
   // grid (heads, 4): block (h, b) owns selected rows 8 b .. 8 b + 7 -- a row per 32 lanes -- against all M rows
   constexpr int kMaxM = 32, kMaxD = 256;
   __shared__ __attribute__((aligned(16))) float cs[kMaxM][kMaxD + 4];  // normalised rows
@@ -348,7 +358,17 @@ k_ortho_block(const float* __restrict__ embed, const int64_t* __restrict__ ids, 
       if (tid < o) red[tid] += red[tid + o];
       __syncthreads();
     }
-    if (tid == 0) partial[h * 4 + blockIdx.y] = red[0];
+    if (tid == 0) { st_agent(partial + h * 4 + blockIdx.y, red[0]); wait_stores(); }
+    // the block that arrives last adds the 4 H block sums in index order and writes the loss (and, for the quantiser's
+    // phase, the sum with the commitment term): no finishing launch
+    if (!ticket_last(counter)) return;
+    if (tid == 0) {
+      double s = 0.0;
+      for (int i = 0; i < 4 * H; ++i) s += ld_agent(partial + i);
+      const float v = static_cast<float>(s * mul + add);
+      loss[0] = v;
+      if (total) total[0] = (plus ? plus[0] : 0.f) + v;
+    }
     return;
   }
   __syncthreads();
@@ -455,6 +475,7 @@ int head_losses_fwd(const HeadLossJobs& j, hipStream_t st) {
   t.ba = mse_blocks(j.n_a);
   t.bb = mse_blocks(j.n_b);
   t.bc = static_cast<int>((j.rows + 3) / 4);
+  t.bz = 0;
   k_head_losses_fwd<<<static_cast<unsigned>(t.ba + t.bb + t.bc), 256, 0, st>>>(t);
   STEMGNN_LAUNCH_CHECK();
   return STEMGNN_OK;
@@ -468,7 +489,13 @@ int head_losses_bwd(const HeadLossJobs& j, hipStream_t st) {
   t.ba = mse_bwd_blocks(j.n_a);
   t.bb = mse_bwd_blocks(j.n_b);
   t.bc = static_cast<int>((j.rows + 3) / 4);
-  k_head_losses_bwd<<<static_cast<unsigned>(t.ba + t.bb + t.bc), 256, 0, st>>>(t);
+  t.bz = 0;
+  if (j.zero_ptr && j.zero_bytes > 0) {
+    if (j.zero_bytes % 16 != 0 || reinterpret_cast<uintptr_t>(j.zero_ptr) % 16 != 0) return STEMGNN_ERR_INVALID_ARG;
+    const int64_t b = (j.zero_bytes / 16 + 255) / 256;
+    t.bz = static_cast<int>(b > 2048 ? 2048 : b);
+  }
+  k_head_losses_bwd<<<static_cast<unsigned>(t.ba + t.bb + t.bc + t.bz), 256, 0, st>>>(t);
   STEMGNN_LAUNCH_CHECK();
   return STEMGNN_OK;
 }
@@ -584,9 +611,14 @@ int stemgnn::ortho_loss_fwd_plus(const float* embed, const int64_t* ids, int64_t
   const int H = static_cast<int>(heads), M = static_cast<int>(num_ids);
   int nparts = H * M;
   if (ortho_block_ok(M, static_cast<int>(code_dim))) {
-    nparts = 4 * H;
-    k_ortho_block<false><<<dim3(H, 4), 256, 0, st>>>(embed, ids, H, static_cast<int>(codebook_size), static_cast<int>(code_dim), M,
-                                            scale, nullptr, partial, nullptr);
+    unsigned int* counter = ticket_counter(loss);
+    if (!counter) return STEMGNN_ERR_HIP;
+    k_ortho_block<false><<<dim3(H, 4), 256, 0, st>>>(embed, ids, H, static_cast<int>(codebook_size),
+                                                     static_cast<int>(code_dim), M, scale, nullptr, partial, nullptr, counter,
+                                                     static_cast<double>(scale) / (static_cast<double>(H) * M * M),
+                                                     -static_cast<double>(scale) / M, loss, plus, total);
+    STEMGNN_LAUNCH_CHECK();
+    return STEMGNN_OK;
   } else {
     launch_ortho<false>(H * M, st, embed, ids, H, static_cast<int>(codebook_size), static_cast<int>(code_dim), M, scale,
                         nullptr, partial, nullptr);
