@@ -106,6 +106,19 @@ def total_loss(losses: Dict[str, torch.Tensor], params: Dict) -> torch.Tensor:
 _WEIGHT_CACHE: Dict = {}
 
 
+_ONES = {}
+
+
+def _ones_like_loss(loss):
+    """The seed gradient of ``loss.backward()`` (a tensor of ones shaped like the loss), allocated once per device and
+    shape instead of filled by a launch every step."""
+    key = (loss.device, tuple(loss.shape), loss.dtype)
+    t = _ONES.get(key)
+    if t is None:
+        t = _ONES[key] = torch.ones_like(loss)
+    return t
+
+
 def pretrain_step(model: PretrainModel, optimizer, scheduler, params: Dict, x, edge_index, edge_attr, bs: int,
                   draws: Optional[Dict] = None, record_draws: bool = True, no_codebook: bool = False,
                   grad_sync=None, forward_fn=None):
@@ -140,7 +153,7 @@ def pretrain_step(model: PretrainModel, optimizer, scheduler, params: Dict, x, e
     loss = total_loss(losses, params)
 
     optimizer.zero_grad(set_to_none=True)
-    loss.backward()
+    loss.backward(gradient=_ones_like_loss(loss))  # a cached 1.0: autograd's own seed is a fill launch per step
     if grad_sync is not None:
         grad_sync()
     grads = [p.grad for p in _trainable(model) if p.grad is not None]

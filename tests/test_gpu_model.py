@@ -760,7 +760,8 @@ def test_deterministic_mode_makes_steps_bit_reproducible(dev):
         if g1 is None:
             continue
         seen += 1
-        torch.testing.assert_close(g1, g2, rtol=1e-3, atol=1e-5 * max(float(g2.abs().max()), 1e-3))
+        # (a bias in front of a BatchNorm has a mathematically zero gradient: what is compared there is rounding noise)
+        torch.testing.assert_close(g1, g2, rtol=1e-3, atol=max(1e-5 * float(g2.abs().max()), 1e-6))
     assert seen > 10
 
 
