@@ -545,34 +545,6 @@ int stemgnn_adamw_step(float* const* params, const float* const* grads, float* c
                        void* stream);
 
 /* ------------------------------------------------------------------------------------
- * Dense products on pre-cut operands ("planes"): an fp32 matrix [M, K] stored as its three exact bf16 pieces,
- * uint16 [3][M][K] with plane p at p * plane_stride elements (csrc/pgemm.hip).  Producers write the planes once;
- * the products stage them by LDS-DMA and issue only matrix instructions.  Same arithmetic and results as
- * stemgnn_linear_fwd / _bwd_data / _bwd_weight in their default mode.  K (the contraction length of the forward
- * form) must be a multiple of 16 (stemgnn_planes_ok), N and K of the weight gradient multiples of 8.
- * ------------------------------------------------------------------------------------ */
-int stemgnn_planes_ok(int64_t k);
-/* planes of an fp32 matrix (rows * cols a multiple of 8). */
-int stemgnn_split_planes(const float* x, int64_t rows, int64_t cols, uint16_t* planes, int64_t plane_stride,
-                         void* stream);
-/* planes of up to 12 weight matrices in one launch; transpose[i] != 0 stores the planes of weights[i]^T
- * ([cols][rows]) -- what backward-data contracts against.  planes[i]: 3 * rows * cols uint16. */
-int stemgnn_prep_weight_planes(const float* const* weights_host, const int64_t* rows_host, const int64_t* cols_host,
-                               const int32_t* transpose_host, uint16_t* const* planes_host, int32_t count, void* stream);
-/* y [M, N] = a1 w1^T (+ a2 w2^T) + bias: a1 [*, k1] (rows >= a1_rows count as zero and are not read; -1: all M),
- * a2 [M, k2] (k2 = 0: none), w1 / w2 = planes of [N, k1] / [N, k2] (plane stride N * k).  stats_partial (NULL: none):
- * [stemgnn_pgemm_stats_blocks(M)][2][N] column sums / sums of squares of y per 128-row tile. */
-int64_t stemgnn_pgemm_stats_blocks(int64_t num_rows);
-int stemgnn_pgemm_fwd(const uint16_t* a1, int64_t a1_stride, int64_t k1, int64_t a1_rows, const uint16_t* w1,
-                      const uint16_t* a2, int64_t a2_stride, int64_t k2, const uint16_t* w2, const float* bias,
-                      int64_t num_rows, int64_t out_dim, float* y, float* stats_partial, void* stream);
-/* dw [N, K] = dy^T x over M rows (dy planes [M, N], x planes [M, K]); db [N] = column sums of dy (NULL: skip). */
-size_t stemgnn_pgemm_dw_workspace_bytes(int64_t num_rows, int64_t out_dim, int64_t in_dim);
-int stemgnn_pgemm_dw(const uint16_t* dy, int64_t dy_stride, const uint16_t* x, int64_t x_stride, int64_t num_rows,
-                     int64_t out_dim, int64_t in_dim, float* dw, float* db, void* workspace, size_t workspace_bytes,
-                     void* stream);
-
-/* ------------------------------------------------------------------------------------
  * bf16 feature storage (BASELINE config 5): the *_k forms of the entry points above take the node-feature /
  * layer-output operand as either fp32 or bf16 (`kind`: STEMGNN_F32 / STEMGNN_BF16; `void*` = float* or uint16_t*).
  * ------------------------------------------------------------------------------------ */

@@ -104,13 +104,6 @@ _SIGNATURES = {
     "stemgnn_vq_fwd": (c_int, [P, P, I64, c_int, P, P, P, P, c_size_t, P]),
     "stemgnn_vq_bwd_scratch_bytes": (c_size_t, [P, I64]),
     "stemgnn_vq_bwd": (c_int, [P, P, I64, P, P, P, P, P, c_size_t, P, c_size_t, P]),
-    "stemgnn_planes_ok": (c_int, [I64]),
-    "stemgnn_split_planes": (c_int, [P, I64, I64, P, I64, P]),
-    "stemgnn_prep_weight_planes": (c_int, [P, P, P, P, P, I32, P]),
-    "stemgnn_pgemm_stats_blocks": (I64, [I64]),
-    "stemgnn_pgemm_fwd": (c_int, [P, I64, I64, I64, P, P, I64, I64, P, P, I64, I64, P, P, P]),
-    "stemgnn_pgemm_dw_workspace_bytes": (c_size_t, [I64, I64, I64]),
-    "stemgnn_pgemm_dw": (c_int, [P, I64, P, I64, I64, I64, I64, P, P, P, c_size_t, P]),
     "stemgnn_heads_save_bytes": (c_size_t, [P, I64, I64, I64, I64]),
     "stemgnn_heads_fwd": (c_int, [P, P, P, P, I64, P, I64, P, P, P, I64, I64, c_uint64, c_uint64, c_uint64, c_uint64,
                                   P, P, P, P, P, P, P, c_size_t, P]),

@@ -171,12 +171,26 @@ int linear_ws_launch(const float* x, const float* w, const float* bias, int64_t 
 // the separate one-block finishing launch (5 us of launch floor for 256 additions) disappears.
 // No fences: on this part a device-scope fence writes back and invalidates the XCD's whole L2 (measured: the
 // arg-max kernel went from 121 to 345 us with one __threadfence() per block).  Instead the few words that cross
-// blocks bypass the caches: a partial is written with st_agent (device-scope store) and wait_stores() holds the
-// thread until memory has acknowledged it; then ticket_last() (all threads of the block) takes a ticket with a
-// relaxed device-scope atomic; the last block reads the partials with ld_agent.  The counter resets itself.
-// csrc/loss_ops.hip owns the counters: ticket_counter(key) returns one of 61 zero-initialised device words, chosen
-// by the key (the output pointer); distinct outputs on concurrently running streams should not share a key.
-unsigned int* ticket_counter(const void* key);
+// blocks bypass the caches.  The hand-off is the form MI355X_MICROARCH.md lists as measured-valid on gfx950 / ROCm 7.2
+// ("Workgroup dispatch, XCD placement & inter-workgroup visibility", first row of the sc1 table) -- an observed
+// property of this part, NOT a guarantee of the HIP memory model, which is why the file refuses to compile for
+// anything else (below) and why tests/test_gpu_kernels.py::test_ticketed_reduction_many_blocks_many_rounds pins it:
+//   producer: every partial is written with st_agent (a device-scope relaxed atomic store = a write-through `sc1`
+//             store); the storing thread runs wait_stores() (s_waitcnt vmcnt(0): memory has acknowledged it); a
+//             workgroup barrier; then ONE lane takes the ticket with a device-scope relaxed atomic add;
+//   consumer: the workgroup whose add returned total - 1; its other waves pass a workgroup barrier behind that add and
+//             read every partial with ld_agent (an `sc1` load: served by L2 / memory, never by the CU's L1).
+// The counter resets itself.  Counters come from a per-(device, stream) pool (csrc/loss_ops.hip: ticket_counter): kernels
+// of one stream run one after the other, so they may share words; reductions enqueued on different streams never do.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "common.h: the fence-free last-block protocol (st_agent / wait_stores / ticket_last) is validated on gfx950 (and gfx942) only"
+#endif
+constexpr int kTicketSlots = 16;  // counter words per (device, stream); distinct reductions of ONE launch take distinct slots
+// slot-th zero-initialised counter word of the calling thread's current device and the given stream (nullptr: the
+// allocation failed).  First use per stream allocates (hipMalloc + hipMemset: not inside a stream capture).
+unsigned int* ticket_counter(hipStream_t st, int slot = 0);
+// 512 doubles of per-(device, stream) scratch for partial sums of launches that take no workspace from the caller
+double* stream_partials(hipStream_t st);
 __device__ __forceinline__ void st_agent(double* p, double v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -189,9 +203,16 @@ __device__ __forceinline__ double ld_agent(const double* p) {
 __device__ __forceinline__ float ld_agent(const float* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// s_waitcnt immediate of the gfx9 family (gfx942 / gfx950): vmcnt = bits [3:0] and [15:14], expcnt = [6:4],
+// lgkmcnt = [11:8]; a field at its maximum means "do not wait on this counter"
+constexpr int gfx9_waitcnt(int vmcnt, int expcnt, int lgkmcnt) {
+  return (vmcnt & 0xF) | ((vmcnt >> 4) << 14) | ((expcnt & 0x7) << 4) | ((lgkmcnt & 0xF) << 8);
+}
+constexpr int kWaitVmcnt0 = gfx9_waitcnt(0, 7, 15);  // vmcnt(0), nothing else
+static_assert(kWaitVmcnt0 == 0x0F70, "gfx9 s_waitcnt encoding");
 __device__ __forceinline__ void wait_stores() {
   __atomic_signal_fence(__ATOMIC_SEQ_CST);
-  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), nothing else: this thread's stores have been acknowledged
+  __builtin_amdgcn_s_waitcnt(kWaitVmcnt0);  // this thread's stores have been acknowledged by memory
   __atomic_signal_fence(__ATOMIC_SEQ_CST);
 }
 // `total`: the number of blocks that take a ticket on this counter (a launch that serves several reductions gives
@@ -284,12 +305,6 @@ struct DwBatch {
           void* workspace, size_t workspace_bytes, hipStream_t st);
   int flush(hipStream_t st);
 };
-
-// csrc/linear.hip: row-split count of a weight-gradient product and the fixed-order reduction of its partial slabs
-// (out[i] = sum_s partial[s][i]; the second family, e.g. the bias gradient, is optional), shared with csrc/pgemm.hip
-int plane_split_count(int64_t M, int64_t out_tiles);
-int reduce_splits_launch(const float* partial, int splits, int64_t n, float* out, const float* partial2, int64_t n2,
-                         float* out2, hipStream_t st);
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }

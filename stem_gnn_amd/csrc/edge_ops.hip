@@ -440,7 +440,7 @@ int stemgnn_edge_dot_bce(const float* z, int64_t N, int64_t D, const int64_t* ed
   if (!z || !edge_index || !coef || !workspace) return STEMGNN_ERR_INVALID_ARG;
   if (workspace_bytes < stemgnn_edge_dot_bce_workspace_bytes(E)) return STEMGNN_ERR_WORKSPACE;
   double* partial = reinterpret_cast<double*>(align_up(reinterpret_cast<uintptr_t>(workspace), 256));
-  unsigned int* counter = ticket_counter(loss);
+  unsigned int* counter = ticket_counter(st);
   if (!counter) return STEMGNN_ERR_HIP;
   STEMGNN_EDGE_DISPATCH(k_edge_dot_bce, E, z, N, static_cast<int>(D), edge_index, kp, kn, loss, coef, partial, counter);
   return STEMGNN_OK;
@@ -449,17 +449,14 @@ int stemgnn_edge_dot_bce(const float* z, int64_t N, int64_t D, const int64_t* ed
 int stemgnn_edge_bce_loss(const float* dots, int64_t kp, int64_t kn, float* loss, float* coef, void* stream_) {
   if (kp < 0 || kn < 0 || !loss) return STEMGNN_ERR_INVALID_ARG;
   if (kp + kn > 0 && (!dots || !coef)) return STEMGNN_ERR_INVALID_ARG;
-  static double* partial = [] {  // [256 blocks][2], one call in flight per device (the step's stream order)
-    double* p = nullptr;
-    return hipMalloc(&p, 512 * sizeof(double)) == hipSuccess ? p : static_cast<double*>(nullptr);
-  }();
-  unsigned int* counter = ticket_counter(loss);
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  double* partial = stream_partials(st);  // [256 blocks][2] of the stream's own scratch (csrc/loss_ops.hip)
+  unsigned int* counter = ticket_counter(st);
   if (!partial || !counter) return STEMGNN_ERR_HIP;
   int64_t blocks = (kp + kn + 1023) / 1024;
   if (blocks < 1) blocks = 1;
   if (blocks > 256) blocks = 256;
-  k_edge_bce<<<static_cast<unsigned>(blocks), 256, 0, static_cast<hipStream_t>(stream_)>>>(dots, kp, kn, loss, coef,
-                                                                                          partial, counter);
+  k_edge_bce<<<static_cast<unsigned>(blocks), 256, 0, st>>>(dots, kp, kn, loss, coef, partial, counter);
   STEMGNN_LAUNCH_CHECK();
   return STEMGNN_OK;
 }

@@ -5,14 +5,12 @@
 //   topo-sem     mse(topo_sem_recon_decoder(cat(q_u, q_v)), edge_attr) on 10 % sampled edges  :72-81
 //   semantic     mean(1 - cos(teacher[:bs], sem_projector(q[:bs])))                         :93-100
 // The heads are independent chains of small, latency-bound launches (1 024-row and 11 k-row products, one-block
-// reductions).  One call enqueues all of them (the arithmetic is that of the single-op entry points, which is what
-// gets launched); optionally (STEMGNN_HEADS_LANES=1) the three chains go to three streams forked from the caller's
-// stream and joined before the call returns -- measured slower than one stream on this part, see lanes_on().
+// reductions).  One call enqueues all of them on the caller's stream (the arithmetic is that of the single-op entry
+// points).  Forking the three chains onto side streams was measured in round 2 (2.04-2.09 vs 1.97 ms per C4 step: the
+// cross-stream event waits cost more than the overlap of these short chains returns) and is gone from the library.
 #include "common.h"
 
 #include <algorithm>
-#include <cstdlib>
-#include <mutex>
 
 namespace stemgnn {
 namespace {
@@ -38,41 +36,6 @@ struct Carver {
     const int rc__ = (expr);              \
     if (rc__ != STEMGNN_OK) return rc__;  \
   } while (0)
-
-// Side streams + events of one device, created on first use and kept for the life of the process.
-struct Lanes {
-  hipStream_t side[2] = {nullptr, nullptr};
-  hipEvent_t fork = nullptr, done[2] = {nullptr, nullptr};
-  bool ready = false;
-};
-std::mutex g_lanes_mu;
-Lanes g_lanes[16];
-
-int get_lanes(Lanes** out) {
-  int dev = 0;
-  STEMGNN_HIP_TRY(hipGetDevice(&dev));
-  if (dev < 0 || dev >= 16) return STEMGNN_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lock(g_lanes_mu);
-  Lanes& l = g_lanes[dev];
-  if (!l.ready) {
-    for (int i = 0; i < 2; ++i) {
-      STEMGNN_HIP_TRY(hipStreamCreateWithFlags(&l.side[i], hipStreamNonBlocking));
-      STEMGNN_HIP_TRY(hipEventCreateWithFlags(&l.done[i], hipEventDisableTiming));
-    }
-    STEMGNN_HIP_TRY(hipEventCreateWithFlags(&l.fork, hipEventDisableTiming));
-    l.ready = true;
-  }
-  *out = &l;
-  return STEMGNN_OK;
-}
-
-// STEMGNN_HEADS_LANES=1 forks the three chains onto side streams (A/B switch; default: the caller's stream only)
-inline bool lanes_on() {
-  // measured on C4 (same box, 40 steps each, alternating): 2.04-2.09 ms/step with the lanes, 1.97 without -- the
-  // cross-stream event waits cost more than the overlap of these short chains returns.  Off unless asked for.
-  static const bool on = [] { const char* e = getenv("STEMGNN_HEADS_LANES"); return e && e[0] == '1'; }();
-  return on;
-}
 
 __global__ void __launch_bounds__(kBlock) k_zero16(uint4* __restrict__ p, int64_t n16) {
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n16;
@@ -166,78 +129,46 @@ int stemgnn_heads_fwd(const stemgnn_heads_params* p, const stemgnn_graph_view* g
     return STEMGNN_ERR_INVALID_ARG;
   if (save_bytes < stemgnn_heads_save_bytes(p, N, E, bs, k)) return STEMGNN_ERR_WORKSPACE;
   hipStream_t s0 = static_cast<hipStream_t>(stream);
-  Lanes* ln = nullptr;
-  STEMGNN_TRY(get_lanes(&ln));
   const HeadsSave s = plan_heads(save, p, N, E, bs, k);
-  const bool fork = lanes_on();
-  hipStream_t s1 = fork ? ln->side[0] : s0, s2 = fork ? ln->side[1] : s0;
-  if (fork) {
-    STEMGNN_HIP_TRY(hipEventRecord(ln->fork, s0));
-    STEMGNN_HIP_TRY(hipStreamWaitEvent(s1, ln->fork, 0));
-    STEMGNN_HIP_TRY(hipStreamWaitEvent(s2, ln->fork, 0));
-  }
 
-  // ---- lane A (caller's stream): topology head.  Sampled positives into the left half of the [2, 2k] edge buffer
-  // and flagged, negatives that avoid them into the right half (pt_model.py:53-60); edge scores on lin(q); BCE.
-  if (fork)
-    STEMGNN_TRY(stemgnn_sample_edges(edge_index, nullptr, E, k, seed, off_topo, topo_perm, topo_edges, 2 * k, nullptr,
-                                     s.selected, s0));
-  else  // one stream: both edge samples of the phase in one launch
-    STEMGNN_TRY(stemgnn_sample_edges2(edge_index, edge_type, E, seed, k, off_topo, topo_perm, topo_edges, 2 * k, s.selected,
-                                      k, off_ts, ts_perm, ts_edges, k, ts_type, s0));
+  // ---- topology head.  Sampled positives into the left half of the [2, 2k] edge buffer and flagged, negatives that
+  // avoid them into the right half (pt_model.py:53-60); edge scores on lin(q); BCE.  Both edge samples of the phase
+  // (this head's and the topo-sem head's) come from one launch.
+  STEMGNN_TRY(stemgnn_sample_edges2(edge_index, edge_type, E, seed, k, off_topo, topo_perm, topo_edges, 2 * k, s.selected,
+                                    k, off_ts, ts_perm, ts_edges, k, ts_type, s0));
   STEMGNN_TRY(stemgnn_negative_sample_into(g->rowptr, g->src, g->eid, s.selected, N, k, seed, off_neg, topo_edges + k,
                                            2 * k, s0));
   STEMGNN_TRY(stemgnn_linear_fwd(q, p->w_topo, D, nullptr, nullptr, 0, p->b_topo, N, D, s.zl, nullptr, nullptr, -1, s0));
   // edge scores and the BCE terms / coefficients in one launch
   STEMGNN_TRY(stemgnn_edge_dot_bce(s.zl, N, D, topo_edges, k, k, losses + 1, s.coef, s.bce_ws, s.bce_bytes, s0));
 
-  // The three products over few rows (sampled pairs, seed rows) share one launch when everything runs on one
-  // stream (DirectBatch, csrc/wsgemm.hip): on their own they are 8 - 90 tiles on 256 CUs, 12 - 20 us each.
-  const bool direct = !fork && stemgnn_linear_set_mode(-1) == 1 && linear_direct_ok(k, D, 2 * D) &&
+  // The three products over few rows (sampled pairs, seed rows) share one launch (DirectBatch, csrc/wsgemm.hip): on
+  // their own they are 8 - 90 tiles on 256 CUs, 12 - 20 us each.
+  const bool direct = stemgnn_linear_set_mode(-1) == 1 && linear_direct_ok(k, D, 2 * D) &&
                       linear_direct_ok(bs, p->in_dim, D) && linear_direct_ok(bs, D, D);
   DirectBatch small;
 
-  // ---- lane B: topo-sem head.  10 % of the edges, their endpoints and types in one launch; the target rows are the
-  // type table's; cat(q_u, q_v) -> Linear -> mse (pt_model.py:72-81)
-  if (fork)
-    STEMGNN_TRY(stemgnn_sample_edges(edge_index, edge_type, E, k, seed, off_ts, ts_perm, ts_edges, k, ts_type, nullptr, s1));
-  STEMGNN_TRY(stemgnn_edge_concat_gather(q, N, D, ts_edges, k, s.zz, etab, T, ts_type, s.target, s1));
+  // ---- topo-sem head.  The target rows are the type table's; cat(q_u, q_v) -> Linear -> mse (pt_model.py:72-81)
+  STEMGNN_TRY(stemgnn_edge_concat_gather(q, N, D, ts_edges, k, s.zz, etab, T, ts_type, s.target, s0));
   if (direct) {
     STEMGNN_TRY(small.add(s.zz, p->w_ts, p->b_ts, k, D, 2 * D, s.h_ts, false, s0));
     STEMGNN_TRY(small.add(q, p->w_feat, p->b_feat, bs, p->in_dim, D, s.h_f, false, s0));
     STEMGNN_TRY(small.add(q, p->w_sem, p->b_sem, bs, D, D, s.h_s, false, s0));
     STEMGNN_TRY(small.flush(s0));
   } else {
-    STEMGNN_TRY(stemgnn_linear_fwd(s.zz, p->w_ts, 2 * D, nullptr, nullptr, 0, p->b_ts, k, D, s.h_ts, nullptr, nullptr, -1, s1));
-  }
-  if (fork) {
-    STEMGNN_TRY(stemgnn_mse_loss_fwd(s.h_ts, s.target, k * D, 1.0f, losses + 2, s.ws[0], s.ws_bytes, s1));
-    STEMGNN_HIP_TRY(hipEventRecord(ln->done[0], s1));
-  }
-
-  // ---- lane C: the two heads on the seed rows q[:bs] (pt_model.py:42-43, 93-100)
-  if (!direct)
+    STEMGNN_TRY(stemgnn_linear_fwd(s.zz, p->w_ts, 2 * D, nullptr, nullptr, 0, p->b_ts, k, D, s.h_ts, nullptr, nullptr, -1, s0));
+    // ---- the two heads on the seed rows q[:bs] (pt_model.py:42-43, 93-100)
     STEMGNN_TRY(stemgnn_linear_fwd(q, p->w_feat, D, nullptr, nullptr, 0, p->b_feat, bs, p->in_dim, s.h_f, nullptr, nullptr,
-                                   -1, s2));
-  if (fork) STEMGNN_TRY(stemgnn_mse_loss_fwd(s.h_f, x_feat, bs * p->in_dim, 1.0f, losses + 0, s.ws[1], s.ws_bytes, s2));
-  if (!direct)
-    STEMGNN_TRY(stemgnn_linear_fwd(q, p->w_sem, D, nullptr, nullptr, 0, p->b_sem, bs, D, s.h_s, nullptr, nullptr, -1, s2));
-  if (fork) {
-    STEMGNN_TRY(stemgnn_cosine_loss_fwd(z_teacher, s.h_s, bs, D, 1.0f, losses + 3, s.cos_save, s.ws[2], s.ws_bytes, s2));
-  } else {
-    // one stream: the three losses of these heads in one launch (csrc/loss_ops.hip: same sums, same order)
-    HeadLossJobs lj{};
-    lj.pred_a = s.h_ts; lj.tgt_a = s.target; lj.n_a = k * D; lj.loss_a = losses + 2; lj.ws_a = s.ws[0];
-    lj.pred_b = s.h_f; lj.tgt_b = x_feat; lj.n_b = bs * p->in_dim; lj.loss_b = losses + 0; lj.ws_b = s.ws[1];
-    lj.z = z_teacher; lj.h = s.h_s; lj.rows = bs; lj.D = D; lj.loss_c = losses + 3; lj.cos_save = s.cos_save;
-    lj.ws_c = s.ws[2];
-    STEMGNN_TRY(head_losses_fwd(lj, s0));
+                                   -1, s0));
+    STEMGNN_TRY(stemgnn_linear_fwd(q, p->w_sem, D, nullptr, nullptr, 0, p->b_sem, bs, D, s.h_s, nullptr, nullptr, -1, s0));
   }
-  if (fork) {
-    STEMGNN_HIP_TRY(hipEventRecord(ln->done[1], s2));
-    STEMGNN_HIP_TRY(hipStreamWaitEvent(s0, ln->done[0], 0));
-    STEMGNN_HIP_TRY(hipStreamWaitEvent(s0, ln->done[1], 0));
-  }
+  // the three losses of these heads in one launch (csrc/loss_ops.hip: same sums, same order as the single-op calls)
+  HeadLossJobs lj{};
+  lj.pred_a = s.h_ts; lj.tgt_a = s.target; lj.n_a = k * D; lj.loss_a = losses + 2; lj.ws_a = s.ws[0];
+  lj.pred_b = s.h_f; lj.tgt_b = x_feat; lj.n_b = bs * p->in_dim; lj.loss_b = losses + 0; lj.ws_b = s.ws[1];
+  lj.z = z_teacher; lj.h = s.h_s; lj.rows = bs; lj.D = D; lj.loss_c = losses + 3; lj.cos_save = s.cos_save;
+  lj.ws_c = s.ws[2];
+  STEMGNN_TRY(head_losses_fwd(lj, s0));
   return STEMGNN_OK;
 }
 
@@ -263,8 +194,6 @@ int stemgnn_heads_bwd(const stemgnn_heads_params* p, int64_t N, const float* q, 
     return STEMGNN_ERR_WORKSPACE;
   const int64_t D = p->dim, I = p->in_dim;
   hipStream_t s0 = static_cast<hipStream_t>(stream);
-  Lanes* ln = nullptr;
-  STEMGNN_TRY(get_lanes(&ln));
   const HeadsSave s = plan_heads(save, p, N, E, bs, k);
   Carver c(scratch);
   float* g_zl = c.take<float>(static_cast<size_t>(N) * D);
@@ -289,61 +218,40 @@ int stemgnn_heads_bwd(const stemgnn_heads_params* p, int64_t N, const float* q, 
   const bool det = stemgnn_set_deterministic(-1) == 1;
   bool zeroed = false;  // g_zl already cleared (by the loss-gradient launch)
 
-  const bool fork = lanes_on();
-  hipStream_t s1 = fork ? ln->side[0] : s0, s2 = fork ? ln->side[1] : s0;
-  // one stream: the four weight gradients run as one split-product launch and one reduction at the end (DwBatch)
+  // the four weight gradients run as one split-product launch and one reduction at the end (DwBatch)
   DwBatch dws;
-  auto weight_grad = [&](const float* dy, const float* x, int64_t M, int64_t N_, int64_t K_, float* dw, float* db, void* ws,
-                         size_t wb, hipStream_t st) -> int {
-    if (fork) return stemgnn_linear_bwd_weight(dy, x, M, N_, K_, dw, db, ws, wb, st);
-    return dws.add(dy, x, kF32, M, N_, K_, dw, db, ws, wb, st);
-  };
-  if (fork) {
-    STEMGNN_HIP_TRY(hipEventRecord(ln->fork, s0));
-    STEMGNN_HIP_TRY(hipStreamWaitEvent(s1, ln->fork, 0));
-    STEMGNN_HIP_TRY(hipStreamWaitEvent(s2, ln->fork, 0));
-  }
-
-  const bool direct = !fork && stemgnn_linear_set_mode(-1) == 1 && linear_direct_ok(k, 2 * D, D) &&
-                      linear_direct_ok(bs, D, I) && linear_direct_ok(bs, D, D);
+  const bool direct = stemgnn_linear_set_mode(-1) == 1 && linear_direct_ok(k, 2 * D, D) && linear_direct_ok(bs, D, I) &&
+                      linear_direct_ok(bs, D, D);
   DirectBatch small;  // the three backward-data products over few rows, one launch (see stemgnn_heads_fwd)
 
-  // ---- lane B: topo-sem head back to the gathered pairs
-  if (fork) {
-    STEMGNN_TRY(stemgnn_mse_loss_bwd(s.h_ts, s.target, k * D, 1.0f, g_losses + 2, g_hts, s1));
-  } else {
-    HeadLossJobs lj{};  // the three loss gradients in one launch
-    lj.pred_a = s.h_ts; lj.tgt_a = s.target; lj.n_a = k * D; lj.g_a = g_losses + 2; lj.gp_a = g_hts;
-    lj.pred_b = s.h_f; lj.tgt_b = x_feat; lj.n_b = bs * I; lj.g_b = g_losses + 0; lj.gp_b = g_hf;
-    lj.z = z_teacher; lj.h = s.h_s; lj.rows = bs; lj.D = D; lj.g_c = g_losses + 3; lj.cos_save = s.cos_save; lj.gh = g_hs;
-    if (!det) {  // the same launch clears the topology head's scatter target
-      lj.zero_ptr = g_zl;
-      lj.zero_bytes = (static_cast<int64_t>(N) * D * 4 + 15) / 16 * 16;
-      zeroed = true;
-    }
-    STEMGNN_TRY(head_losses_bwd(lj, s0));
+  // ---- the three loss gradients in one launch
+  HeadLossJobs lj{};
+  lj.pred_a = s.h_ts; lj.tgt_a = s.target; lj.n_a = k * D; lj.g_a = g_losses + 2; lj.gp_a = g_hts;
+  lj.pred_b = s.h_f; lj.tgt_b = x_feat; lj.n_b = bs * I; lj.g_b = g_losses + 0; lj.gp_b = g_hf;
+  lj.z = z_teacher; lj.h = s.h_s; lj.rows = bs; lj.D = D; lj.g_c = g_losses + 3; lj.cos_save = s.cos_save; lj.gh = g_hs;
+  if (!det) {  // the same launch clears the topology head's scatter target
+    lj.zero_ptr = g_zl;
+    lj.zero_bytes = (static_cast<int64_t>(N) * D * 4 + 15) / 16 * 16;
+    zeroed = true;
   }
-  if (!direct) STEMGNN_TRY(stemgnn_linear_bwd_data(g_hts, p->w_ts, k, D, 2 * D, g_zz, s1));
-  STEMGNN_TRY(weight_grad(g_hts, s.zz, k, D, 2 * D, p->g_w_ts, p->b_ts ? p->g_b_ts : nullptr, ws_ts, wb_ts, s1));
-  if (fork) STEMGNN_HIP_TRY(hipEventRecord(ln->done[0], s1));
-
-  // ---- lane C: the two seed-row heads
-  if (fork) STEMGNN_TRY(stemgnn_mse_loss_bwd(s.h_f, x_feat, bs * I, 1.0f, g_losses + 0, g_hf, s2));
-  if (!direct) STEMGNN_TRY(stemgnn_linear_bwd_data(g_hf, p->w_feat, bs, I, D, g_head_f, s2));
-  STEMGNN_TRY(weight_grad(g_hf, q, bs, I, D, p->g_w_feat, p->b_feat ? p->g_b_feat : nullptr, ws_f, wb_f, s2));
-  if (fork) STEMGNN_TRY(stemgnn_cosine_loss_bwd(z_teacher, s.h_s, bs, D, 1.0f, g_losses + 3, s.cos_save, g_hs, s2));
-  if (!direct) STEMGNN_TRY(stemgnn_linear_bwd_data(g_hs, p->w_sem, bs, D, D, g_head_s, s2));
-  STEMGNN_TRY(weight_grad(g_hs, q, bs, D, D, p->g_w_sem, p->b_sem ? p->g_b_sem : nullptr, ws_s, wb_s, s2));
-  if (fork) STEMGNN_HIP_TRY(hipEventRecord(ln->done[1], s2));
+  STEMGNN_TRY(head_losses_bwd(lj, s0));
+  // ---- topo-sem head back to the gathered pairs; the two seed-row heads
+  STEMGNN_TRY(dws.add(g_hts, s.zz, kF32, k, D, 2 * D, p->g_w_ts, p->b_ts ? p->g_b_ts : nullptr, ws_ts, wb_ts, s0));
+  STEMGNN_TRY(dws.add(g_hf, q, kF32, bs, I, D, p->g_w_feat, p->b_feat ? p->g_b_feat : nullptr, ws_f, wb_f, s0));
+  STEMGNN_TRY(dws.add(g_hs, q, kF32, bs, D, D, p->g_w_sem, p->b_sem ? p->g_b_sem : nullptr, ws_s, wb_s, s0));
   if (direct) {
     // dx[M, K] = dy[M, N] w[N, K]: the weight as stored is the [contraction][output] layout
     STEMGNN_TRY(small.add(g_hts, p->w_ts, nullptr, k, 2 * D, D, g_zz, true, s0));
     STEMGNN_TRY(small.add(g_hf, p->w_feat, nullptr, bs, D, I, g_head_f, true, s0));
     STEMGNN_TRY(small.add(g_hs, p->w_sem, nullptr, bs, D, D, g_head_s, true, s0));
     STEMGNN_TRY(small.flush(s0));
+  } else {
+    STEMGNN_TRY(stemgnn_linear_bwd_data(g_hts, p->w_ts, k, D, 2 * D, g_zz, s0));
+    STEMGNN_TRY(stemgnn_linear_bwd_data(g_hf, p->w_feat, bs, I, D, g_head_f, s0));
+    STEMGNN_TRY(stemgnn_linear_bwd_data(g_hs, p->w_sem, bs, D, D, g_head_s, s0));
   }
 
-  // ---- lane A: topology head; its backward-data product lays down the dense gradient the other lanes add into
+  // ---- topology head; its backward-data product lays down the dense gradient the other heads add into
   if (det) {
     STEMGNN_TRY(stemgnn_edge_dot_bwd_det(s.coef, g_losses + 1, s.zl, N, D, topo_edges, 2 * k, g_zl, det_ws, det_bytes, s0));
   } else {
@@ -351,15 +259,12 @@ int stemgnn_heads_bwd(const stemgnn_heads_params* p, int64_t N, const float* q, 
     STEMGNN_TRY(stemgnn_edge_dot_bwd_scaled(s.coef, g_losses + 1, s.zl, N, D, topo_edges, 2 * k, g_zl, s0));
   }
   STEMGNN_TRY(stemgnn_linear_bwd_data(g_zl, p->w_topo, N, D, D, g_q, s0));
-  STEMGNN_TRY(weight_grad(g_zl, q, N, D, D, p->g_w_topo, p->b_topo ? p->g_b_topo : nullptr, ws_t, wb_t, s0));
-  if (fork) STEMGNN_HIP_TRY(hipStreamWaitEvent(s0, ln->done[0], 0));
-  if (!det && !fork) {
+  STEMGNN_TRY(dws.add(g_zl, q, kF32, N, D, D, p->g_w_topo, p->b_topo ? p->g_b_topo : nullptr, ws_t, wb_t, s0));
+  if (!det) {
     // the scatter of the sampled pairs' gradients and the two seed-row heads' gradients, one launch
     STEMGNN_TRY(stemgnn_edge_concat_bwd_add(g_zz, N, D, ts_edges, k, g_q, g_head_f, g_head_s, bs * D, s0));
   } else {
-    if (det) STEMGNN_TRY(stemgnn_edge_concat_bwd_det(g_zz, N, D, ts_edges, k, g_q, det_ws, det_bytes, s0));
-    else STEMGNN_TRY(stemgnn_edge_concat_bwd(g_zz, N, D, ts_edges, k, g_q, s0));
-    if (fork) STEMGNN_HIP_TRY(hipStreamWaitEvent(s0, ln->done[1], 0));
+    STEMGNN_TRY(stemgnn_edge_concat_bwd_det(g_zz, N, D, ts_edges, k, g_q, det_ws, det_bytes, s0));
     const int64_t n4 = bs * D / 4;
     int64_t grid = (n4 + kBlock - 1) / kBlock;
     if (grid > 2048) grid = 2048;

@@ -1127,10 +1127,8 @@ inline FwdPlan plan_fwd(int64_t M, int64_t N) {
 // re-read) want S small: S = 512 / (#output tiles), capped at 256 (one tile: 58.8 us at S = 247
 // vs 65 us at S = 458; four tiles: 134-149 us at S = 128 vs 176-183 us at S = 458).
 inline int pick_splits(int64_t M, int64_t tiles) {
-  static const int64_t env_blocks = [] { const char* e = getenv("STEMGNN_DW_BLOCKS"); return e ? atoll(e) : 0; }();
-  static const int64_t env_cap = [] { const char* e = getenv("STEMGNN_DW_CAP"); return e ? atoll(e) : 0; }();
-  int64_t target = (env_blocks > 0 ? env_blocks : 512) / (tiles < 1 ? 1 : tiles);
-  const int64_t cap = env_cap > 0 ? env_cap : 256;
+  int64_t target = 512 / (tiles < 1 ? 1 : tiles);
+  const int64_t cap = 256;
   if (target > cap) target = cap;
   if (target < 1) target = 1;
   int64_t rows = (M + target - 1) / target;
@@ -1143,17 +1141,9 @@ inline int pick_splits(int64_t M, int64_t tiles) {
 }
 
 // the weight-stationary kernel wants most CUs busy: products with fewer 128-row tiles stay on the tile kernel.
-// STEMGNN_WS=0 (or stemgnn_linear_set_ws) keeps every product there (A/B, tests).
-std::atomic<int> g_ws_min_tiles{-1};  // -1: not read yet; 0: off
-inline int64_t ws_min_tiles() {
-  int v = g_ws_min_tiles.load(std::memory_order_relaxed);
-  if (v < 0) {
-    const char* e = getenv("STEMGNN_WS");
-    v = (e && e[0] == '0') ? 0 : 128;
-    g_ws_min_tiles.store(v, std::memory_order_relaxed);
-  }
-  return v;
-}
+// stemgnn_linear_set_ws(0) keeps every product there (the tests compare the two kernels' bits that way).
+std::atomic<int> g_ws_min_tiles{128};  // 0: off
+inline int64_t ws_min_tiles() { return g_ws_min_tiles.load(std::memory_order_relaxed); }
 inline bool ws_enabled() { return ws_min_tiles() > 0; }
 #define kWsMinTiles ws_min_tiles()
 
@@ -1163,8 +1153,6 @@ inline int64_t out_tiles(int64_t N, int64_t K) { return ((N + kBN - 1) / kBN) * 
 }  // namespace stemgnn
 
 namespace stemgnn {
-int plane_split_count(int64_t M, int64_t tiles) { return pick_splits(M, tiles); }
-
 int DwBatch::add(const float* dy, const void* x, int x_kind, int64_t M, int64_t N, int64_t K, float* dw, float* db,
                  void* workspace, size_t workspace_bytes, hipStream_t st) {
   if (x_kind != kF32 && x_kind != kBF16) return STEMGNN_ERR_INVALID_ARG;
@@ -1244,15 +1232,6 @@ int DwBatch::flush(hipStream_t st) {
   k_reduce_many<<<static_cast<unsigned>(blocks), kBlock, 0, st>>>(red);
   STEMGNN_LAUNCH_CHECK();
   count = 0;
-  return STEMGNN_OK;
-}
-int reduce_splits_launch(const float* partial, int splits, int64_t n, float* out, const float* partial2, int64_t n2,
-                         float* out2, hipStream_t st) {
-  const int blocks1 = static_cast<int>((n / 4 + 15) / 16);
-  const int blocks2 = (partial2 && out2) ? static_cast<int>((n2 / 4 + 15) / 16) : 0;
-  k_reduce_splits<<<static_cast<unsigned>(blocks1 + blocks2), kBlock, 0, st>>>(partial, splits, n, out, partial2, n2,
-                                                                              out2, blocks1);
-  STEMGNN_LAUNCH_CHECK();
   return STEMGNN_OK;
 }
 }  // namespace stemgnn

@@ -7,6 +7,10 @@
 // inside one block, so results are bitwise reproducible.
 #include "common.h"
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 namespace stemgnn {
 namespace {
 
@@ -442,16 +446,47 @@ __global__ void k_weighted_sum_bwd(ScalarTable t, const float* __restrict__ g, f
 }  // namespace stemgnn
 
 namespace stemgnn {
-unsigned int* ticket_counter(const void* key) {
-  static unsigned int* base = [] {
-    unsigned int* p = nullptr;
-    if (hipMalloc(&p, 64 * sizeof(unsigned int)) != hipSuccess) return static_cast<unsigned int*>(nullptr);
-    if (hipMemset(p, 0, 64 * sizeof(unsigned int)) != hipSuccess) return static_cast<unsigned int*>(nullptr);
-    return p;
-  }();
-  if (!base) return nullptr;
-  return base + (reinterpret_cast<uintptr_t>(key) >> 2) % 61;
+// Per-(device, stream) scratch of the "last block finishes" reductions (common.h): kTicketSlots zero-initialised counter
+// words and 512 doubles for partial sums.  Kernels of one stream run one after the other and every counter is back at
+// zero when its kernel ends, so all reductions enqueued on a stream share its words; two streams never share any.
+namespace {
+struct StreamScratch {
+  unsigned int* counters = nullptr;
+  double* partials = nullptr;
+};
+std::mutex g_scratch_mu;
+std::map<std::pair<int, hipStream_t>, StreamScratch> g_scratch;
+
+StreamScratch stream_scratch(hipStream_t st) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return StreamScratch{};
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  auto it = g_scratch.find({dev, st});
+  if (it != g_scratch.end()) return it->second;
+  // not cached on failure: the next call tries again
+  constexpr size_t kCounterBytes = 256, kBytes = kCounterBytes + 512 * sizeof(double);
+  static_assert(kTicketSlots * sizeof(unsigned int) <= kCounterBytes, "counter words fit their line pair");
+  unsigned char* p = nullptr;
+  if (hipMalloc(&p, kBytes) != hipSuccess) return StreamScratch{};
+  if (hipMemset(p, 0, kBytes) != hipSuccess) {
+    (void)hipFree(p);
+    return StreamScratch{};
+  }
+  StreamScratch s;
+  s.counters = reinterpret_cast<unsigned int*>(p);
+  s.partials = reinterpret_cast<double*>(p + kCounterBytes);
+  g_scratch[{dev, st}] = s;
+  return s;
 }
+}  // namespace
+
+unsigned int* ticket_counter(hipStream_t st, int slot) {
+  if (slot < 0 || slot >= kTicketSlots) return nullptr;
+  const StreamScratch s = stream_scratch(st);
+  return s.counters ? s.counters + slot : nullptr;
+}
+double* stream_partials(hipStream_t st) { return stream_scratch(st).partials; }
+
 static inline int mse_blocks(int64_t n) {
   int64_t b = (n / 4 + 255) / 256;
   return static_cast<int>(b < 1 ? 1 : (b > 256 ? 256 : b));
@@ -467,11 +502,10 @@ int head_losses_fwd(const HeadLossJobs& j, hipStream_t st) {
   t.part_a = reinterpret_cast<double*>(align_up(reinterpret_cast<uintptr_t>(j.ws_a), 256));
   t.part_b = reinterpret_cast<double*>(align_up(reinterpret_cast<uintptr_t>(j.ws_b), 256));
   t.part_c = reinterpret_cast<double*>(align_up(reinterpret_cast<uintptr_t>(j.ws_c), 256));
-  t.cnt_a = ticket_counter(j.loss_a);
-  t.cnt_b = ticket_counter(j.loss_b);
-  t.cnt_c = ticket_counter(j.loss_c);
+  t.cnt_a = ticket_counter(st, 0);  // three reductions in one launch: three words of the stream's pool
+  t.cnt_b = ticket_counter(st, 1);
+  t.cnt_c = ticket_counter(st, 2);
   if (!t.cnt_a || !t.cnt_b || !t.cnt_c) return STEMGNN_ERR_HIP;
-  if (t.cnt_a == t.cnt_b || t.cnt_a == t.cnt_c || t.cnt_b == t.cnt_c) return STEMGNN_ERR_INVALID_ARG;  // one launch
   t.ba = mse_blocks(j.n_a);
   t.bb = mse_blocks(j.n_b);
   t.bc = static_cast<int>((j.rows + 3) / 4);
@@ -544,7 +578,7 @@ int stemgnn_mse_loss_fwd(const float* pred, const float* target, int64_t n, floa
   int64_t blocks = (n / 4 + 255) / 256;
   if (blocks < 1) blocks = 1;
   if (blocks > 256) blocks = 256;
-  unsigned int* counter = ticket_counter(loss);
+  unsigned int* counter = ticket_counter(st);
   if (!counter) return STEMGNN_ERR_HIP;
   k_mse_partial<<<static_cast<unsigned>(blocks), 256, 0, st>>>(pred, target, n, partial, counter,
                                                                static_cast<double>(scale) / (n > 0 ? n : 1), loss);
@@ -573,7 +607,7 @@ int stemgnn_cosine_loss_fwd(const float* z, const float* h, int64_t rows, int64_
   if (workspace_bytes < stemgnn_loss_workspace_bytes(rows)) return STEMGNN_ERR_WORKSPACE;
   double* row_loss = reinterpret_cast<double*>(align_up(reinterpret_cast<uintptr_t>(workspace), 256));
   if (rows > 0) {
-    unsigned int* counter = ticket_counter(loss);
+    unsigned int* counter = ticket_counter(st);
     if (!counter) return STEMGNN_ERR_HIP;
     k_cos_rows<<<static_cast<unsigned>((rows + 3) / 4), 256, 0, st>>>(z, h, rows, static_cast<int>(dim), save, row_loss,
                                                                       counter, static_cast<double>(scale) / rows, loss);
@@ -611,7 +645,7 @@ int stemgnn::ortho_loss_fwd_plus(const float* embed, const int64_t* ids, int64_t
   const int H = static_cast<int>(heads), M = static_cast<int>(num_ids);
   int nparts = H * M;
   if (ortho_block_ok(M, static_cast<int>(code_dim))) {
-    unsigned int* counter = ticket_counter(loss);
+    unsigned int* counter = ticket_counter(st);
     if (!counter) return STEMGNN_ERR_HIP;
     k_ortho_block<false><<<dim3(H, 4), 256, 0, st>>>(embed, ids, H, static_cast<int>(codebook_size),
                                                      static_cast<int>(code_dim), M, scale, nullptr, partial, nullptr, counter,

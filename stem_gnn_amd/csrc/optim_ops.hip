@@ -211,7 +211,7 @@ int stemgnn_grad_norm_coef(const float* const* grads, const int64_t* sizes, int3
   if (!workspace || workspace_bytes < stemgnn_clip_grad_workspace_bytes(total, count)) return STEMGNN_ERR_WORKSPACE;
   double* partial = reinterpret_cast<double*>(align_up(reinterpret_cast<uintptr_t>(workspace), 256));
   if (blocks > 0) {
-    unsigned int* counter = ticket_counter(out);
+    unsigned int* counter = ticket_counter(st);
     if (!counter) return STEMGNN_ERR_HIP;
     k_sumsq_partial<<<static_cast<unsigned>(blocks), kBlock, 0, st>>>(t, partial, counter, max_norm, out);
   } else {
@@ -243,7 +243,7 @@ int stemgnn_clip_grad_norm(float* const* grads, const int64_t* sizes, int32_t co
   if (!workspace || workspace_bytes < stemgnn_clip_grad_workspace_bytes(total, count)) return STEMGNN_ERR_WORKSPACE;
   double* partial = reinterpret_cast<double*>(align_up(reinterpret_cast<uintptr_t>(workspace), 256));
   if (blocks > 0) {
-    unsigned int* counter = ticket_counter(out);
+    unsigned int* counter = ticket_counter(st);
     if (!counter) return STEMGNN_ERR_HIP;
     k_sumsq_partial<<<static_cast<unsigned>(blocks), kBlock, 0, st>>>(t, partial, counter, max_norm, out);
   } else {

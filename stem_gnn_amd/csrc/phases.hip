@@ -296,7 +296,10 @@ int stemgnn_encoder_bwd(const stemgnn_graph_view* g, const void* x, const float*
     STEMGNN_TRY(stemgnn_linear_bwd_data(g_y, y.w_r, N, y.out_dim, y.in_dim, g_prev, stream));
     if (A > 0) {
       // the rows that carry an aggregate are few (a sampled batch: seeds + first hop): the few-row product, if it fits
-      if (stemgnn_linear_few_rows(g_y, y.w_l, nullptr, A, y.in_dim, y.out_dim, g_agg, 1, stream) != STEMGNN_OK)
+      // (chosen by shape and mode up front: a launch error of either path is an error of the phase, not a fallback)
+      if (stemgnn_linear_set_mode(-1) == 1 && linear_direct_ok(A, y.in_dim, y.out_dim))
+        STEMGNN_TRY(stemgnn_linear_few_rows(g_y, y.w_l, nullptr, A, y.in_dim, y.out_dim, g_agg, 1, stream));
+      else
         STEMGNN_TRY(stemgnn_linear_bwd_data(g_y, y.w_l, A, y.out_dim, y.in_dim, g_agg, stream));
       // the aggregation's backward adds onto lin_r's share (no separate accumulation pass)
       STEMGNN_TRY(stemgnn_sage_agg_bwd_acc_k(g_agg, h_prev, cfg->feature_kind, N, y.in_dim, g->rowptr_t, g->dst_t,

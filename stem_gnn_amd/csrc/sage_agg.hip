@@ -487,10 +487,7 @@ int launch_fwd_one(size_t lds, dim3 units, hipStream_t st, const float* x, int64
   //    augmented graph (eight or twelve rows in flight and two rows per group were all slower);
   //  * 1e5 rows / 1e6 edges and beyond: one row per group (78.0 vs 78.5 us), also with a split plan (95 vs 110 us).
   const bool small = V == 1 && sp.counts == nullptr && N <= (1 << 18);
-  static const int variant = [] { const char* e = getenv("STEMGNN_K1_VARIANT"); return e ? atoi(e) : 0; }();
-  if (small && variant == 2) return launch_fwd_r<G, V, MODE, 1, (V == 1 ? 8 : 0)>(lds, units, st, x, N, D, rowptr, src, aux, ea, etab, T, agg, relu, sp);
-  if (small && variant == 3) return launch_fwd_r<G, V, MODE, (V == 1 ? 2 : 1), (V == 1 ? 8 : 0)>(lds, units, st, x, N, D, rowptr, src, aux, ea, etab, T, agg, relu, sp);
-  if (small && (N > 32768 || variant == 9)) return launch_fwd_r<G, V, MODE, (V == 1 ? 2 : 1)>(lds, units, st, x, N, D, rowptr, src, aux, ea, etab, T, agg, relu, sp);
+  if (small && N > 32768) return launch_fwd_r<G, V, MODE, (V == 1 ? 2 : 1)>(lds, units, st, x, N, D, rowptr, src, aux, ea, etab, T, agg, relu, sp);
   return launch_fwd_r<G, V, MODE, 1>(lds, units, st, x, N, D, rowptr, src, aux, ea, etab, T, agg, relu, sp);
 }
 

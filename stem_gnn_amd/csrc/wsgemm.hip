@@ -59,7 +59,7 @@ template <int KS, bool STATS, bool BT>
 __global__ void __launch_bounds__(kThreads, 2)
 k_linear_ws(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, int64_t M, int N,
             float* __restrict__ y, float* __restrict__ stats_partial /*[64-row tiles][2][N]*/, int64_t row_base,
-            int64_t stats_block0, int64_t store_rows, int dbg) {
+            int64_t stats_block0, int64_t store_rows) {
   constexpr int K = KS * kKC;
   static_assert(KS % 2 == 0, "the last step refills ring slot 0 while slot (KS - 1) & 1 is read");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -107,13 +107,11 @@ k_linear_ws(const float* __restrict__ x, const float* __restrict__ w, const floa
   auto fetch = [&](int64_t t, int s) {
     const int64_t m0 = row_base + (t < tiles ? t : tiles - 1) * kTileM;  // past the last tile: a harmless re-read
     const int64_t ma = m0 + r0 < M ? m0 + r0 : M - 1, mb = m0 + r1 < M ? m0 + r1 : M - 1;
-    if (dbg & 1) { ra[s][0] = ra[s][1] = make_float4(1.f, 2.f, 3.f, 4.f); return; }  // probe: no activation loads
     ra[s][0] = ld4(x + ma * K + s * kKC + c4s);
     ra[s][1] = ld4(x + mb * K + s * kKC + c4s);
   };
   auto stash = [&](int s, int slot) {
     unsigned char* const base = ring + slot * kSlot;
-    if (dbg & 2) return;  // probe: no cut, no LDS writes
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int off = (i ? r1 : r0) * kLdP + 2 * c4s;
@@ -156,10 +154,8 @@ k_linear_ws(const float* __restrict__ x, const float* __restrict__ w, const floa
 #pragma unroll
           for (int tm = 0; tm < 2; ++tm)
             a[tm][p] = *reinterpret_cast<const bf16x8*>(slot + p * kPlane + (tm * 32 + lj) * kLdP + ko);
-        if (!(dbg & 4)) {  // probe: no matrix instructions
 #pragma unroll
-          for (int tm = 0; tm < 2; ++tm) acc[tm] = mfma_x3(a[tm], bw[2 * s + q], acc[tm]);
-        }
+        for (int tm = 0; tm < 2; ++tm) acc[tm] = mfma_x3(a[tm], bw[2 * s + q], acc[tm]);
       }
       // behind the matrix instructions (they run on while the VALU cuts the next chunk): chunk s + 1 of this tile --
       // or, at the last step, chunk 0 of the next -- goes to the other ring slot (last read one barrier ago), and
@@ -217,7 +213,6 @@ k_linear_ws(const float* __restrict__ x, const float* __restrict__ w, const floa
       for (int i = 0; i < 8; ++i) {
         const int rl = (tid >> 5) + 8 * i, c4 = tid & 31;
         const int64_t m = m0 + rl;
-        if (dbg & 8) continue;  // probe: no output stores
         if (CLS == 0 || m < row_end) st4(y + m * N + n0 + 4 * c4, ld4(tile + rl * kLdT + 4 * c4));
       }
     }
@@ -260,9 +255,8 @@ int launch_ws(const float* x, const float* w, const float* bias, int64_t M, int 
   if (gx < 1) gx = 1;
   if (gx > tiles) gx = tiles;
   dim3 grid(static_cast<unsigned>(gx), static_cast<unsigned>(gy));
-  static const int dbg = [] { const char* e = getenv("STEMGNN_WS_DBG"); return e ? atoi(e) : 0; }();  // ablation probe
   k_linear_ws<KS, STATS, BT><<<grid, kThreads, kLdsBytes, st>>>(x, w, bias, M, N, y, stats_partial, row_base,
-                                                               stats_block0, store_rows, dbg);
+                                                               stats_block0, store_rows);
   STEMGNN_LAUNCH_CHECK();
   return STEMGNN_OK;
 }

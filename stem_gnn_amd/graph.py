@@ -110,7 +110,7 @@ class GraphStructure:
         """Adopt a by-target CSR whose slot j IS edge j of `edge_index` (what the HIP sampler emits)."""
         g = cls(None, num_nodes)
         g.max_in_degree, g.max_out_degree = max_in_degree, max_out_degree
-        if active_rows is not None and 0 <= active_rows < num_nodes and not os.environ.get("STEMGNN_NO_ACTIVE_ROWS"):
+        if active_rows is not None and 0 <= active_rows < num_nodes:
             if validate and int(rowptr[active_rows].item()) != int(rowptr[-1].item()):
                 raise RuntimeError("from_csr: rows >= active_rows must have no in-edges")
             g.active_rows = int(active_rows)

@@ -33,9 +33,14 @@ def compute_multitask_loss(pred: Tensor, y: Tensor) -> Tensor:
     return (per_entry * labelled).sum() / labelled.sum()
 
 
-def _segment_pool(z: Tensor, batch: Tensor, how: str) -> Tensor:
+def _segment_pool(z: Tensor, batch: Optional[Tensor], how: str) -> Tensor:
     """global_{mean,add,max}_pool (what ft_model.py:62-69 takes from torch_geometric): rows of ``z`` reduced per
-    graph id in ``batch``; the number of graphs is ``batch.max() + 1`` as in PyG."""
+    graph id in ``batch``; the number of graphs is ``batch.max() + 1`` as in PyG, a graph id without nodes pools to a
+    zero row, and ``batch=None`` (the reference's default) means ONE graph: a single pooled row over all nodes."""
+    if batch is None:
+        if how == "max":
+            return z.amax(dim=0, keepdim=True)
+        return z.sum(dim=0, keepdim=True) if how == "sum" else z.mean(dim=0, keepdim=True)
     graphs = int(batch.max().item()) + 1
     where = batch.view(-1, 1).expand_as(z)
     acc = z.new_zeros(graphs, z.size(1))

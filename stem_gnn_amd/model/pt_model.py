@@ -8,7 +8,6 @@ step through the CPU oracle.  They can also be injected through ``draws=``.
 """
 from __future__ import annotations
 
-import os
 from copy import deepcopy
 from typing import Dict, Optional
 
@@ -55,8 +54,6 @@ class PretrainModel(nn.Module):
         self.topo_sem_recon_decoder = topo_sem_recon_decoder
         self.sem_encoder = deepcopy(self.encoder)  # pt_model.py:22
         self.sem_projector = nn.Linear(self.encoder.hidden_dim, self.encoder.hidden_dim)
-        self.teacher_side_stream = os.environ.get("STEMGNN_TEACHER_STREAM", "0") == "1"  # measured: no gain, K1 slower when overlapped
-        self._side_stream = None
         self._flat_student: Optional[Tensor] = None
         self._flat_teacher: Optional[Tensor] = None
         self.last_draws: Dict[str, Tensor] = {}
@@ -167,28 +164,16 @@ class PretrainModel(nn.Module):
 
     def _teacher_forward(self, g, rows=None):
         """sem_encoder(orig graph).detach() (pt_model.py:93); only its rows [:bs] are ever read (:96-97), which
-        ``rows`` tells the encoder.  Optionally issued on a side HIP stream (measured: no gain)."""
+        ``rows`` tells the encoder.  (Issuing it on a side HIP stream was measured in round 2: no gain, K1 slower
+        when overlapped -- the step runs on one stream.)"""
         orig_x, orig_edge_index, orig_edge_attr = g[0], g[1], g[2]
-        if not (self.teacher_side_stream and orig_x.is_cuda):
-            with torch.no_grad():
-                if rows is not None and hasattr(self.sem_encoder, "_encode_phase"):
-                    return self.sem_encoder.encode(orig_x, orig_edge_index, orig_edge_attr, out_rows=rows), None
-                return self.sem_encoder(orig_x, orig_edge_index, orig_edge_attr), None
-        if self._side_stream is None:
-            self._side_stream = torch.cuda.Stream(device=orig_x.device)
-        cur = torch.cuda.current_stream(orig_x.device)
-        self._side_stream.wait_stream(cur)
-        with torch.cuda.stream(self._side_stream), torch.no_grad():
-            z = self.sem_encoder(orig_x, orig_edge_index, orig_edge_attr)
-        return z, self._side_stream
+        with torch.no_grad():
+            if rows is not None and hasattr(self.sem_encoder, "_encode_phase"):
+                return self.sem_encoder.encode(orig_x, orig_edge_index, orig_edge_attr, out_rows=rows)
+            return self.sem_encoder(orig_x, orig_edge_index, orig_edge_attr)
 
-    def sem_recon_loss(self, g, quantize, eta=1.0, bs=None, teacher=None):
-        if teacher is None:
-            teacher = self._teacher_forward(g, rows=None if bs is None else int(bs))
-        z, side = teacher
-        if side is not None:
-            torch.cuda.current_stream(z.device).wait_stream(side)
-            z.record_stream(torch.cuda.current_stream(z.device))
+    def sem_recon_loss(self, g, quantize, eta=1.0, bs=None):
+        z = self._teacher_forward(g, rows=None if bs is None else int(bs))
         # the projector is row-wise and only rows [:bs] are used (pt_model.py:94-97): project those rows only
         h = self._lin(self.sem_projector, quantize[:bs])
         if eta == 1.0 and h.is_cuda:
@@ -229,7 +214,7 @@ class PretrainModel(nn.Module):
                 self.vq.skip_codes = skip
         return z, quantize, indices, commit_loss
 
-    def _heads_phase(self, query, g, ratio, bs, draws, teacher):
+    def _heads_phase(self, query, g, ratio, bs, draws):
         """The four heads as one library call per direction (ops.HeadsFn), or None when the call is not the standard
         pretraining configuration (pretrain.py:91-130: Linear decoders, InnerProductDecoder with its projection, edge
         attributes as (type table, int64 type ids), a sampling ratio in (0, 1), no injected draws)."""
@@ -252,12 +237,7 @@ class PretrainModel(nn.Module):
         num_edges = graph.edge_index.size(1)
         if num_edges == 0:
             return None
-        if teacher is None:
-            teacher = self._teacher_forward(g, rows=int(bs))
-        z_t, side = teacher
-        if side is not None:
-            torch.cuda.current_stream(z_t.device).wait_stream(side)
-            z_t.record_stream(torch.cuda.current_stream(z_t.device))
+        z_t = self._teacher_forward(g, rows=int(bs))
         k = max(int(num_edges * ratio), 1)
         seed, o1 = ops.next_dropout_key()
         _, o2 = ops.next_dropout_key()
@@ -274,7 +254,6 @@ class PretrainModel(nn.Module):
         x, edge_index, edge_attr = aug_g[0], aug_g[1], aug_g[2]
         orig_x, orig_edge_index, orig_edge_attr = g[0], g[1], g[2]
         self.last_draws = {}
-        teacher = self._teacher_forward(g) if self.teacher_side_stream else None  # optional side-stream overlap
         z, quantize, indices, commit_loss = self.quantize(x, edge_index, edge_attr)
         env_reg_loss = self.encoder.get_env_reg()
         if no_codebook:
@@ -282,7 +261,7 @@ class PretrainModel(nn.Module):
             commit_loss = torch.tensor(0.0, device=z.device)
         else:
             query = quantize
-        fused = self._heads_phase(query, g, topo_recon_ratio, bs, draws, teacher)
+        fused = self._heads_phase(query, g, topo_recon_ratio, bs, draws)
         if fused is not None:
             feat_recon_loss, topo_recon_loss, topo_sem_recon_loss, sem_recon_loss = fused
         elif topo_recon_ratio not in (0.0, 1.0) and query.is_cuda:
@@ -306,13 +285,13 @@ class PretrainModel(nn.Module):
             feat_recon_loss = ops.MseLossFn.apply(self.feat_recon(q_head), orig_x[:bs])  # pt_model.py:42-43
             topo_recon_loss = self.topo_recon_loss(q_all, orig_edge_index, ratio=topo_recon_ratio, draws=draws)
             topo_sem_recon_loss = ops.MseLossFn.apply(self._lin(self.topo_sem_recon_decoder, zz), target)  # :80-81
-            sem_recon_loss = self.sem_recon_loss(g, q_head, eta=1.0, bs=bs, teacher=teacher)
+            sem_recon_loss = self.sem_recon_loss(g, q_head, eta=1.0, bs=bs)
         else:
             feat_recon_loss = self.feat_recon_loss(query, orig_x, bs=bs)
             topo_recon_loss = self.topo_recon_loss(query, orig_edge_index, ratio=topo_recon_ratio, draws=draws)
             topo_sem_recon_loss = self.topo_sem_recon_loss(query, orig_edge_index, orig_edge_attr,
                                                            ratio=topo_recon_ratio, draws=draws)
-            sem_recon_loss = self.sem_recon_loss(g, query, eta=1.0, bs=bs, teacher=teacher)
+            sem_recon_loss = self.sem_recon_loss(g, query, eta=1.0, bs=bs)
         losses = {
             "feat_recon_loss": feat_recon_loss,
             "topo_recon_loss": topo_recon_loss,

@@ -350,8 +350,8 @@ def sage_agg_bwd(g_agg: Tensor, x: Tensor, graph, edge_attr: Optional[Tensor], e
     return g_x
 
 
-SPLIT_CHUNK = int(os.environ.get("STEMGNN_SPLIT_CHUNK", "64"))    # edges per work item of a heavy row
-SPLIT_HEAVY = int(os.environ.get("STEMGNN_SPLIT_HEAVY", "128"))   # rows with more edges than this are split
+SPLIT_CHUNK = 64    # edges per work item of a heavy row
+SPLIT_HEAVY = 128   # rows with more edges than this are split
 
 
 class SplitPlan:
@@ -702,56 +702,6 @@ def transpose(w: Tensor) -> Tensor:
     out = torch.empty(w.size(1), w.size(0), dtype=torch.float32, device=w.device)
     check(lib.stemgnn_transpose(_p(w), w.size(0), w.size(1), _p(out), _stream()), "transpose")
     return out
-
-
-# ---- products on pre-cut operands (csrc/pgemm.hip); thin wrappers used by the tests and the kernel bench --------
-def split_planes(x: Tensor) -> Tensor:
-    """int16 [3, M, K]: the three exact bf16 pieces of fp32 x [M, K]."""
-    _req(x, torch.float32, "x", 2)
-    planes = torch.empty(3, x.size(0), x.size(1), dtype=torch.int16, device=x.device)
-    check(lib.stemgnn_split_planes(_p(x), x.size(0), x.size(1), _p(planes), x.numel(), _stream()), "split_planes")
-    return planes
-
-
-def weight_planes(weights, transpose) -> list:
-    """Planes of several weight matrices in one launch (transpose[i]: planes of the transposed matrix)."""
-    n = len(weights)
-    outs = [torch.empty(3, *(w.shape[::-1] if t else w.shape), dtype=torch.int16, device=w.device)
-            for w, t in zip(weights, transpose)]
-    check(lib.stemgnn_prep_weight_planes((ctypes.c_void_p * n)(*[w.data_ptr() for w in weights]),
-                                         (ctypes.c_int64 * n)(*[w.size(0) for w in weights]),
-                                         (ctypes.c_int64 * n)(*[w.size(1) for w in weights]),
-                                         (ctypes.c_int32 * n)(*[int(bool(t)) for t in transpose]),
-                                         (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs]), n, _stream()),
-          "prep_weight_planes")
-    return outs
-
-
-def pgemm_fwd(a1: Tensor, w1: Tensor, a2: Optional[Tensor] = None, w2: Optional[Tensor] = None,
-              bias: Optional[Tensor] = None, want_stats: bool = False, a1_rows: int = -1):
-    """y = a1 w1^T (+ a2 w2^T) + bias on planes (a*: int16 [3, M, K], w*: int16 [3, N, K])."""
-    M = a1.size(1) if a2 is None else a2.size(1)
-    N, K1 = w1.size(1), w1.size(2)
-    K2 = 0 if a2 is None else a2.size(2)
-    y = torch.empty(M, N, dtype=torch.float32, device=a1.device)
-    blocks = int(lib.stemgnn_pgemm_stats_blocks(M))
-    partial = torch.empty(max(blocks, 1), 2, N, dtype=torch.float32, device=a1.device) if want_stats else None
-    check(lib.stemgnn_pgemm_fwd(_p(a1), a1.size(1) * a1.size(2), K1, a1_rows, _p(w1), _p(a2),
-                                0 if a2 is None else a2.size(1) * a2.size(2), K2, _p(w2), _p(bias), M, N, _p(y),
-                                _p(partial), _stream()), "pgemm_fwd")
-    return y, partial
-
-
-def pgemm_dw(dy: Tensor, x: Tensor, want_bias: bool, rows: int = -1):
-    """dw = dy^T x, db = colsum(dy) on planes (dy int16 [3, M, N], x int16 [3, M, K]); ``rows``: leading rows only."""
-    M = dy.size(1) if rows < 0 else rows
-    N, K = dy.size(2), x.size(2)
-    dw = torch.empty(N, K, dtype=torch.float32, device=dy.device)
-    db = torch.empty(N, dtype=torch.float32, device=dy.device) if want_bias else None
-    ws = _workspace(lib.stemgnn_pgemm_dw_workspace_bytes(M, N, K), dy.device)
-    check(lib.stemgnn_pgemm_dw(_p(dy), dy.size(1) * dy.size(2), _p(x), x.size(1) * x.size(2), M, N, K, _p(dw), _p(db),
-                               _p(ws), ws.numel(), _stream()), "pgemm_dw")
-    return dw, db
 
 
 class LinearFn(torch.autograd.Function):

@@ -38,6 +38,14 @@ def test_pooling_and_multitask_loss():
             rows = z[batch == g]
             if rows.numel():
                 torch.testing.assert_close(out[g], ref(rows))
+            else:  # a graph id without nodes pools to a zero row (what PyG's scatter leaves there)
+                assert float(out[g].abs().max()) == 0.0
+        # batch=None (the reference's default for encode_graph, ft_model.py:62): one graph, one pooled row
+        torch.testing.assert_close(_segment_pool(z, None, how), ref(z).unsqueeze(0))
+    empty = torch.tensor([0, 0, 2, 2, 2])  # id 1 has no nodes
+    for how in ("sum", "mean", "max"):
+        out = _segment_pool(z[:5], empty, how)
+        assert out.shape == (3, 6) and float(out[1].abs().max()) == 0.0
     pred = torch.randn(40, 5)
     y = torch.randint(0, 2, (40, 5)).float()
     a = compute_multitask_loss(pred, y.clone())

@@ -783,43 +783,6 @@ def test_linear_with_zero_tail_promise(dev, m, rows, k1, k2, n):
 
 
 # ---------------------------------------------------------------------------- round-2 kernels
-@pytest.mark.parametrize("m,k1,k2,n,rows", [(1000, 128, 0, 128, -1), (777, 64, 32, 96, -1), (2000, 128, 128, 128, 300),
-                                            (130, 16, 0, 512, -1), (4097, 512, 0, 128, -1)])
-def test_plane_products_are_bit_identical_to_the_staged_ones(dev, m, k1, k2, n, rows):
-    """csrc/pgemm.hip (operands as three bf16 planes, LDS-DMA staging, transposing reads for the weight gradient)
-    runs the same six-product arithmetic as csrc/linear.hip in the same order: forward (+ concat-K, + rows that carry
-    no first operand, + BatchNorm column sums), backward-data through transposed weight planes, weight gradient."""
-    from stem_gnn_amd import ops
-    torch.manual_seed(m + n)
-    a = torch.randn(m, k1, device=dev) * (1 + 3 * torch.rand(m, 1, device=dev))
-    w = torch.randn(n, k1, device=dev) * 0.2
-    a2 = torch.randn(m, k2, device=dev) if k2 else None
-    w2 = torch.randn(n, k2, device=dev) * 0.2 if k2 else None
-    b = torch.randn(n, device=dev)
-    if rows >= 0:
-        a[rows:] = 0
-    y0, p0, _ = ops.linear_fwd(a, w, a2, w2, b, True, rows)
-    wp = ops.weight_planes([w] + ([w2] if k2 else []), [False] * (2 if k2 else 1))
-    ap = ops.split_planes(a if rows < 0 else a[:rows].contiguous()) if k2 else ops.split_planes(a)
-    y1, p1 = ops.pgemm_fwd(ap, wp[0], ops.split_planes(a2) if k2 else None, wp[1] if k2 else None, b, True, rows)
-    assert torch.equal(y1, y0)
-    torch.testing.assert_close(p1.sum(0), p0.sum(0), rtol=1e-5, atol=1e-3)  # same sums, different row tiles
-    # planes are exact: h + m + l == the fp32 value
-    pl = ops.split_planes(a).view(torch.bfloat16).float()
-    assert torch.equal((pl[0] + pl[1]) + pl[2], a)
-    # backward-data: dx = dy w through the planes of w^T
-    dy = torch.randn(m, n, device=dev)
-    d0 = ops.linear_bwd_data(dy, w)
-    d1, _ = ops.pgemm_fwd(ops.split_planes(dy), ops.weight_planes([w], [True])[0])
-    assert torch.equal(d1, d0)
-    # weight gradient (+ bias gradient: fp32 sums in a different order)
-    if n % 8 == 0 and k1 % 8 == 0:
-        w0, b0 = ops.linear_bwd_weight(dy, a, True)
-        w1, b1 = ops.pgemm_dw(ops.split_planes(dy), ops.split_planes(a), True)
-        assert torch.equal(w1, w0)
-        torch.testing.assert_close(b1, b0, rtol=1e-5, atol=1e-4 * max(b0.abs().max().item(), 1.0))
-
-
 @pytest.mark.parametrize("m,k2,n,rows,store", [(1000, 0, 128, -1, -1), (777, 0, 512, -1, 300), (2000, 128, 128, 300, -1),
                                                (1300, 128, 256, 0, -1), (4097, 0, 128, -1, 1000), (129, 0, 96, -1, -1)])
 def test_weight_stationary_product_returns_the_tile_kernels_bits(dev, m, k2, n, rows, store):
@@ -1064,3 +1027,85 @@ def test_vq_project_out_algebra_and_fused_backward(dev, N, H, K, D, Dc):
                                           norm.data_ptr(), ind.data_ptr(), embed.data_ptr(), N, H, Dc, K, got.data_ptr(), st))
     scale = ref.abs().max().item()
     torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-6 * max(scale, 1.0))
+
+
+# ---------------------------------------------------------------------------- round-3: the "last block finishes" protocol
+def _fixed_order_finish(partials: np.ndarray, mul: float) -> np.float32:
+    """finish_sum_block (csrc/loss_ops.hip): thread t adds partial[t], partial[t + 256], ... in fp64, then a pairwise
+    tree over the 256 threads; the product with `mul` is rounded to fp32 once."""
+    n = partials.size
+    pad = np.zeros((n + 255) // 256 * 256, dtype=np.float64)
+    pad[:n] = partials
+    lanes = np.zeros(256, dtype=np.float64)
+    for row in pad.reshape(-1, 256):  # sequential per thread
+        lanes = lanes + row
+    o = 128
+    while o > 0:
+        lanes[:o] = lanes[:o] + lanes[o:2 * o]
+        o //= 2
+    return np.float32(lanes[0] * mul)
+
+
+def test_ticketed_reduction_many_blocks_many_rounds(dev):
+    """The fence-free last-block hand-off (csrc/common.h: st_agent / wait_stores / ticket_last / ld_agent) is an observed
+    property of gfx950, not a guarantee of the HIP memory model.  Pin it: a reduction whose 4 096
+    blocks cover every XCD (16 rounds of resident blocks, so late blocks start long after early ones finished), 150
+    rounds in one process with fresh inputs each round (a partial read stale from the round before changes the sum),
+    each result compared BIT FOR BIT with the fixed-order sum of the partials the kernel itself wrote -- the value
+    the two-launch k_finish_sum path returns."""
+    from stem_gnn_amd._lib import lib, check
+    rows, D = 16384, 256
+    st = torch.cuda.current_stream().cuda_stream
+    ws_bytes = int(lib.stemgnn_loss_workspace_bytes(rows))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    base = (ws.data_ptr() + 255) // 256 * 256 - ws.data_ptr()
+    row_loss = ws[base:base + rows * 8].view(torch.float64)
+    save = torch.empty(rows, 3, device=dev)
+    loss = torch.empty(1, device=dev)
+    g = torch.Generator(device=dev).manual_seed(7)
+    bad = 0
+    for it in range(150):
+        z = torch.randn(rows, D, device=dev, generator=g)
+        h = torch.randn(rows, D, device=dev, generator=g)
+        check(lib.stemgnn_cosine_loss_fwd(z.data_ptr(), h.data_ptr(), rows, D, 1.0, loss.data_ptr(), save.data_ptr(),
+                                          ws.data_ptr(), ws_bytes, st), "cosine_loss_fwd")
+        got = loss.cpu().numpy()[0]
+        exp = _fixed_order_finish(row_loss.cpu().numpy(), 1.0 / rows)
+        bad += int(got.tobytes() != exp.tobytes())
+        # the partials themselves are the row losses 1 - cos (fp32 arithmetic, widened)
+        torch.testing.assert_close(row_loss.float(), 1.0 - save[:, 0], rtol=0, atol=0)
+    assert bad == 0, f"{bad} of 150 ticketed sums differ from the fixed-order sum of their own partials"
+
+
+def test_two_streams_reduce_side_by_side(dev):
+    """Round 2 hashed the OUTPUT POINTER of a reduction into a pool of 61 counter words, so two reductions in flight on
+    two streams whose outputs collided mod 61 corrupted each other's "last block" decision.
+    Counters now belong to the (device, stream) pair.  Two streams run mean-squared-error reductions at the same time,
+    200 rounds, into outputs that are 61 floats apart (the old colliding keys); both must return their own sums."""
+    from stem_gnn_amd._lib import lib, check
+    n = 1 << 20
+    out = torch.zeros(62, device=dev)
+    s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    ws_bytes = int(lib.stemgnn_loss_workspace_bytes(256))
+    ws1 = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    ws2 = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    a = torch.randn(4, n, device=dev)
+    b = torch.randn(4, n, device=dev)
+    torch.cuda.synchronize()
+    exp1 = [float(((a[i] - b[i]).double() ** 2).mean()) for i in range(4)]
+    exp2 = [float(((a[i] - 2 * b[i]).double() ** 2).mean()) for i in range(4)]
+    b2 = 2 * b
+    torch.cuda.synchronize()
+    for it in range(200):
+        i = it % 4
+        check(lib.stemgnn_mse_loss_fwd(a[i].data_ptr(), b[i].data_ptr(), n, 1.0, out[0:].data_ptr(), ws1.data_ptr(),
+                                       ws_bytes, s1.cuda_stream), "mse s1")
+        check(lib.stemgnn_mse_loss_fwd(a[i].data_ptr(), b2[i].data_ptr(), n, 1.0, out[61:].data_ptr(), ws2.data_ptr(),
+                                       ws_bytes, s2.cuda_stream), "mse s2")
+        s1.synchronize()
+        s2.synchronize()
+        r = out.cpu()
+        assert abs(float(r[0]) - exp1[i]) <= 1e-5 * exp1[i], (it, float(r[0]), exp1[i])
+        assert abs(float(r[61]) - exp2[i]) <= 1e-5 * exp2[i], (it, float(r[61]), exp2[i])
+        out.zero_()
+        torch.cuda.synchronize()

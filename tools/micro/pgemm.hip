@@ -1,3 +1,6 @@
+// NOT part of libstemgnn_hip.so any more (round 3): the plane-operand products were built, bit-identical to the staged
+// kernels and measured slower (DESIGN.md, K3 "planes"; profiles/round2_pgemm_bench.log).  Kept as the record of that
+// experiment; it compiled against csrc/common.h of commit b742edb and exported the stemgnn_pgemm_* entry points.
 // Dense products on operands that are ALREADY cut into their three exact bf16 pieces ("planes").
 //
 // csrc/linear.hip cuts every fp32 operand into h + m + l while it stages it: per wave and K chunk ~440 VALU

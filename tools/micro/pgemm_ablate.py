@@ -1,3 +1,4 @@
+# Round-2 record: ran against the library of commit b742edb, which still exported stemgnn_pgemm_* (tools/micro/pgemm.hip).
 """Ablations of k_pgemm_fwd (STEMGNN_PGEMM_DBG bits: 1 no MFMA, 2 no weight DMA, 4 no stores, 8 no activation DMA)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,3 +1,4 @@
+# Round-2 record: ran against the library of commit b742edb, which still exported stemgnn_pgemm_* (tools/micro/pgemm.hip).
 """Plane-operand products (csrc/pgemm.hip) beside the register-staged kernels (csrc/linear.hip): correctness
 (bit-identical results expected) and time per launch at C4-batch shapes.  Run on the GPU box."""
 import os
