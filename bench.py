@@ -100,9 +100,22 @@ def cpu_baseline(params, batch_cpu, bs, budget_s):
         if time.perf_counter() - t0 >= budget_s or steps >= 50:
             break
     dt = time.perf_counter() - t0
-    return {"value": e * steps / dt, "unit": "edges/s", "cores": cores, "kind": "port",
+    return {"value": e * steps / dt, "unit": "edges/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
             "sample": f"{steps} full pretrain steps of the CPU oracle on one batch ({n} nodes, {e} edges, D={D}), "
-                      f"{dt:.1f} s, torch {torch.__version__} fp32, {cores} threads"}
+                      f"{dt:.1f} s, torch {torch.__version__} fp32, {cores} threads on {cpu_model()}"}
+
+
+def cpu_model() -> str:
+    """The host CPU as /proc/cpuinfo names it (SURVEY.md section 8d asks for the core count AND the model)."""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine() or "unknown"
 
 
 def step_algorithmic_bytes(N, A, E, E_aug, k, bs, D, HD, in_dim, T):

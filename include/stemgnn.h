@@ -389,6 +389,10 @@ int stemgnn_transpose(const float* in, int64_t rows, int64_t cols, float* out, v
  * Dc must be a multiple of 4 and <= 1024, K <= 65536.
  * ------------------------------------------------------------------------------------ */
 size_t stemgnn_vq_workspace_bytes(int64_t num_rows, int64_t heads, int64_t code_dim, int64_t codebook_size);
+/* Which kernel the calling thread's most recent stemgnn_vq_assign_fwd / _lean call launched: 0 none yet, 1 the tile
+ * form (k_vq_assign), 2 the weight-stationary form (k_vq_assign_ws: K = Dc = 128, >= 16 384 rows).  The golden tests
+ * use it to make sure a production-shape fixture was served by the production kernel. */
+int stemgnn_vq_assign_last_path(void);
 
 int stemgnn_vq_assign_fwd(const float* xp, int64_t num_rows, int64_t heads, int64_t code_dim,
                           const float* embed, int64_t codebook_size, int training,

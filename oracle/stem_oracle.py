@@ -271,10 +271,16 @@ class OracleVectorQuantize(nn.Module):
     def codebook(self) -> Tensor:
         return self._codebook.embed
 
-    def forward(self, z: Tensor, ortho_ids: Optional[Tensor] = None):
+    def forward(self, z: Tensor, ortho_ids: Optional[Tensor] = None, tie_ind: Optional[Tensor] = None,
+                tie_tol: float = 1e-5):
         """z [N, dim] -> (quantize [N, dim], embed_ind [N, H] int64, loss [1], orig_quantize [N, H*Dc]).
 
-        ``ortho_ids`` replaces ``torch.randperm(K)[:max_codes]`` (vq.py:1024)."""
+        ``ortho_ids`` replaces ``torch.randperm(K)[:max_codes]`` (vq.py:1024).
+        ``tie_ind`` [N, H] (test aid for long replays): the assignment another implementation of this forward made.
+        Where it differs from this arg-max but its similarity is within ``tie_tol`` of the maximum -- a near-tie, which
+        fp32 summation order alone decides -- it is adopted, like any other replayed draw; a proposal further from the
+        maximum is NOT adopted and counted in ``last_tie_rejected`` (the caller asserts zero).  ``last_tie_adopted``
+        counts the adopted ones."""
         n = z.size(0)
         h, dc, k = self.heads, self.codebook_dim, self.codebook_size
         cb = self._codebook
@@ -286,6 +292,16 @@ class OracleVectorQuantize(nn.Module):
         flat = x.float()
         sim = torch.einsum('hnd,hcd->hnc', flat, embed.detach() if not isinstance(embed, nn.Parameter) else embed)
         ind = sim.argmax(dim=-1)  # gumbel_sample with stochastic=False (vq.py:78-80): first max wins
+        self.last_tie_adopted = self.last_tie_rejected = 0
+        if tie_ind is not None:
+            prop = tie_ind.reshape(n, h).permute(1, 0).to(ind.dtype)
+            with torch.no_grad():
+                differs = prop != ind
+                short = sim.max(dim=-1).values - sim.gather(-1, prop.clamp(0, k - 1).unsqueeze(-1)).squeeze(-1)
+                adopt = differs & (short <= tie_tol) & (prop >= 0) & (prop < k)
+            self.last_tie_adopted = int(adopt.sum())
+            self.last_tie_rejected = int((differs & ~adopt).sum())
+            ind = torch.where(adopt, prop, ind)
         if self.training:
             onehot = F.one_hot(ind, k).to(flat.dtype)
             quant = torch.einsum('hnc,hcd->hnd', onehot, embed)  # vq.py:655-657
@@ -387,7 +403,8 @@ class OraclePretrainModel(nn.Module):
         x, ei, ea = aug_g
         ox, oei, oea = g
         z = self.encoder(x, ei, ea, dropout_masks=draws.get('student_dropout'))  # pt_model.py:112
-        quantize, indices, commit_loss, _ = self.vq(z, ortho_ids=draws.get('ortho_ids'))  # pt_model.py:113
+        quantize, indices, commit_loss, _ = self.vq(z, ortho_ids=draws.get('ortho_ids'),
+                                                    tie_ind=draws.get('vq_indices'))  # pt_model.py:113
         env_reg = self.encoder.get_env_reg()
         q = quantize
         # feat_recon_loss, pt_model.py:42-43
@@ -437,6 +454,8 @@ def pretrain_step(model: OraclePretrainModel, optimizer, scheduler, params, x, e
     aug_x = mask_feature_col(x, draws['feat_keep'])  # pretrain.py:41
     aug_ei, aug_ea, _ = dropout_adj_undirected(edge_index, edge_attr, draws['edge_keep'])  # pretrain.py:42-44
     z, quantize, indices, losses = model((aug_x, aug_ei, aug_ea), (x, edge_index, edge_attr), bs, draws)
+    # a replayed assignment ('vq_indices') may differ from this arg-max at near-ties only: anything else is a parity error
+    assert model.vq.last_tie_rejected == 0, f"{model.vq.last_tie_rejected} code assignments differ beyond near-ties"
     loss = total_loss(losses, params)
     optimizer.zero_grad()
     loss.backward()

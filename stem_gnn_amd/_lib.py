@@ -165,6 +165,7 @@ _SIGNATURES = {
                                         P, P, P, P, c_size_t, P]),
     "stemgnn_dropout_keep_mask": (c_int, [I64, c_float, c_uint64, c_uint64, P, P]),
     "stemgnn_vq_workspace_bytes": (c_size_t, [I64, I64, I64, I64]),
+    "stemgnn_vq_assign_last_path": (c_int, []),
     "stemgnn_vq_assign_fwd": (c_int, [P, I64, I64, I64, P, I64, c_int, P, P, P, P, P, c_float, P, c_size_t, P]),
     "stemgnn_vq_assign_bwd": (c_int, [P, P, c_float, P, P, P, P, I64, I64, I64, I64, P, P]),
     "stemgnn_vq_ema_workspace_bytes": (c_size_t, [I64, I64, I64, I64]),

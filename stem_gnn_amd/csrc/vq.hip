@@ -723,6 +723,9 @@ using namespace stemgnn;
 
 extern "C" {
 
+static thread_local int g_last_assign_path = 0;  // 0 none yet, 1 k_vq_assign (tile form), 2 k_vq_assign_ws
+int stemgnn_vq_assign_last_path(void) { return g_last_assign_path; }
+
 size_t stemgnn_vq_workspace_bytes(int64_t N, int64_t H, int64_t Dc, int64_t K) {
   if (!vq_dims_ok(N, H, Dc, K)) return 0;
   return static_cast<size_t>(row_blocks(N < 1 ? 1 : N) * H) * sizeof(float) + 512;
@@ -804,7 +807,11 @@ static int vq_assign_impl(const float* xp, int64_t N, int64_t H, int64_t Dc, con
   // lean form at K = Dc = 128: the weight-stationary kernel (csrc/wsgemm.hip), same results
   if (x3 && !quant && esq && stemgnn_linear_set_ws(-1) > 0 && vq_assign_ws_ok(N, H, Dc, K) &&
       rb * H >= 1024)  // its partials (at most two blocks per CU) fit the workspace
+  {
+    g_last_assign_path = 2;
     return vq_assign_ws_launch(xp, N, H, embed, esq, norm, ind, partial, counter, sq_scale, sqerr, st);
+  }
+  g_last_assign_path = 1;
 #define STEMGNN_VQ_LAUNCH(CG)                                                                                         \
   do {                                                                                                                \
     if (x3) k_vq_assign<CG, true><<<grid, kBlock, 0, st>>>(xp, N, Hi, Dci, embed, Ki, training, xn, norm, ind, quant, \

@@ -186,6 +186,7 @@ def pretrain_step(model: PretrainModel, optimizer, scheduler, params: Dict, x, e
                                         for (s, o) in model.sem_encoder.last_dropout_keys]
         if model.vq.last_ortho_ids is not None:
             out_draws["ortho_ids"] = model.vq.last_ortho_ids
+        out_draws["vq_indices"] = indices.detach()  # how this run resolved near-ties of the arg-max (oracle: tie_ind)
     return loss.detach(), {k: v.detach() for k, v in losses.items()}, out_draws
 
 

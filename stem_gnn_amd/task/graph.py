@@ -38,20 +38,15 @@ def ft_graph(model, dataset, loader, optimizer, split, labels, params, scheduler
     return {"act_loss": act, "jac_loss": jac, "env_loss": env, "loss": tot}
 
 
-def _predict_graphs(model, loader, device):
-    preds, labels = [], []
-    for batch in loader:
-        z = _encode(model, batch, device)
-        preds.append(model.get_lin_logits(z).mean(1).detach())
-        labels.append(batch.y.to(device).to(torch.float64))
-    return torch.cat(preds, dim=0), torch.cat(labels, dim=0)
-
-
-def _evaluate_loader(model, loader, device, params):
+def _split_metric(model, loader, device, params):
+    """The task metric over one split's loader: mean-pooled graph embeddings -> per-head class logits averaged over
+    the heads (reference task/graph.py:57-77), scored against the fp64 labels; an absent or empty split is NaN."""
     if loader is None or len(loader) == 0:
         return float("nan")
-    pred, y = _predict_graphs(model, loader, device)
-    return evaluate(pred, y, None, params)
+    scored = [(model.get_lin_logits(_encode(model, batch, device)).mean(1).detach(),
+               batch.y.to(device).to(torch.float64)) for batch in loader]
+    logits, targets = (torch.cat(col, dim=0) for col in zip(*scored))
+    return evaluate(logits, targets, None, params)
 
 
 def eval_graph(model, dataset, loader, split, labels, params, **kwargs):
@@ -60,6 +55,7 @@ def eval_graph(model, dataset, loader, split, labels, params, **kwargs):
     device = get_device_from_model(model)
     train_loader, val_loader, test_loader = loader
     with torch.no_grad():
-        return {"train": _evaluate_loader(model, train_loader, device, params),
-                "val": _evaluate_loader(model, val_loader, device, params),
-                "test": _evaluate_loader(model, test_loader, device, params), "metric": task2metric[params["task"]]}
+        scores = {name: _split_metric(model, ld, device, params)
+                  for name, ld in zip(("train", "val", "test"), (train_loader, val_loader, test_loader))}
+    scores["metric"] = task2metric[params["task"]]
+    return scores
