@@ -26,6 +26,7 @@ namespace {
 
 constexpr int kBlock = 256;          // 4 waves; wave w owns data rows [32w, 32w+32) of the tile
 constexpr int kRowsPerBlock = 128;
+constexpr int kWsPartials = 1024;  // workspace floats reserved for k_vq_assign_ws: two blocks per CU, up to 512 CUs
 constexpr int kKC = 32;              // k-chunk staged in LDS per step
 constexpr int kPad = 4;              // row padding (floats): 36-dword stride -> conflict-free ds_read_b128
 constexpr int kLd = kKC + kPad;
@@ -728,7 +729,8 @@ int stemgnn_vq_assign_last_path(void) { return g_last_assign_path; }
 
 size_t stemgnn_vq_workspace_bytes(int64_t N, int64_t H, int64_t Dc, int64_t K) {
   if (!vq_dims_ok(N, H, Dc, K)) return 0;
-  return static_cast<size_t>(row_blocks(N < 1 ? 1 : N) * H) * sizeof(float) + 512;
+  // one partial per (row block, head) of the tile form; the weight-stationary form writes at most two per CU
+  return static_cast<size_t>(row_blocks(N < 1 ? 1 : N) * H + kWsPartials) * sizeof(float) + 512;
 }
 
 static int vq_assign_impl(const float* xp, int64_t N, int64_t H, int64_t Dc, const float* embed, int64_t K,
@@ -805,8 +807,7 @@ static int vq_assign_impl(const float* xp, int64_t N, int64_t H, int64_t Dc, con
   if (!counter) return STEMGNN_ERR_HIP;
   const double sq_scale = static_cast<double>(sqerr_scale);
   // lean form at K = Dc = 128: the weight-stationary kernel (csrc/wsgemm.hip), same results
-  if (x3 && !quant && esq && stemgnn_linear_set_ws(-1) > 0 && vq_assign_ws_ok(N, H, Dc, K) &&
-      rb * H >= 1024)  // its partials (at most two blocks per CU) fit the workspace
+  if (x3 && !quant && esq && stemgnn_linear_set_ws(-1) > 0 && vq_assign_ws_ok(N, H, Dc, K))
   {
     g_last_assign_path = 2;
     return vq_assign_ws_launch(xp, N, H, embed, esq, norm, ind, partial, counter, sq_scale, sqerr, st);

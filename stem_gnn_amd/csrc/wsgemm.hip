@@ -611,6 +611,7 @@ int vq_assign_ws_launch(const float* xp, int64_t N, int64_t H, const float* embe
   int64_t gx = 2 * cus / H;
   if (gx < 1) gx = 1;
   if (gx > tiles) gx = tiles;
+  if (gx * H > 1024) gx = 1024 / H;  // the partials the caller's workspace reserves (csrc/vq.hip: kWsPartials)
   dim3 grid(static_cast<unsigned>(gx), static_cast<unsigned>(H));
   k_vq_assign_ws<<<grid, kThreads, kVqLdsBytes, st>>>(xp, N, static_cast<int>(H), embed, esq, norm, ind, sq_partial,
                                                       counter, sq_scale, sq_out);

@@ -890,7 +890,11 @@ def test_vq_assign_weight_stationary_matches_the_tile_form(dev, N, H):
         n1, i1, s1 = run()
     finally:
         lib.stemgnn_linear_set_ws(prev)
-    assert torch.equal(i1, i0) and torch.equal(n1, n0)
+    assert torch.equal(i1, i0)
+    # the row norms: the same chunk order, but the two kernels' compilers contract the sums of squares differently --
+    # a few units in the last place (these sizes ran the tile form twice until round 3 lifted the row gate)
+    rel = ((n1 - n0).abs() / n0.clamp_min(1e-30)).max().item()
+    assert rel <= 4e-7, rel
     torch.testing.assert_close(s1, s0, rtol=1e-5, atol=1e-6)
     xh = xp.view(N, H, Dc)
     torch.testing.assert_close(n1, xh.norm(dim=-1), rtol=1e-5, atol=1e-6)
