@@ -25,6 +25,7 @@
 // 32 staged through LDS with register prefetch of the next chunk.
 #include "common.h"
 
+#include <algorithm>
 #include <atomic>
 #include <cstdlib>
 
@@ -660,6 +661,11 @@ k_code_segment_sums_cols(const int64_t* __restrict__ ind, int H, int K, const fl
       if (n < NC) pw[static_cast<int64_t>(n) * D + d0 + lj] = acc[t][r];
     }
 }
+
+// (Round 3 measured a form of these sums without matrix instructions -- per chunk the (row, head) entries counting-sorted
+// by code bin in LDS, each bin owned by one eight-lane group, sums in registers, bit-reproducible: correct, but 53 us in
+// the step against this kernel's 49: staging 13 + sort 16 + walk 12 us of LDS round trips per 128-row chunk.  Dropped;
+// the kernel is kept as a record in tools/micro/segsum_bins.hip.)
 
 // One launch serves several products (a phase's weight gradients): a block finds its job in a table passed by value.
 constexpr int kDwJobs = 8;

@@ -484,7 +484,8 @@ int launch_fwd_one(size_t lds, dim3 units, hipStream_t st, const float* x, int64
   //  * launches over ALL rows of a sampled batch (1e5 rows, 89 % of them empty): two rows per group, 22.3 -> 20.1 us;
   //  * launches over the ~1.1e4 rows that can receive edges (what the encoder phase issues; every row has ~10 edges):
   //    one row per group, four source rows in flight -- 14.1 -> 12.9 us on the batch graph, 6.8 -> 5.2 us on the
-  //    augmented graph (eight or twelve rows in flight and two rows per group were all slower);
+  //    augmented graph (eight or twelve rows in flight and two rows per group were all slower; round 3 re-measured
+  //    4 / 5 / 6 / 10 rows in flight at 12.90 / 12.81 / 13.02 / 13.96 us: the depth is not what bounds the launch);
   //  * 1e5 rows / 1e6 edges and beyond: one row per group (78.0 vs 78.5 us), also with a split plan (95 vs 110 us).
   const bool small = V == 1 && sp.counts == nullptr && N <= (1 << 18);
   if (small && N > 32768) return launch_fwd_r<G, V, MODE, (V == 1 ? 2 : 1)>(lds, units, st, x, N, D, rowptr, src, aux, ea, etab, T, agg, relu, sp);

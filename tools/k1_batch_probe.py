@@ -1,5 +1,5 @@
 """K1 forward on C4 sampler batches over the rows that can receive edges (what the encoder phase launches), exact
-per-launch kernel time via the library's HIP-event stamps.  STEMGNN_K1_VARIANT selects the launch shape."""
+per-launch kernel time via the library's HIP-event stamps.  STEMGNN_K1_PROBE selects the launch shape."""
 import ctypes, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from stem_gnn_amd import ops
@@ -32,5 +32,5 @@ for name, graphs in (("batch graph", [b.graph for b in batches]), ("augmented gr
             torch.cuda.synchronize()
             ms, n, by = ops.k1_timer.collect()
             ops.k1_timer.reset(False)
-        print(f"variant={os.environ.get('STEMGNN_K1_VARIANT', '0')} {name} {'cold' if cold else 'warm'}: {n} launches, avg {ms / n * 1e3:.2f} us, "
+        print(f"variant={os.environ.get('STEMGNN_K1_PROBE', '0')} {name} {'cold' if cold else 'warm'}: {n} launches, avg {ms / n * 1e3:.2f} us, "
               f"{by / n / 1e6:.1f} MB, {by / ms / 1e6:.0f} GB/s ({by / ms / 1e6 / 8000:.3f} of 8 TB/s)", flush=True)
