@@ -56,6 +56,10 @@ def parse():
     ap.add_argument("--e2e-steps", type=int, default=40, help="extra steps timed with the loader inside the loop (0: skip)")
     ap.add_argument("--feature-dtype", default="auto", choices=["auto", "f32", "bf16"],
                     help="storage of node features / layer outputs (auto: bf16 for c5 -- BASELINE config 5 -- else f32)")
+    ap.add_argument("--gemm", default="auto", choices=["auto", "f32", "bf16"],
+                    help="dense products: f32 = fp32 results from exact bf16 pieces (the headline mode); bf16 = one bf16 "
+                         "matrix pass on rounded operands, fp32 accumulation, fp32 VQ core (BASELINE config 5); auto = "
+                         "bf16 for the c5 workload, f32 otherwise")
     ap.add_argument("--no-extra", action="store_true", help="skip the K1 legs at C2 / C3 size and the dense-product leg")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
     return ap.parse_args()
@@ -194,9 +198,29 @@ def k1_at_full_graph_sizes(dev):
         ms, launches, by = ops.k1_timer.collect()
         ops.k1_timer.reset(False)
         gbs = by / (ms * 1e-3) / 1e9
-        out[name] = {"kernel": "k_sage_agg_fwd", "avg_launch_us": ms * 1e3 / launches,
+        out[name] = {"kernel": "k_sage_agg_fwd", "edge_attr": "type-indexed (4E + T*D*4 bytes)",
+                     "avg_launch_us": ms * 1e3 / launches,
                      "algorithmic_bytes_per_launch": by / launches, "achieved": gbs, "peak": 8000.0, "unit": "GB/s",
                      "frac": gbs / 8000.0}
+        if n == 100_000:
+            # the drop-in signature (reference pretrain.py:38 hands the operator a dense [E, D] edge_attr =
+            # edge_text_feat[xe]; encoder.py:72-73): the same kernel reading an [E, D] row per edge through the
+            # original edge id -- SURVEY.md section 8(d)'s 1 080 B/edge form
+            dense = g.edge_text_feat[g.xe].contiguous()
+            for _ in range(3):
+                ops.sage_agg_fwd(x, gs, dense, None)
+            ops.k1_timer.reset(True)
+            for _ in range(10):
+                ops.sage_agg_fwd(x, gs, dense, None)
+            torch.cuda.synchronize()
+            ms, launches, by = ops.k1_timer.collect()
+            ops.k1_timer.reset(False)
+            gbs = by / (ms * 1e-3) / 1e9
+            out[name + ", dense edge_attr [E, D] (drop-in signature)"] = {
+                "kernel": "k_sage_agg_fwd", "edge_attr": "dense (E*D*4 + 4E bytes)", "avg_launch_us": ms * 1e3 / launches,
+                "algorithmic_bytes_per_launch": by / launches, "achieved": gbs, "peak": 8000.0, "unit": "GB/s",
+                "frac": gbs / 8000.0}
+            del dense
         del g, x, gs
     torch.cuda.empty_cache()
     return out
@@ -242,6 +266,9 @@ def main():
     else:
         g = make_graph(wl["nodes"], wl["edges"], D, wl["types"], kind="U", device=dev, graph_seed=1234, feat_seed=0,
                        feat_rows=wl.get("feat_rows", 0))
+    gemm_bf16 = args.gemm == "bf16" or (args.gemm == "auto" and args.workload == "c5")
+    if gemm_bf16:
+        ops.linear_set_mode(2)  # every Linear of the path as one bf16 matrix pass; the VQ similarity core stays exact
     feat_bf16 = args.feature_dtype == "bf16" or (args.feature_dtype == "auto" and args.workload == "c5")
     if feat_bf16:
         g.node_text_feat = g.node_text_feat.bfloat16()  # the feature table lives in HBM as bf16; arithmetic stays fp32
@@ -394,7 +421,9 @@ def main():
             "metric": "pretrain edges/sec (fwd+bwd) on 1M-node/20M-edge synthetic graph, 1/2/4/8 GPUs",
             "value": edges / dt, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if not feat_bf16 else "f32 (arithmetic, VQ core, gradients) on bf16-stored features", "data": "synthetic",
+            "dtype": ("bf16 GEMMs (fp32 accumulation), fp32 VQ core" + (", bf16-stored features" if feat_bf16 else "")) if gemm_bf16
+                     else ("f32" if not feat_bf16 else "f32 (arithmetic, VQ core, gradients) on bf16-stored features"),
+            "data": "synthetic",
             "config": {"workload": wl["desc"], "nodes": wl["nodes"], "edges": wl["edges"], "feat_dim": D,
                        "layers": params["num_layers"], "vq_heads": params["codebook_head"],
                        "codebook_size": params["codebook_size"], "code_dim": params["code_dim"],
@@ -442,11 +471,12 @@ def main():
             torch.cuda.synchronize()
             us = ev0.elapsed_time(ev1) / reps * 1e3
             flop = 2.0 * (Mb + A_b) * D * D
-            x3 = ops.linear_set_mode(-1) == 1
+            x3 = ops.linear_set_mode(-1) >= 1
+            pieces = 6.0 if ops.linear_set_mode(-1) == 1 else 1.0
             out["roofline_dense"] = {
                 "bound": "hbm", "kernel": "k_linear_fwd_x3<128, true> (lin_l(agg[:A]) + lin_r(x) + BatchNorm statistics, one launch)",
                 "rows": Mb, "aggregate_rows": A_b, "us_per_launch": us, "fp32_equivalent_tflops": flop / us / 1e6,
-                "mfma_frac_of_bf16_peak": (6.0 if x3 else 1.0) * flop / us / 1e6 / (2500.0 if x3 else 157.0),
+                "mfma_frac_of_bf16_peak": pieces * flop / us / 1e6 / (2500.0 if x3 else 157.0),
                 "algorithmic_bytes": (2.0 * Mb + A_b) * D * 4, "achieved": (2.0 * Mb + A_b) * D * 4 / us / 1e3,
                 "peak": peak, "unit": "GB/s", "frac": (2.0 * Mb + A_b) * D * 4 / us / 1e3 / peak}
             out["configs_extra"] = k1_at_full_graph_sizes(dev)

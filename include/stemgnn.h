@@ -281,8 +281,11 @@ int stemgnn_dropout_keep_mask(int64_t n, float p, uint64_t seed, uint64_t offset
 /* The three dense products below run on the bf16 matrix cores by default: every fp32 operand is cut exactly
  * into three bf16 pieces and the six significant piece products are accumulated in fp32 -- no further from the
  * fp64 result than the fp32-MFMA kernels (csrc/linear.hip).  mode 0 selects the fp32-MFMA kernels, 1 the
- * default; any other value only queries.  Returns the previous mode.  The tile plan
- * (stemgnn_linear_stats_blocks) depends on the mode: set it before sizing buffers. */
+ * default, 2 the bf16 GEMM mode of BASELINE config 5 (what autocast would do to the reference's nn.Linear calls:
+ * both operands of every product rounded to bf16, one matrix pass, fp32 accumulation, fp32 bias / output / bias
+ * gradient; the quantiser's similarity / arg-max core keeps the exact form, model/vq.py:623,634); any other value only
+ * queries.  Returns the previous mode.  The tile plan (stemgnn_linear_stats_blocks) depends on the mode: set it
+ * before sizing buffers.  STEMGNN_GEMM=f32 / bf16 in the environment starts the process in mode 0 / 2. */
 int stemgnn_linear_set_mode(int mode);
 
 /* y [M, N] = x1 [M, K1] w1[N, K1]^T (+ x2 [M, K2] w2 [N, K2]^T when K2 > 0) + bias [N] (NULL: none).

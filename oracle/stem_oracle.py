@@ -338,6 +338,43 @@ class OracleVectorQuantize(nn.Module):
 
 
 # --------------------------------------------------------------------------------------
+# bf16 GEMM mode (BASELINE config 5 "bf16").  The reference has no autocast call; this
+# emulates what the library's stemgnn_linear_set_mode(2) does to every nn.Linear on the path: BOTH operands of a
+# product rounded to bf16 (nearest even), fp32 accumulation, fp32 bias; in the backward the incoming gradient is
+# rounded the same way for the two products it enters, the bias gradient stays its fp32 column sum.  Everything that
+# is not an nn.Linear (the quantiser's similarity einsum, vq.py:623,634; BatchNorm; the losses) stays fp32.
+# --------------------------------------------------------------------------------------
+class _Bf16Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        xb, wb = x.detach().bfloat16().float(), w.detach().bfloat16().float()
+        ctx.save_for_backward(xb, wb)
+        ctx.has_bias = b is not None
+        y = xb @ wb.t()
+        return y + b if b is not None else y
+
+    @staticmethod
+    def backward(ctx, gy):
+        xb, wb = ctx.saved_tensors
+        gb = gy.bfloat16().float()
+        g2, x2 = gb.reshape(-1, gb.shape[-1]), xb.reshape(-1, xb.shape[-1])
+        return gb @ wb, g2.t() @ x2, (gy.reshape(-1, gy.shape[-1]).sum(0) if ctx.has_bias else None)
+
+
+class bf16_gemms:
+    """Context manager: every ``F.linear`` (hence every ``nn.Linear``) inside runs as ``_Bf16Linear``."""
+
+    def __enter__(self):
+        self._orig = torch.nn.functional.linear
+        torch.nn.functional.linear = lambda input, weight, bias=None: _Bf16Linear.apply(input, weight, bias)
+        return self
+
+    def __exit__(self, *exc):
+        torch.nn.functional.linear = self._orig
+        return False
+
+
+# --------------------------------------------------------------------------------------
 # PyG 2.3.0 utilities used by pretrain.py:41-44 and pt_model.py:60, with the random
 # draw passed in.  PARITY UNPINNED (PyG absent): restated from PyG 2.3.0 semantics.
 # --------------------------------------------------------------------------------------
@@ -404,7 +441,8 @@ class OraclePretrainModel(nn.Module):
         ox, oei, oea = g
         z = self.encoder(x, ei, ea, dropout_masks=draws.get('student_dropout'))  # pt_model.py:112
         quantize, indices, commit_loss, _ = self.vq(z, ortho_ids=draws.get('ortho_ids'),
-                                                    tie_ind=draws.get('vq_indices'))  # pt_model.py:113
+                                                    tie_ind=draws.get('vq_indices'),
+                                                    tie_tol=float(draws.get('vq_tie_tol', 1e-5)))  # pt_model.py:113
         env_reg = self.encoder.get_env_reg()
         q = quantize
         # feat_recon_loss, pt_model.py:42-43

@@ -108,8 +108,27 @@ __device__ __forceinline__ void split8(float4 a, float4 b, uint4& h, uint4& m, u
 // q[i] = columns c .. c+3 of contraction row 4 (tid & 7) + i (c = 4 (tid >> 3)): split every element and store column j
 // as the 4 consecutive contraction steps of plane row c + j, i.e. the transposed image [column][32 k] the fragment
 // reads want, for an operand whose contraction index is its SLOW dimension.
+// One-piece form (bf16 GEMM mode, stemgnn_linear_set_mode(2)): an operand is ROUNDED to bf16 (nearest even, what torch's
+// .bfloat16() does) and only the h plane is written; the product is then ONE matrix instruction per tile and k step.
+__device__ __forceinline__ uint32_t rne_bits(float f) {
+  const __bf16 b = static_cast<__bf16>(f);
+  return static_cast<uint32_t>(__builtin_bit_cast(uint16_t, b));
+}
+__device__ __forceinline__ uint2 pack_rne(float4 a) {
+  return make_uint2(rne_bits(a.x) | (rne_bits(a.y) << 16), rne_bits(a.z) | (rne_bits(a.w) << 16));
+}
+template <int PIECES = 3>
 __device__ __forceinline__ void stash_transposed(const float4 (&q)[4], unsigned char* planes, int plane_bytes, int tid) {
   const int kq = tid & 7, cq = tid >> 3;
+  if (PIECES == 1) {
+    const float v[4][4] = {{q[0].x, q[0].y, q[0].z, q[0].w}, {q[1].x, q[1].y, q[1].z, q[1].w},
+                           {q[2].x, q[2].y, q[2].z, q[2].w}, {q[3].x, q[3].y, q[3].z, q[3].w}};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      *reinterpret_cast<uint2*>(planes + (4 * cq + j) * kLdP + 8 * kq) =
+          make_uint2(rne_bits(v[0][j]) | (rne_bits(v[1][j]) << 16), rne_bits(v[2][j]) | (rne_bits(v[3][j]) << 16));
+    return;
+  }
   uint32_t hb[4][4], mb[4][4], lb[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {

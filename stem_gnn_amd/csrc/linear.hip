@@ -205,7 +205,8 @@ __device__ __forceinline__ int stage_row(int idx) {
   const int r = idx >> 3;
   return (r & ~7) | ((r & 1) << 2) | ((r >> 1) & 3);
 }
-template <int BM, bool STATS, bool BT = false, int X2K = kF32>
+// PIECES = 1: the bf16 GEMM mode -- operands rounded to bf16 while staged, one matrix instruction per tile and k step.
+template <int BM, bool STATS, bool BT = false, int X2K = kF32, int PIECES = 3>
 __global__ void __launch_bounds__(kBlock, 2)
 k_linear_fwd_x3(const float* __restrict__ x1, const float* __restrict__ w1, int K1, const float* __restrict__ x2,
              const float* __restrict__ w2, int K2, const float* __restrict__ bias, int64_t M, int N,
@@ -268,22 +269,30 @@ k_linear_fwd_x3(const float* __restrict__ x1, const float* __restrict__ w1, int 
     held_bf16 = X2K == kBF16 && second;
   };
   auto stash = [&]() {
-    if (BT) stash_transposed(rb, sB, PB, tid);
+    if (BT) stash_transposed<PIECES>(rb, sB, PB, tid);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int idx = t * kBlock + tid;
       const int off = stage_row(idx) * kLdP + 8 * (idx & 7);
       uint2 h, m, l;
       if (!BT) {
-        split3(rb[t], h, m, l);
-        *reinterpret_cast<uint2*>(sB + off) = h;
-        *reinterpret_cast<uint2*>(sB + PB + off) = m;
-        *reinterpret_cast<uint2*>(sB + 2 * PB + off) = l;
+        if (PIECES == 1) {
+          *reinterpret_cast<uint2*>(sB + off) = pack_rne(rb[t]);
+        } else {
+          split3(rb[t], h, m, l);
+          *reinterpret_cast<uint2*>(sB + off) = h;
+          *reinterpret_cast<uint2*>(sB + PB + off) = m;
+          *reinterpret_cast<uint2*>(sB + 2 * PB + off) = l;
+        }
       }
       if (t < FA) {
         if (X2K == kBF16 && held_bf16) {  // four bf16 values ARE the h plane of their fp32 widening; m = l = 0 and
           // never read (the matrix loop takes the one-piece form for these chunks)
           *reinterpret_cast<uint2*>(sA + off) = make_uint2(__float_as_uint(ra[t].x), __float_as_uint(ra[t].y));
+          continue;
+        }
+        if (PIECES == 1) {
+          *reinterpret_cast<uint2*>(sA + off) = pack_rne(ra[t]);
           continue;
         }
         split3(ra[t], h, m, l);
@@ -322,9 +331,9 @@ k_linear_fwd_x3(const float* __restrict__ x1, const float* __restrict__ w1, int 
       const int ko = ks * 32 + hi * 16;  // bytes: lane half 0 takes k 0..7, half 1 k 8..15 of the 16-wide step
       bf16x8 a[TM][3], b[TN][3];
       // chunks of a bf16-stored second operand carry one piece (stash() left the m / l planes alone): three products
-      const bool one_piece = X2K == kBF16 && step >= c1;  // block-uniform
+      const bool one_piece = PIECES == 1 || (X2K == kBF16 && step >= c1);  // block-uniform
 #pragma unroll
-      for (int p = 0; p < 3; ++p) {
+      for (int p = 0; p < PIECES; ++p) {
         if (!(one_piece && p > 0)) {
 #pragma unroll
           for (int t = 0; t < TM; ++t)
@@ -334,7 +343,13 @@ k_linear_fwd_x3(const float* __restrict__ x1, const float* __restrict__ w1, int 
         for (int t = 0; t < TN; ++t)
           b[t][p] = *reinterpret_cast<const bf16x8*>(sB + p * PB + (wn * 32 * TN + t * 32 + lj) * kLdP + ko);
       }
-      if (one_piece) {
+      if (PIECES == 1) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][0], acc[tm][tn], 0, 0, 0);
+      } else if (one_piece) {
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -682,7 +697,8 @@ struct DwTable {
   int count;
 };
 
-template <int XK>  // element kind of x (common.h: kF32 / kBF16), compile-time: a run-time kind cost the fp32 launch 18 %
+template <int XK, int PIECES = 3>  // element kind of x (common.h: kF32 / kBF16), compile-time: a run-time kind cost the
+// fp32 launch 18 %; PIECES = 1: the bf16 GEMM mode (dY and x rounded to bf16 while staged; db stays the fp32 column sum)
 __global__ void __launch_bounds__(kBlock, 2)
 k_linear_bwd_weight_x3(const DwTable tab) {
   constexpr int PL = kBN * kLdP;
@@ -722,7 +738,7 @@ k_linear_bwd_weight_x3(const DwTable tab) {
       else rb[i].clear();
     }
   };
-  auto stash_t = [&](const float4 (&q)[4], unsigned char* planes) { stash_transposed(q, planes, PL, tid); };
+  auto stash_t = [&](const float4 (&q)[4], unsigned char* planes) { stash_transposed<PIECES>(q, planes, PL, tid); };
 
   floatx16 acc[2][2];
 #pragma unroll
@@ -757,7 +773,7 @@ k_linear_bwd_weight_x3(const DwTable tab) {
       const int ko = ks * 32 + hi * 16;
       bf16x8 a[2][3], b[2][3];
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
+      for (int p = 0; p < PIECES; ++p)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           a[t][p] = *reinterpret_cast<const bf16x8*>(sA + p * PL + (wi * 64 + t * 32 + lj) * kLdP + ko);
@@ -766,9 +782,13 @@ k_linear_bwd_weight_x3(const DwTable tab) {
 #pragma unroll
       for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
-        for (int tj = 0; tj < 2; ++tj)
-          acc[ti][tj] = XK == kBF16 ? mfma_x3_b1(a[ti], b[tj][0], acc[ti][tj])  // a bf16-stored x is its own h piece
-                                    : mfma_x3(a[ti], b[tj], acc[ti][tj]);
+        for (int tj = 0; tj < 2; ++tj) {
+          if (PIECES == 1)
+            acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ti][0], b[tj][0], acc[ti][tj], 0, 0, 0);
+          else
+            acc[ti][tj] = XK == kBF16 ? mfma_x3_b1(a[ti], b[tj][0], acc[ti][tj])  // a bf16-stored x is its own h piece
+                                      : mfma_x3(a[ti], b[tj], acc[ti][tj]);
+        }
     }
     __syncthreads();
   }
@@ -1073,19 +1093,27 @@ inline bool lin_dims_ok(int64_t M, int64_t N, int64_t K) {
   return M >= 0 && N > 0 && K > 0 && K % 4 == 0 && N <= 65536 && K <= 65536;
 }
 
-// Which matrix-core path the three products take: 1 (default) = bf16 pieces, 0 = v_mfma_f32_32x32x2_f32 (kept as
-// the cross-check of the split product).  STEMGNN_GEMM=f32 in the environment starts the process in mode 0;
-// stemgnn_linear_set_mode switches at run time.
+// Which matrix-core path the dense products take: 1 (default) = fp32 results from three exact bf16 pieces per operand;
+// 0 = v_mfma_f32_32x32x2_f32 (kept as the cross-check of the split product); 2 = bf16 GEMMs (BASELINE config 5,
+// what autocast would do to the reference's Linears) -- both operands of every product
+// ROUNDED to bf16 while staged, one matrix pass, fp32 accumulation, fp32 bias / output / bias gradient; the quantiser's
+// similarity / arg-max core keeps the exact form (vq.py:623,634 force fp32 there).  Mode 2 runs on the tile kernels
+// only (the weight-stationary, few-row and fused-quantiser kernels are exact-form kernels and stand aside).
+// STEMGNN_GEMM=f32 / bf16 in the environment starts the process in mode 0 / 2; stemgnn_linear_set_mode switches at run
+// time.
 std::atomic<int> g_gemm_mode{-1};
-inline bool gemm_x3() {
+inline int gemm_mode() {
   int m = g_gemm_mode.load(std::memory_order_relaxed);
   if (m < 0) {
     const char* e = getenv("STEMGNN_GEMM");
-    m = (e && e[0] == 'f') ? 0 : 1;
+    m = (e && e[0] == 'f') ? 0 : ((e && e[0] == 'b') ? 2 : 1);
     g_gemm_mode.store(m, std::memory_order_relaxed);
   }
-  return m == 1;
+  return m;
 }
+inline bool gemm_x3() { return gemm_mode() == 1; }        // the exact three-piece form
+inline bool gemm_bf16() { return gemm_mode() == 2; }      // one rounded piece
+inline bool gemm_matrix_bf16() { return gemm_mode() >= 1; }  // either: the bf16 matrix-core tile kernels
 
 // Resident-block slots of the 128-row forward tile kernel on this device (blocks per CU x CUs).
 template <bool X3>
@@ -1105,7 +1133,7 @@ inline int64_t fwd_slots_of() {
   }();
   return slots;
 }
-inline int64_t fwd_slots() { return gemm_x3() ? fwd_slots_of<true>() : fwd_slots_of<false>(); }
+inline int64_t fwd_slots() { return gemm_matrix_bf16() ? fwd_slots_of<true>() : fwd_slots_of<false>(); }
 
 // Tile plan of the forward product: whole rounds of 128-row tiles, and (when the last round
 // would be mostly empty) its rows as 32-row tiles.  Measured at N = 128 on MI355X: 768 tiles (one
@@ -1153,6 +1181,30 @@ inline int64_t ws_min_tiles() { return g_ws_min_tiles.load(std::memory_order_rel
 inline bool ws_enabled() { return ws_min_tiles() > 0; }
 #define kWsMinTiles ws_min_tiles()
 
+// One launch of the forward tile kernel in the process's matrix-core mode (0 fp32 MFMA, 1 exact bf16 pieces, 2 bf16
+// GEMM), for fp32 or bf16-stored second operands, with or without the BatchNorm column sums.
+template <int BM>
+inline void launch_fwd_tile(int mode, bool bf, dim3 grid, hipStream_t st, const float* x1, const float* w1, int k1,
+                            const float* x2, const float* w2, int k2, const float* bias, int64_t M, int n, float* y,
+                            float* stats, int64_t row_base, int64_t stats_block0, int64_t x1r, int64_t sr) {
+#define STEMGNN_FWD_ARGS x1, w1, k1, x2, w2, k2, bias, M, n, y, stats, row_base, stats_block0, x1r, sr
+  if (mode == 0) {
+    if (stats) k_linear_fwd<BM, true><<<grid, kBlock, 0, st>>>(STEMGNN_FWD_ARGS);
+    else k_linear_fwd<BM, false><<<grid, kBlock, 0, st>>>(STEMGNN_FWD_ARGS);
+  } else if (mode == 1) {
+    if (stats && bf) k_linear_fwd_x3<BM, true, false, kBF16><<<grid, kBlock, 0, st>>>(STEMGNN_FWD_ARGS);
+    else if (stats) k_linear_fwd_x3<BM, true><<<grid, kBlock, 0, st>>>(STEMGNN_FWD_ARGS);
+    else if (bf) k_linear_fwd_x3<BM, false, false, kBF16><<<grid, kBlock, 0, st>>>(STEMGNN_FWD_ARGS);
+    else k_linear_fwd_x3<BM, false><<<grid, kBlock, 0, st>>>(STEMGNN_FWD_ARGS);
+  } else {
+    if (stats && bf) k_linear_fwd_x3<BM, true, false, kBF16, 1><<<grid, kBlock, 0, st>>>(STEMGNN_FWD_ARGS);
+    else if (stats) k_linear_fwd_x3<BM, true, false, kF32, 1><<<grid, kBlock, 0, st>>>(STEMGNN_FWD_ARGS);
+    else if (bf) k_linear_fwd_x3<BM, false, false, kBF16, 1><<<grid, kBlock, 0, st>>>(STEMGNN_FWD_ARGS);
+    else k_linear_fwd_x3<BM, false, false, kF32, 1><<<grid, kBlock, 0, st>>>(STEMGNN_FWD_ARGS);
+  }
+#undef STEMGNN_FWD_ARGS
+}
+
 inline int64_t out_tiles(int64_t N, int64_t K) { return ((N + kBN - 1) / kBN) * ((K + kBN - 1) / kBN); }
 
 }  // namespace
@@ -1162,7 +1214,7 @@ namespace stemgnn {
 int DwBatch::add(const float* dy, const void* x, int x_kind, int64_t M, int64_t N, int64_t K, float* dw, float* db,
                  void* workspace, size_t workspace_bytes, hipStream_t st) {
   if (x_kind != kF32 && x_kind != kBF16) return STEMGNN_ERR_INVALID_ARG;
-  if (x_kind == kBF16 && !gemm_x3()) return STEMGNN_ERR_INVALID_ARG;  // the fp32-MFMA cross-check twins read fp32 only
+  if (x_kind == kBF16 && !gemm_matrix_bf16()) return STEMGNN_ERR_INVALID_ARG;  // the fp32-MFMA cross-check twins read fp32 only
   if (!lin_dims_ok(M, N, K) || N % 4 != 0 || !dw) return STEMGNN_ERR_INVALID_ARG;
   if (!fits_i32(M)) return STEMGNN_ERR_TOO_LARGE;
   if (M == 0) {
@@ -1188,7 +1240,8 @@ int DwBatch::add(const float* dy, const void* x, int x_kind, int64_t M, int64_t 
 
 int DwBatch::flush(hipStream_t st) {
   if (count == 0) return STEMGNN_OK;
-  if (gemm_x3()) {
+  if (gemm_matrix_bf16()) {
+    const bool one = gemm_bf16();
     for (int kind = kF32; kind <= kBF16; ++kind) {
       DwTable tab;
       tab.count = 0;
@@ -1205,7 +1258,9 @@ int DwBatch::flush(hipStream_t st) {
         t.block_end = blocks;
       }
       if (tab.count == 0) continue;
-      if (kind == kBF16) k_linear_bwd_weight_x3<kBF16><<<static_cast<unsigned>(blocks), kBlock, 0, st>>>(tab);
+      if (kind == kBF16 && one) k_linear_bwd_weight_x3<kBF16, 1><<<static_cast<unsigned>(blocks), kBlock, 0, st>>>(tab);
+      else if (kind == kBF16) k_linear_bwd_weight_x3<kBF16><<<static_cast<unsigned>(blocks), kBlock, 0, st>>>(tab);
+      else if (one) k_linear_bwd_weight_x3<kF32, 1><<<static_cast<unsigned>(blocks), kBlock, 0, st>>>(tab);
       else k_linear_bwd_weight_x3<kF32><<<static_cast<unsigned>(blocks), kBlock, 0, st>>>(tab);
       STEMGNN_LAUNCH_CHECK();
     }
@@ -1264,8 +1319,8 @@ int stemgnn_linear_set_ws(int min_tiles) {
 }
 
 int stemgnn_linear_set_mode(int mode) {
-  const int prev = gemm_x3() ? 1 : 0;
-  if (mode == 0 || mode == 1) g_gemm_mode.store(mode, std::memory_order_relaxed);
+  const int prev = gemm_mode();
+  if (mode == 0 || mode == 1 || mode == 2) g_gemm_mode.store(mode, std::memory_order_relaxed);
   return prev;
 }
 
@@ -1302,7 +1357,7 @@ int stemgnn_linear_fwd_rows_k(const float* x1, const float* w1, int64_t K1, cons
   if (x2_kind != kF32 && x2_kind != kBF16) return STEMGNN_ERR_INVALID_ARG;
   const float* x2 = static_cast<const float*>(x2_);
   const bool bf = x2_kind == kBF16 && K2 > 0;
-  if (bf && !gemm_x3()) return STEMGNN_ERR_INVALID_ARG;  // the fp32-MFMA cross-check twins read fp32 only
+  if (bf && !gemm_matrix_bf16()) return STEMGNN_ERR_INVALID_ARG;  // the fp32-MFMA cross-check twins read fp32 only
   const int64_t sr = (store_rows < 0 || store_rows > M) ? M : store_rows;
   if (!lin_dims_ok(M, N, K1) || K2 < 0 || K2 % 4 != 0) return STEMGNN_ERR_INVALID_ARG;
   const int64_t x1r = (x1_rows < 0 || x1_rows > M) ? M : x1_rows;
@@ -1333,39 +1388,18 @@ int stemgnn_linear_fwd_rows_k(const float* x1, const float* w1, int64_t K1, cons
       return STEMGNN_OK;
     }
   }
+  const int mode = gemm_mode();
   if (plan.main_tiles > 0) {
     dim3 grid(static_cast<unsigned>(plan.main_tiles), static_cast<unsigned>(gy));
-    if (stats_partial) {
-      if (x3 && bf) k_linear_fwd_x3<128, true, false, kBF16><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, stats_partial, 0, 0, x1r, sr);
-      else if (x3) k_linear_fwd_x3<128, true><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, stats_partial, 0, 0, x1r, sr);
-      else k_linear_fwd<128, true><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, stats_partial, 0, 0, x1r, sr);
-    } else {
-      if (x3 && bf) k_linear_fwd_x3<128, false, false, kBF16><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, nullptr, 0, 0, x1r, sr);
-      else if (x3) k_linear_fwd_x3<128, false><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, nullptr, 0, 0, x1r, sr);
-      else k_linear_fwd<128, false><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, nullptr, 0, 0, x1r, sr);
-    }
+    launch_fwd_tile<128>(mode, bf, grid, st, x1, w1, k1, x2, w2, k2, bias, M, n, y, stats_partial, 0, 0, x1r, sr);
     STEMGNN_LAUNCH_CHECK();
   }
   if (plan.tail_tiles > 0) {
     // the rows of the last, mostly empty round of 128-row tiles run as 32-row tiles: 4x the blocks,
     // a quarter of the latency each, instead of a handful of full-size stragglers
     dim3 grid(static_cast<unsigned>(plan.tail_tiles), static_cast<unsigned>(gy));
-    const int64_t row_base = plan.main_tiles * kBM;
-    if (stats_partial) {
-      if (x3 && bf) k_linear_fwd_x3<32, true, false, kBF16><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, stats_partial,
-                                                                                     row_base, 2 * plan.main_tiles, x1r, sr);
-      else if (x3) k_linear_fwd_x3<32, true><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, stats_partial,
-                                                                      row_base, 2 * plan.main_tiles, x1r, sr);
-      else k_linear_fwd<32, true><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, stats_partial,
-                                                           row_base, 2 * plan.main_tiles, x1r, sr);
-    } else {
-      if (x3 && bf) k_linear_fwd_x3<32, false, false, kBF16><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, nullptr,
-                                                                                      row_base, 2 * plan.main_tiles, x1r, sr);
-      else if (x3) k_linear_fwd_x3<32, false><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, nullptr,
-                                                                       row_base, 2 * plan.main_tiles, x1r, sr);
-      else k_linear_fwd<32, false><<<grid, kBlock, 0, st>>>(x1, w1, k1, x2, w2, k2, bias, M, n, y, nullptr,
-                                                            row_base, 2 * plan.main_tiles, x1r, sr);
-    }
+    launch_fwd_tile<32>(mode, bf, grid, st, x1, w1, k1, x2, w2, k2, bias, M, n, y, stats_partial, plan.main_tiles * kBM,
+                        2 * plan.main_tiles, x1r, sr);
     STEMGNN_LAUNCH_CHECK();
   }
   return STEMGNN_OK;
@@ -1386,16 +1420,19 @@ int stemgnn_linear_bwd_data(const float* dy, const float* w, int64_t M, int64_t 
   const bool x3 = gemm_x3();
   if (x3 && ws_enabled() && N == 128 && K % kBN == 0 && (M + kBM - 1) / kBM >= kWsMinTiles)
     return linear_ws_launch(dy, w, nullptr, M, K, 128, dx, nullptr, 0, 0, M, true, st);
+  const int mode = gemm_mode();
   if (plan.main_tiles > 0) {
     dim3 grid(static_cast<unsigned>(plan.main_tiles), static_cast<unsigned>(gy));
-    if (x3) k_linear_fwd_x3<128, false, true><<<grid, kBlock, 0, st>>>(dy, w, kc, nullptr, nullptr, 0, nullptr, M, n, dx, nullptr, 0, 0, M, M);
+    if (mode == 2) k_linear_fwd_x3<128, false, true, kF32, 1><<<grid, kBlock, 0, st>>>(dy, w, kc, nullptr, nullptr, 0, nullptr, M, n, dx, nullptr, 0, 0, M, M);
+    else if (mode == 1) k_linear_fwd_x3<128, false, true><<<grid, kBlock, 0, st>>>(dy, w, kc, nullptr, nullptr, 0, nullptr, M, n, dx, nullptr, 0, 0, M, M);
     else k_linear_fwd<128, false, true><<<grid, kBlock, 0, st>>>(dy, w, kc, nullptr, nullptr, 0, nullptr, M, n, dx, nullptr, 0, 0, M, M);
     STEMGNN_LAUNCH_CHECK();
   }
   if (plan.tail_tiles > 0) {
     dim3 grid(static_cast<unsigned>(plan.tail_tiles), static_cast<unsigned>(gy));
     const int64_t row_base = plan.main_tiles * kBM;
-    if (x3) k_linear_fwd_x3<32, false, true><<<grid, kBlock, 0, st>>>(dy, w, kc, nullptr, nullptr, 0, nullptr, M, n, dx, nullptr, row_base, 0, M, M);
+    if (mode == 2) k_linear_fwd_x3<32, false, true, kF32, 1><<<grid, kBlock, 0, st>>>(dy, w, kc, nullptr, nullptr, 0, nullptr, M, n, dx, nullptr, row_base, 0, M, M);
+    else if (mode == 1) k_linear_fwd_x3<32, false, true><<<grid, kBlock, 0, st>>>(dy, w, kc, nullptr, nullptr, 0, nullptr, M, n, dx, nullptr, row_base, 0, M, M);
     else k_linear_fwd<32, false, true><<<grid, kBlock, 0, st>>>(dy, w, kc, nullptr, nullptr, 0, nullptr, M, n, dx, nullptr, row_base, 0, M, M);
     STEMGNN_LAUNCH_CHECK();
   }

@@ -802,7 +802,8 @@ static int vq_assign_impl(const float* xp, int64_t N, int64_t H, int64_t Dc, con
   const int64_t rb = row_blocks(N);
   dim3 grid(static_cast<unsigned>(rb), static_cast<unsigned>(H));
   const int Hi = static_cast<int>(H), Dci = static_cast<int>(Dc), Ki = static_cast<int>(K);
-  const bool x3 = stemgnn_linear_set_mode(-1) == 1;  // the mode of the dense products (csrc/linear.hip)
+  // the similarity product takes the exact three-piece form in the bf16 GEMM mode too (vq.py:623,634: fp32 forced there)
+  const bool x3 = stemgnn_linear_set_mode(-1) >= 1;
   unsigned int* counter = ticket_counter(st);
   if (!counter) return STEMGNN_ERR_HIP;
   const double sq_scale = static_cast<double>(sqerr_scale);

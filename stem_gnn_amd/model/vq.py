@@ -247,8 +247,11 @@ class VectorQuantize(nn.Module):
         n = x.size(0)
         h, dc = self.heads, self.codebook_dim
         cb = self._codebook
+        # (the one-call phase reads project_out off a code table built in fp32: in the bf16 GEMM mode the module runs its
+        # products as products, on rounded operands, through the per-op path)
         phase = (self.skip_codes and cb._initted_host and self.has_projections and x.is_cuda
-                 and x.dtype == torch.float32 and not (self.training and cb.ema_update and not freeze_codebook))
+                 and x.dtype == torch.float32 and not (self.training and cb.ema_update and not freeze_codebook)
+                 and ops.linear_set_mode(-1) != 2)
         if phase:
             return self._forward_phase(x, only_one, None if only_one else lead)
         xp = self._project(self.project_in, x).float()  # vq.py:881; the codebook forces fp32 (vq.py:623,634)

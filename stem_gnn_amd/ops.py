@@ -637,8 +637,9 @@ class BnActDropFn(torch.autograd.Function):
 # K3 / K5: dense projections on the fp32 matrix cores
 # ----------------------------------------------------------------------------------------
 def linear_set_mode(mode: int) -> int:
-    """1 (default): fp32 products from exact bf16 pieces on the bf16 matrix cores; 0: fp32-MFMA kernels.
-    Returns the previous mode (any other argument only queries)."""
+    """1 (default): fp32 products from exact bf16 pieces on the bf16 matrix cores; 0: fp32-MFMA kernels; 2: bf16 GEMMs
+    (BASELINE config 5: operands of every Linear rounded to bf16, one matrix pass, fp32 accumulation; the quantiser's
+    similarity / arg-max core stays exact).  Returns the previous mode (any other argument only queries)."""
     return int(lib.stemgnn_linear_set_mode(int(mode)))
 
 

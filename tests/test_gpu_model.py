@@ -938,6 +938,100 @@ def test_pretrain_step_with_bf16_feature_storage(dev):
         torch.testing.assert_close(p2.detach().cpu(), p1.detach(), rtol=1e-3, atol=3e-4, msg=lambda m: f"{n1}: {m}")
 
 
+@pytest.mark.parametrize("storage", ["f32", "bf16"])
+def test_pretrain_step_with_bf16_gemms(dev, storage):
+    """BASELINE config 5 as written ("bf16"; SURVEY.md section 7 step 7: autocast for the K3 / K5 products, the VQ core
+    fp32): ``ops.linear_set_mode(2)`` runs every Linear of the path -- lin_l / lin_r, project_in / project_out, the
+    decoders, the semantic projector, forward and both backward products -- as ONE bf16 matrix pass on operands rounded
+    to bf16, fp32 accumulation; the quantiser's similarity / arg-max stays exact (vq.py:623,634).  Two bars:
+      * 2e-4 (+1e-5) against the oracle that rounds the same operands at the same points (O.bf16_gemms): the two sides
+        differ by fp32 summation order, and where that moves a value across a bf16 rounding boundary, by one bf16 ulp
+        of that element; near-ties of the arg-max are replayed up to 1e-3 for the same reason and counted;
+      * 3e-2 against the plain fp32 oracle: what the mode itself costs (8 significant bits per operand)."""
+    from stem_gnn_amd import ops
+    from stem_gnn_amd.graph import EdgeTypeAttr
+    from stem_gnn_amd.pretrain import default_params, pretrain_step
+    N, E, D, L, H, K, bs = 600, 5000, 64, 2, 4, 64, 200
+    om, gm = make_models(D, L, H, K, D, dev)
+    om32, _ = make_models(D, L, H, K, D, dev)
+    bf = storage == "bf16"
+    if bf:
+        om.encoder.bf16_storage = om.sem_encoder.bf16_storage = True
+    params = default_params()
+    torch.manual_seed(13)
+    x = torch.nn.functional.normalize(torch.randn(N, D), dim=-1)
+    if bf:
+        x = x.bfloat16()
+    half = torch.randint(0, N, (2, E // 2))
+    ei = torch.cat([half, half.flip(0)], dim=1)[:, torch.randperm(E)]
+    table = torch.nn.functional.normalize(torch.randn(4, D), dim=-1)
+    et = torch.randint(0, 4, (E,))
+    opt_o = torch.optim.AdamW(om.parameters(), lr=1e-4, weight_decay=1e-5)
+    opt_32 = torch.optim.AdamW(om32.parameters(), lr=1e-4, weight_decay=1e-5)
+    opt_g = ops.FusedAdamW(gm.parameters(), lr=1e-4, weight_decay=1e-5)
+    ops.manual_seed(6)
+    prev = ops.linear_set_mode(2)
+    ties = 0
+    try:
+        assert ops.linear_set_mode(-1) == 2
+        for step in range(3):
+            loss_g, losses_g, draws = pretrain_step(gm, opt_g, None, params, x.to(dev), ei.to(dev),
+                                                    EdgeTypeAttr(table.to(dev), et.to(dev)), bs)
+            cpu_draws = {k: ([m.cpu() for m in v] if isinstance(v, list) else v.cpu()) for k, v in draws.items()}
+            cpu_draws["vq_tie_tol"] = 1e-3
+            with O.bf16_gemms():
+                loss_o, losses_o, _ = O.pretrain_step(om, opt_o, None, params, x.float(), ei, table[et], bs, cpu_draws)
+            ties += om.vq.last_tie_adopted
+            loss_f, losses_f, _ = O.pretrain_step(om32, opt_32, None, params, x.float(), ei, table[et], bs,
+                                                  {k: v for k, v in cpu_draws.items() if k not in ("vq_indices", "vq_tie_tol")})
+            for k in losses_o:
+                torch.testing.assert_close(losses_g[k].cpu().reshape(-1), losses_o[k].reshape(-1), rtol=2e-4, atol=1e-5,
+                                           msg=lambda m: f"step {step} {k} (bf16 GEMMs emulated): {m}")
+                torch.testing.assert_close(losses_g[k].cpu().reshape(-1), losses_f[k].reshape(-1), rtol=3e-2, atol=2e-3,
+                                           msg=lambda m: f"step {step} {k} (plain fp32 oracle): {m}")
+    finally:
+        ops.linear_set_mode(prev)
+    assert ties <= 12, ties
+    for (n1, p1), (n2, p2) in zip(om.named_parameters(), gm.named_parameters()):
+        if "lin_l.bias" in n1 or n1.startswith("sem_encoder"):
+            continue
+        torch.testing.assert_close(p2.detach().cpu(), p1.detach(), rtol=1e-3, atol=3e-4, msg=lambda m: f"{n1}: {m}")
+
+
+@pytest.mark.parametrize("m,k1,k2,n,rows", [(1000, 128, 0, 128, -1), (777, 64, 32, 96, -1), (2000, 128, 128, 128, 300),
+                                            (4097, 768, 0, 128, -1), (1300, 96, 0, 3072, -1)])
+def test_bf16_gemm_mode_is_the_product_of_the_rounded_operands(dev, m, k1, k2, n, rows):
+    """Kernel-level statement of mode 2: y = round(x1) round(w1)^T (+ round(x2) round(w2)^T) + b, dx = round(dy) round(w),
+    dw = round(dy)^T round(x), db = colsum(dy), all accumulated in fp32 -- against torch on the rounded operands in fp64
+    (1e-5 of the largest output: fp32 accumulation only)."""
+    from stem_gnn_amd import ops
+    torch.manual_seed(m + n)
+    r = lambda t: t.bfloat16().double()  # noqa: E731
+    a = torch.randn(m, k1, device=dev) * (1 + 3 * torch.rand(m, 1, device=dev))
+    w = torch.randn(n, k1, device=dev) * 0.2
+    a2 = torch.randn(m, k2, device=dev) if k2 else None
+    w2 = torch.randn(n, k2, device=dev) * 0.2 if k2 else None
+    b = torch.randn(n, device=dev)
+    if rows >= 0:
+        a[rows:] = 0
+    dy = torch.randn(m, n, device=dev)
+    prev = ops.linear_set_mode(2)
+    try:
+        y, _, _ = ops.linear_fwd(a, w, a2, w2, b, False, rows)
+        dx = ops.linear_bwd_data(dy, w)
+        dw, db = ops.linear_bwd_weight(dy, a, True)
+    finally:
+        ops.linear_set_mode(prev)
+    ref = r(a) @ r(w).t() + (r(a2) @ r(w2).t() if k2 else 0) + b.double()
+    tol = lambda t: 1e-5 * float(t.abs().max())  # noqa: E731
+    torch.testing.assert_close(y.double(), ref, rtol=1e-5, atol=tol(ref))
+    ref_dx = r(dy) @ r(w)
+    torch.testing.assert_close(dx.double(), ref_dx, rtol=1e-5, atol=tol(ref_dx))
+    ref_dw = r(dy).t() @ r(a)
+    torch.testing.assert_close(dw.double(), ref_dw, rtol=1e-5, atol=tol(ref_dw))
+    torch.testing.assert_close(db.double(), dy.double().sum(0), rtol=1e-5, atol=1e-4 * float(dy.abs().sum(0).max()))
+
+
 def test_deterministic_mode_makes_steps_bit_reproducible(dev):
     """stemgnn_set_deterministic(1): the decoders' backward scatters add in a fixed order (edges grouped by node)
     instead of with fp32 atomics -- the only order-dependent arithmetic on the path.  Two runs of three optimiser steps
