@@ -60,6 +60,9 @@ def parse():
                     help="dense products: f32 = fp32 results from exact bf16 pieces (the headline mode); bf16 = one bf16 "
                          "matrix pass on rounded operands, fp32 accumulation, fp32 VQ core (BASELINE config 5); auto = "
                          "bf16 for the c5 workload, f32 otherwise")
+    ap.add_argument("--pmc-traffic", default="auto", choices=["auto", "off"],
+                    help="auto (N = 1, c4): measure roofline.traffic live -- two short child runs of this script under "
+                         "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes); off: quote profiles/step_traffic.json")
     ap.add_argument("--no-extra", action="store_true", help="skip the K1 legs at C2 / C3 size and the dense-product leg")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
     return ap.parse_args()
@@ -120,6 +123,70 @@ def cpu_model() -> str:
         pass
     import platform
     return platform.processor() or platform.machine() or "unknown"
+
+
+def pmc_step_traffic(args, timeout_s=300):
+    """HBM bytes from the PMC counters, collected as MI355X_MICROARCH.md prescribes: one rocprofv3 --pmc pass per counter
+    (FETCH_SIZE, WRITE_SIZE), nothing else traced, over a short run of THIS script (child processes; this process never
+    execs).  FETCH_SIZE tallies 128-B requests at 64 B on gfx950: read bytes = 2 * FETCH_SIZE KiB; WRITE_SIZE is exact for
+    16-byte streaming stores.  Steps are cut at the teacher's EMA kernel; the K1 launches of a step are split into the
+    two on the batch graph (the larger fetches) and the two on the augmented graph.
+    -> dict(traffic_bytes_per_step, k1_batch_traffic_bytes_per_launch, k1_augmented_traffic_bytes_per_launch) or
+    dict(error=...)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {"error": "rocprofv3 not found"}
+    per = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="stemgnn_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", counter, "--", sys.executable,
+               os.path.abspath(__file__), "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-extra",
+               "--e2e-steps", "0", "--pmc-traffic", "off", "--workload", args.workload, "--batch-size",
+               str(args.batch_size), "--gemm", args.gemm, "--feature-dtype", args.feature_dtype]
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
+                               stderr=subprocess.DEVNULL, timeout=timeout_s)
+            rows = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if row["Counter_Name"] == counter:
+                            rows.append((int(row["Dispatch_Id"]), row["Kernel_Name"], float(row["Counter_Value"])))
+            rows.sort()
+            if r.returncode != 0 or not rows:
+                return {"error": f"rocprofv3 --pmc {counter}: rc {r.returncode}, {len(rows)} counter rows"}
+            per[counter] = rows
+        except (subprocess.TimeoutExpired, OSError) as e:
+            return {"error": f"rocprofv3 --pmc {counter}: {type(e).__name__}"}
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+
+    def steps_of(rows, scale):
+        """bytes per dispatch, cut into steps at k_ema_lerp (the step's last kernel); the last full steps only"""
+        cuts = [i for i, (_, k, _) in enumerate(rows) if "k_ema_lerp" in k]
+        return [[(k, v * 1024.0 * scale) for _, k, v in rows[a + 1:b + 1]] for a, b in zip(cuts[:-1], cuts[1:])][-4:]
+
+    rd, wr = steps_of(per["FETCH_SIZE"], 2.0), steps_of(per["WRITE_SIZE"], 1.0)
+    if not rd or len(rd) != len(wr) or any(len(a) != len(b) for a, b in zip(rd, wr)):
+        return {"error": "the two counter passes saw different launch sequences"}
+    totals, k1b, k1a = [], [], []
+    for a, b in zip(rd, wr):
+        totals.append(sum(v for _, v in a) + sum(v for _, v in b))
+        k1 = sorted(((va, va + vb) for (ka, va), (_, vb) in zip(a, b) if "k_sage_agg_fwd" in ka), reverse=True)
+        half = len(k1) // 2
+        k1b += [t for _, t in k1[:half]]
+        k1a += [t for _, t in k1[half:]]
+    mean = lambda v: sum(v) / len(v) if v else None  # noqa: E731
+    return {"traffic_bytes_per_step": mean(totals), "k1_batch_traffic_bytes_per_launch": mean(k1b),
+            "k1_augmented_traffic_bytes_per_launch": mean(k1a), "launches_per_step": len(rd[-1]),
+            "source": "measured in this run: two child runs of bench.py (6 steps) under rocprofv3 --pmc FETCH_SIZE and "
+                      "--pmc WRITE_SIZE (separate passes, nothing else traced); read = 2 x FETCH_SIZE KiB on gfx950 "
+                      "(MI355X_MICROARCH.md), averaged over the last four steps"}
 
 
 def step_algorithmic_bytes(N, A, E, E_aug, k, bs, D, HD, in_dim, T):
@@ -399,17 +466,23 @@ def main():
         # HBM bytes from the PMC counters are collected by separate rocprofv3 --pmc passes on this workload
         # (tools/prof_pmc.sh -> profiles/step_traffic.json), NOT in this run: the file's numbers are quoted here
         tinfo = {}
+        tsource = "not measured"
+        if args.pmc_traffic == "auto" and world == 1 and args.workload == "c4":
+            tinfo = pmc_step_traffic(args)
+            tsource = tinfo.get("source") or ("live PMC pass failed (" + tinfo.get("error", "?") + ")")
         tpath = os.path.join(ROOT, "profiles", "step_traffic.json")
-        if args.workload == "c4" and args.batch_size == 1024 and os.path.exists(tpath):
+        if "traffic_bytes_per_step" not in tinfo and args.workload == "c4" and args.batch_size == 1024 and os.path.exists(tpath):
             with open(tpath) as fh:
                 tinfo = json.load(fh)
+            tsource = (tsource + "; " if "failed" in tsource else "") + \
+                "quoted from profiles/step_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this " \
+                "workload, tools/prof_pmc.sh; not measured in this run)"
         head = k1_batch or k1_aug or {"achieved": 0.0, "frac": 0.0}
         roofline = {"bound": "hbm", "kernel": "k_sage_agg_fwd (K1, type-indexed edge attr), launches on the batch graph "
                                               "(the teacher's two per step; rows = the nodes that can receive edges)",
                     "achieved": head["achieved"], "peak": peak, "unit": "GB/s", "frac": head["frac"],
                     "traffic": tinfo.get("k1_batch_traffic_bytes_per_launch"),
-                    "traffic_source": "profiles/step_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
-                                      "of this workload; not measured in this run)",
+                    "traffic_source": tsource,
                     "launches": head.get("launches"), "avg_launch_us": head.get("avg_launch_us"),
                     "algorithmic_bytes_per_launch": head.get("algorithmic_bytes_per_launch"),
                     "rows_per_launch": head.get("rows_per_launch"), "edges_per_launch": head.get("edges_per_launch"),

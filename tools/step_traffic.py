@@ -78,9 +78,10 @@ if k1:
     m = min(len(f), len(w)) // n * n
     f, w = f[len(f) - m:], w[len(w) - m:]
     cls = {"augmented": [], "batch": []}
-    for i in range(m):
-        which = "augmented" if (i % n) < n // 2 else "batch"  # student (augmented graph) first, then teacher
-        cls[which].append(2 * f[i] * 1024 + w[i] * 1024)
+    for s0 in range(0, m, n):  # per step: the launches with the larger fetches ran on the batch graph (the teacher's)
+        tot = sorted(((f[i], 2 * f[i] * 1024 + w[i] * 1024) for i in range(s0, s0 + n)), reverse=True)
+        cls["batch"] += [t for _, t in tot[:n // 2]]
+        cls["augmented"] += [t for _, t in tot[n // 2:]]
     for c, v in cls.items():
         if v:
             info["k1_%s_traffic_bytes_per_launch" % c] = sum(v[-10:]) / len(v[-10:])
