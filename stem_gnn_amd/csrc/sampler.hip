@@ -49,7 +49,11 @@ k_seed_fix(int32_t B, const int32_t* __restrict__ n_id, int32_t* __restrict__ lo
   if (v > INT_MAX - B - 1) local_of[g] = INT_MAX - v;  // first position that named this node
 }
 
-// One thread per frontier node: draw min(deg, fanout) distinct in-neighbour slots.
+// One thread per frontier node: draw min(deg, fanout) distinct in-neighbour slots (Floyd's algorithm: for j = deg - f ..
+// deg - 1 draw t ~ U[0, j] and take t unless already taken, else j), emitted in CSR order.  Rows of up to 64 slots
+// (every row of the C4 graph) keep the chosen set as a 64-bit mask in a register: membership is a shift, the ascending
+// walk a find-first-set -- the round-2 form kept a sorted array, which the compiler put in scratch memory, and took
+// 41 us per hop for ten thousand rows; longer rows still take that form.
 __global__ void __launch_bounds__(kThreads)
 k_sample_hop(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src, const int32_t* __restrict__ etype,
              const int32_t* __restrict__ n_id, const BatchCounters* __restrict__ ctr, int hop, int fanout,
@@ -61,32 +65,73 @@ k_sample_hop(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src
   if (i >= f1 - f0) { s_cnt[i] = 0; return; }
   const int32_t v = n_id[f0 + i];
   const int beg = rowptr[v], deg = rowptr[v + 1] - beg;
-  int chosen[kMaxFanout];
-  int c = 0;
-  if (fanout < 0 || deg <= fanout) {
-    c = deg < kMaxFanout ? deg : kMaxFanout;
+  const int64_t out0 = static_cast<int64_t>(i) * fanout;
+  if (fanout < 0 || deg <= fanout) {  // the whole row (capped at the widest fan-out the buffers hold)
+    int c = deg < kMaxFanout ? deg : kMaxFanout;
     if (fanout >= 0 && c > fanout) c = fanout;
-    for (int j = 0; j < c; ++j) chosen[j] = j;
-  } else {
-    // Floyd: for j = deg-f .. deg-1: t ~ U[0, j]; take t unless already taken, else take j
-    uint32_t r[4];
+    s_cnt[i] = c;
+    for (int j = 0; j < c; ++j) {
+      s_src[out0 + j] = src[beg + j];
+      s_type[out0 + j] = etype ? etype[beg + j] : 0;
+    }
+    return;
+  }
+  uint32_t r[4];
+  if (deg <= 64) {
+    uint64_t mask = 0;
     for (int q = 0; q < fanout; ++q) {
       if ((q & 3) == 0) Philox::gen(seed, offset, static_cast<uint64_t>(i) * 8 + (q >> 2), r);
       const int j = deg - fanout + q;
       int t = static_cast<int>(r[q & 3] % static_cast<uint32_t>(j + 1));
-      bool taken = false;
-      for (int a = 0; a < c; ++a) taken |= (chosen[a] == t);
-      if (taken) t = j;
-      // insertion keeps `chosen` ascending (CSR order among the chosen edges)
-      int p = c++;
-      while (p > 0 && chosen[p - 1] > t) { chosen[p] = chosen[p - 1]; --p; }
-      chosen[p] = t;
+      if ((mask >> t) & 1ull) t = j;  // j itself was never drawn before: every earlier draw is < j
+      mask |= 1ull << t;
     }
+    s_cnt[i] = fanout;
+    if (fanout <= 16) {
+      // ascending slots = CSR order among the chosen edges; all loads of the row in flight before the first store (the
+      // reads are scattered over an 80 MB array: one at a time they are a chain of cache and TLB misses)
+      int pos[16], vs[16], vt[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        pos[j] = mask ? __ffsll(static_cast<unsigned long long>(mask)) - 1 : 0;
+        mask &= mask - 1;
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        vs[j] = j < fanout ? src[beg + pos[j]] : 0;
+        vt[j] = (j < fanout && etype) ? etype[beg + pos[j]] : 0;
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if (j < fanout) { s_src[out0 + j] = vs[j]; s_type[out0 + j] = vt[j]; }
+      return;
+    }
+    for (int j = 0; j < fanout; ++j) {
+      const int t = __ffsll(static_cast<unsigned long long>(mask)) - 1;
+      mask &= mask - 1;
+      s_src[out0 + j] = src[beg + t];
+      s_type[out0 + j] = etype ? etype[beg + t] : 0;
+    }
+    return;
+  }
+  int chosen[kMaxFanout];
+  int c = 0;
+  for (int q = 0; q < fanout; ++q) {
+    if ((q & 3) == 0) Philox::gen(seed, offset, static_cast<uint64_t>(i) * 8 + (q >> 2), r);
+    const int j = deg - fanout + q;
+    int t = static_cast<int>(r[q & 3] % static_cast<uint32_t>(j + 1));
+    bool taken = false;
+    for (int a = 0; a < c; ++a) taken |= (chosen[a] == t);
+    if (taken) t = j;
+    // insertion keeps `chosen` ascending (CSR order among the chosen edges)
+    int p = c++;
+    while (p > 0 && chosen[p - 1] > t) { chosen[p] = chosen[p - 1]; --p; }
+    chosen[p] = t;
   }
   s_cnt[i] = c;
   for (int j = 0; j < c; ++j) {
-    s_src[static_cast<int64_t>(i) * fanout + j] = src[beg + chosen[j]];
-    s_type[static_cast<int64_t>(i) * fanout + j] = etype ? etype[beg + chosen[j]] : 0;
+    s_src[out0 + j] = src[beg + chosen[j]];
+    s_type[out0 + j] = etype ? etype[beg + chosen[j]] : 0;
   }
 }
 
