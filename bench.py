@@ -141,6 +141,10 @@ def pmc_step_traffic(args, timeout_s=300):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return {"error": "rocprofv3 not found"}
+    # under somebody else's profiler (its tool library preloaded into this process and inherited by children) a nested
+    # rocprofv3 would initialise the GPU in its launcher and then exec: not from here
+    if any(k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return {"error": "this run is itself being profiled"}
     per = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="stemgnn_pmc_", dir="/tmp")
@@ -393,13 +397,21 @@ def main():
         return pretrain_step(model, opt, sched, params, x, ei, EdgeTypeAttr(g.edge_text_feat, xe), bs,
                              record_draws=False, forward_fn=fwd)
 
-    for i in range(args.warmup):
-        step(i)
-    # a generation-2 cyclic GC pass over the long-lived objects (model, resident batches) costs ~70 ms when
-    # it happens to fire inside a step: collect now, then keep the collector off the hot loop
+    # Housekeeping BEFORE the warm-up steps, so that the device goes from the last warm-up step straight into the timed
+    # ones (a 100 ms host pause between them lets the clocks drop, and a 20-step timed region is then 3 % slower than
+    # a 100-step one):
+    #  * a generation-2 cyclic GC pass over the long-lived objects (model, resident batches) costs ~70 ms when it
+    #    happens to fire inside a step: collect now, then keep the collector off the hot loop;
+    #  * the caching allocator's pool is reserved in one piece: batch sizes differ by a fraction of a per cent, and a
+    #    step whose largest buffer is the largest seen so far would otherwise go to hipMalloc inside the timed region.
     gc.collect()
     gc.freeze()
     gc.disable()
+    if not wl["full_batch"]:
+        pool = torch.empty(6 << 30, dtype=torch.uint8, device=dev)
+        del pool
+    for i in range(args.warmup):
+        step(i)
     ops.k1_timer.reset(True)
     if world > 1:
         dist.barrier()

@@ -4,7 +4,7 @@ set -e
 mkdir -p gpurun_out
 for i in 1 2 3; do
   (cd _ab && python bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-extra --e2e-steps 0 2>/dev/null) > gpurun_out/ab_head_$i.json
-  python bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-extra --e2e-steps 0 2>/dev/null > gpurun_out/ab_tree_$i.json
+  python bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-extra --e2e-steps 0 --pmc-traffic off 2>/dev/null > gpurun_out/ab_tree_$i.json
 done
 python - <<'PY'
 import json,glob

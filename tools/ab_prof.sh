@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 for w in tree head; do
   if [ $w = head ]; then D=$R/_ab; else D=$R; fi
   cd $D
-  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/abp_$w -o run -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra --e2e-steps 0 > /tmp/abp_$w.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/abp_$w -o run -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra --e2e-steps 0 --pmc-traffic off > /tmp/abp_$w.log 2>&1
   cp $(find /tmp/abp_$w -name '*kernel_stats.csv' | head -1) $R/gpurun_out/abp/${w}_kernel_stats.csv
 done
 cd $R

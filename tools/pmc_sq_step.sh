@@ -7,7 +7,7 @@ P2="SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_VALU_MFMA_BUSY
 i=0
 for P in "$P1" "$P2"; do
   i=$((i+1)); rm -rf /tmp/pmcsq_$i
-  rocprofv3 --pmc $P --output-format csv -d /tmp/pmcsq_$i -o p -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extra --e2e-steps 0 > /tmp/pmcsq_$i.log 2>&1
+  rocprofv3 --pmc $P --output-format csv -d /tmp/pmcsq_$i -o p -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extra --e2e-steps 0 --pmc-traffic off > /tmp/pmcsq_$i.log 2>&1
   echo "pass $i rc=$?"
 done
 FILTER="$*" python3 - <<'PY' > gpurun_out/pmc_sq_step.txt

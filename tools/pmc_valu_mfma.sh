@@ -2,7 +2,7 @@
 # VALU : MFMA instruction ratio of the product kernels over a short C4 bench run (one rocprofv3 --pmc pass).
 R=$(pwd); cd /tmp && export TMPDIR=/tmp && cd $R
 rm -rf /tmp/pmcvm
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU --output-format csv -d /tmp/pmcvm -o p -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extra --e2e-steps 0 > /tmp/pmcvm.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU --output-format csv -d /tmp/pmcvm -o p -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extra --e2e-steps 0 --pmc-traffic off > /tmp/pmcvm.log 2>&1
 echo "rc=$?"
 python3 - <<'PY' > gpurun_out/pmc_valu_mfma.txt
 import csv,glob,collections

@@ -3,7 +3,7 @@
 # per-step traffic table.  usage: tools/prof_pmc.sh <tag>   (GPU box; writes gpurun_out/<tag>_step_traffic.{csv,json})
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-args="--steps 10 --warmup 3 --no-cpu-baseline --e2e-steps 0 --no-extra"
+args="--steps 10 --warmup 3 --no-cpu-baseline --e2e-steps 0 --no-extra --pmc-traffic off"
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmc_${tag}_$c
   rocprofv3 --pmc $c --output-format csv -d gpurun_out/pmc_${tag}_$c -o $c -- python3 bench.py $args > gpurun_out/${tag}_pmc_$c.log 2>&1

@@ -5,7 +5,7 @@ tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/prof_$tag
 rm -rf "$out"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -o "$tag" -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --e2e-steps 0 "$@" > "gpurun_out/${tag}_prof.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -o "$tag" -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --e2e-steps 0 --pmc-traffic off "$@" > "gpurun_out/${tag}_prof.log" 2>&1
 echo "rocprof rc=$?"
 trace=$(find "$out" -name "*kernel_trace.csv" | head -1)
 stats=$(find "$out" -name "*kernel_stats.csv" | head -1)
