@@ -448,17 +448,21 @@ def main():
             def __len__(self):
                 return 0
 
-        done = 0
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for b in PrefetchLoader(Rest(), dev, prepare):
-            if done == args.e2e_steps:
-                break
-            pretrain_step(model, opt, sched, params, b.feat, b.graph, EdgeTypeAttr(g.edge_text_feat, b.xe), b.batch_size,
-                          record_draws=False, forward_fn=fwd)
-            done += 1
-        torch.cuda.synchronize()
-        e2e_ms = (time.perf_counter() - t1) / max(done, 1) * 1e3
+        def in_loop(steps):
+            done = 0
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for b in PrefetchLoader(Rest(), dev, prepare):
+                if done == steps:
+                    break
+                pretrain_step(model, opt, sched, params, b.feat, b.graph, EdgeTypeAttr(g.edge_text_feat, b.xe), b.batch_size,
+                              record_draws=False, forward_fn=fwd)
+                done += 1
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t1) / max(done, 1) * 1e3
+
+        e2e_ms = in_loop(args.e2e_steps)
+
 
     if rank == 0:
         peak = 8000.0  # MI355X HBM3E spec, GB/s (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
