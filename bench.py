@@ -431,35 +431,39 @@ def main():
     edges = float(sum(batches[i][1].num_edges for i in range(args.warmup, total)))
     dt, edges = reduce_bench_stats(dt, edges, dev)
 
-    # the same step with the loader INSIDE the loop (sample -> gather features -> both CSR views ->
-    # step), reported beside the headline, never as `value`.  One batch is sampled ahead on a side stream.
+    # the same step with the loader INSIDE the loop (sample with both CSR views -> gather features ->
+    # step), reported beside the headline, never as `value`.  The loader runs two batches ahead on a side stream
+    # (data/sampler.py PrefetchLoader): the host never waits for a batch's sizes.
     e2e_ms = None
     if not wl["full_batch"] and args.e2e_steps > 0:
         from stem_gnn_amd.data.sampler import PrefetchLoader
 
-        def prepare(b):
-            b.feat = ops.gather_rows(g.node_text_feat, b.x.contiguous())
-            b.graph.ensure_transpose()
+        def prepare(b):  # both CSR views, 1 / in-degree and the row ids come from the sampler's own launches
+            b.feat = ops.gather_rows(g.node_text_feat, b.x, validate=False, capacity=b.cap_nodes)
 
-        class Rest:  # the batches this rank's loader has not handed out yet
-            def __iter__(self):
-                return it
+        class Rest:  # this rank's loader from the top of its shard again, epoch after epoch
+            def iter_pending(self):
+                while True:
+                    yield from loader.iter_pending()
 
             def __len__(self):
                 return 0
 
-        def in_loop(steps):
-            done = 0
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
+        def in_loop(steps, warm=5):
+            # `warm` untimed steps first: the loader's side stream gets its hardware queue and its own allocator pool
+            # on first use (a few hipMallocs: ~7 ms, once per run, which would otherwise be spread over `steps`)
+            done, t1 = 0, None
             for b in PrefetchLoader(Rest(), dev, prepare):
-                if done == steps:
+                if done == warm:
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                if done == warm + steps:
                     break
                 pretrain_step(model, opt, sched, params, b.feat, b.graph, EdgeTypeAttr(g.edge_text_feat, b.xe), b.batch_size,
                               record_draws=False, forward_fn=fwd)
                 done += 1
             torch.cuda.synchronize()
-            return (time.perf_counter() - t1) / max(done, 1) * 1e3
+            return (time.perf_counter() - t1) / max(done - warm, 1) * 1e3
 
         e2e_ms = in_loop(args.e2e_steps)
 

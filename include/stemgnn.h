@@ -141,6 +141,23 @@ int stemgnn_sample_batch(const int32_t* rowptr, const int32_t* src, const int32_
                          uint64_t seed, uint64_t offset, int32_t* local_of, int64_t cap_nodes, int64_t cap_edges,
                          int32_t* n_id, int32_t* b_rowptr, int32_t* b_src, int32_t* b_type, int64_t* b_coo,
                          int32_t* counts, void* workspace, size_t workspace_bytes, void* stream);
+/* The same batch plus everything its consumers would otherwise derive with further launches (one call = 11 launches for
+ * two hops): the by-SOURCE CSR rowptr_t [cap_nodes+1] / dst_t / eid_t / type_t [cap_edges] -- identical to
+ * stemgnn_csr_build(key_row = 0) of b_coo followed by a gather of the types (rows in edge order) --, inv_deg
+ * [cap_nodes] = 1 / max(in-degree, 1) (stemgnn_inv_degree of b_rowptr), and the int64 forms the reference's batch
+ * object carries (pretrain.py:166-176 reads batch.n_id / batch.x / batch.xe): n_id64 [cap_nodes], type64 [cap_edges],
+ * x_out[i] = x[n_id[i]] (x = the dataset's node -> feature-row table, int64 [num_nodes]; NULL: x_out = n_id).
+ * Here b_coo is written as a CONTIGUOUS [2, E_b] (row stride E_b, not cap_edges), and `counts` is only ever written
+ * (by one thread of the last-but-one launch): it may be device-accessible pinned host memory (hipHostMalloc), which
+ * saves the size copy -- the caller then waits for an event recorded behind the call instead.  n_id64 / type64 / x_out may each
+ * be NULL. */
+int stemgnn_sample_batch_views(const int32_t* rowptr, const int32_t* src, const int32_t* etype, int64_t num_nodes,
+                               const int64_t* seeds, int64_t batch_size, const int32_t* fanouts_host, int64_t hops,
+                               uint64_t seed, uint64_t offset, int32_t* local_of, int64_t cap_nodes, int64_t cap_edges,
+                               int32_t* n_id, int32_t* b_rowptr, int32_t* b_src, int32_t* b_type, int64_t* b_coo,
+                               int32_t* counts, int32_t* rowptr_t, int32_t* dst_t, int32_t* eid_t, int32_t* type_t,
+                               float* inv_deg, int64_t* n_id64, int64_t* type64, const int64_t* x, int64_t* x_out,
+                               void* workspace, size_t workspace_bytes, void* stream);
 
 /* out[i] = table[index[i]] for int32 tables (edge-type id per CSR slot = xe[eid[slot]]). */
 int stemgnn_gather_i32(const int32_t* table, const int32_t* index, int64_t n, int32_t* out, void* stream);

@@ -87,6 +87,8 @@ _SIGNATURES = {
     "stemgnn_sampler_workspace_bytes": (c_size_t, [I64, I64, I64]),
     "stemgnn_sample_batch": (c_int, [P, P, P, I64, P, I64, P, I64, c_uint64, c_uint64, P, I64, I64, P, P, P, P, P, P, P,
                                      c_size_t, P]),
+    "stemgnn_sample_batch_views": (c_int, [P, P, P, I64, P, I64, P, I64, c_uint64, c_uint64, P, I64, I64, P, P, P, P, P, P,
+                                           P, P, P, P, P, P, P, P, P, P, c_size_t, P]),
     "stemgnn_gather_i32": (c_int, [P, P, I64, P, P]),
     "stemgnn_group_by_key": (c_int, [P, I64, I64, P, P, P, c_size_t, P]),
     "stemgnn_sage_agg_fwd": (c_int, [P, I64, I64, P, P, P, P, P, P, I64, P, P]),

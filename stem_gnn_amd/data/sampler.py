@@ -28,13 +28,14 @@ class Batch:
     xe: Tensor                # int64 [Eb] edge-type ids
     node_text_feat: Tensor
     edge_text_feat: Tensor
+    cap_nodes: int = 0        # the most nodes a batch of this many seeds / these fan-outs can have (buffer sizing)
 
 
 class HipNeighborSampler:
     """The same contract on the fused HIP sampler (csrc/sampler.hip): the full graph's by-target
-    CSR and edge types stay resident in HBM, a batch is a dozen small launches + one 8-byte
-    device->host copy, and the batch arrives with its by-target CSR already built
-    (``Batch.graph``)."""
+    CSR and edge types stay resident in HBM, a batch is 11 launches (two hops) + one 12-byte
+    device->host copy, and the batch arrives with BOTH CSR views, 1 / in-degree and its int64 id / type / feature-row
+    vectors already built (``Batch.graph``): no launch is left for the consumer but the feature gather."""
 
     def __init__(self, edge_index: Tensor, xe: Tensor, num_nodes: int, x: Tensor, node_text_feat: Tensor,
                  edge_text_feat: Tensor, num_neighbors: List[int], seed: int = 0):
@@ -43,7 +44,9 @@ class HipNeighborSampler:
         rowptr, src, eid, _ = ops.csr_build(edge_index.contiguous(), num_nodes, 1)
         self.rowptr, self.src = rowptr, src
         self.etype = ops.gather_i32(xe.to(torch.int32).contiguous(), eid)
-        self.x, self.ntf, self.etf = x, node_text_feat, edge_text_feat
+        self.x, self.ntf, self.etf = x.contiguous(), node_text_feat, edge_text_feat
+        self._slots = None  # identity slot -> edge map, shared by every batch (slices of one arange)
+        self._sizes = None  # pinned landing zone of the batches' sizes
         self.local_of = ops.sampler_init_map(num_nodes, edge_index.device)
         self.seed, self.calls = int(seed), 0
         # degree bounds of every batch, known on the host once (one sync here, none per batch): a
@@ -56,19 +59,45 @@ class HipNeighborSampler:
         cap = max((f if f >= 0 else d_in) for f in self.fanouts) if self.fanouts else 0
         self.batch_max_in_degree, self.batch_max_out_degree = int(min(cap, d_in)), int(d_out)
 
-    def sample(self, seeds: Tensor) -> Batch:
-        from ..graph import GraphStructure
+    def sample_async(self, seeds: Tensor) -> "PendingBatch":
+        """Enqueue the batch's launches on the current stream and return at once; ``result()`` waits for its sizes
+        (12 bytes) only.  A loader that keeps one batch in flight beyond the one being prepared never waits."""
         self.calls += 1
-        n_id, rowptr, src, etype, coo, nb, eb, ab = ops.sample_batch(self.rowptr, self.src, self.etype, self.num_nodes,
-                                                                 seeds.contiguous(), self.fanouts, self.seed,
-                                                                 self.calls * 64, self.local_of)
-        n_id64 = n_id.long()
-        b = Batch(batch_size=seeds.numel(), n_id=n_id64, x=self.x.index_select(0, n_id64), edge_index=coo, xe=etype.long(),
-                  node_text_feat=self.ntf, edge_text_feat=self.etf)
-        b.graph = GraphStructure.from_csr(rowptr, src, coo, nb, etype_slot=etype,
+        if self._sizes is None:
+            self._sizes = torch.empty(8, 3, dtype=torch.int32, pin_memory=True)  # ring: at most a few batches in flight
+        pend = ops.sample_batch_views_launch(self.rowptr, self.src, self.etype, self.num_nodes, seeds.contiguous(),
+                                             self.fanouts, self.seed, self.calls * 64, self.local_of, self.x,
+                                             counts_host=self._sizes[self.calls % 8])
+        return PendingBatch(self, pend, seeds.numel())
+
+    def _adopt(self, o: dict, batch_size: int) -> Batch:
+        from ..graph import GraphStructure
+        eb = o["eb"]
+        if self._slots is None or self._slots.numel() < eb:
+            cap, level = 0, batch_size
+            for f in self.fanouts:
+                level *= f
+                cap += level
+            self._slots = torch.arange(max(cap, eb), dtype=torch.int32, device=o["src"].device)
+        b = Batch(batch_size=batch_size, n_id=o["n_id64"], x=o["x"], edge_index=o["coo"], xe=o["type64"],
+                  node_text_feat=self.ntf, edge_text_feat=self.etf, cap_nodes=o["cap_nodes"])
+        b.graph = GraphStructure.from_csr(o["rowptr"], o["src"], o["coo"], o["nb"], etype_slot=o["type"],
                                           max_in_degree=self.batch_max_in_degree,
-                                          max_out_degree=self.batch_max_out_degree, active_rows=ab)
+                                          max_out_degree=self.batch_max_out_degree, active_rows=o["ab"],
+                                          eid=self._slots[:eb],
+                                          by_source=(o["rowptr_t"], o["dst_t"], o["eid_t"], o["type_t"], o["inv_deg"]))
         return b
+
+    def sample(self, seeds: Tensor) -> Batch:
+        return self.sample_async(seeds).result()
+
+
+class PendingBatch:
+    def __init__(self, sampler: HipNeighborSampler, pend, batch_size: int):
+        self.sampler, self.pend, self.batch_size = sampler, pend, batch_size
+
+    def result(self) -> Batch:
+        return self.sampler._adopt(self.pend.result(), self.batch_size)
 
 
 class NeighborLoader:
@@ -89,6 +118,11 @@ class NeighborLoader:
     def __iter__(self):
         for i in range(0, self.nodes.numel(), self.batch_size):
             yield self.sampler.sample(self.nodes[i:i + self.batch_size])
+
+    def iter_pending(self):
+        """The same batches as handles whose launches are enqueued (``result()`` -> Batch): see PrefetchLoader."""
+        for i in range(0, self.nodes.numel(), self.batch_size):
+            yield self.sampler.sample_async(self.nodes[i:i + self.batch_size])
 
 
 class MixLoader:
@@ -119,12 +153,20 @@ class MixLoader:
         for i in range(0, nodes.numel(), self.batch_size):
             yield self.sampler.sample(nodes[i:i + self.batch_size])
 
+    def iter_pending(self):
+        nodes = self._epoch_nodes()
+        self.epoch += 1
+        for i in range(0, nodes.numel(), self.batch_size):
+            yield self.sampler.sample_async(nodes[i:i + self.batch_size])
+
 
 class PrefetchLoader:
-    """Wraps a loader of device-resident batches (e.g. NeighborLoader over a HipNeighborSampler): batch i+1 is
-    sampled on a side HIP stream BEFORE the caller enqueues step i, so the sampler's launches and its one
-    device->host size read overlap the steps already queued on the current stream instead of holding them up.
-    ``prepare(batch)`` (optional) runs on the side stream too, e.g. the feature gather and the transposed CSR.
+    """Wraps a loader of device-resident batches (e.g. NeighborLoader over a HipNeighborSampler) and runs it on a side
+    HIP stream ahead of the consumer.  With a loader that offers ``iter_pending()`` the pipeline is two deep: while the
+    caller enqueues step i, batch i+1 is being prepared (its sizes, read on the host, arrived a step ago -- no wait) and
+    the sampler launches of batch i+2 are enqueued, so the host never blocks on the device and the sampler's kernels
+    overlap the steps already queued.  Without it, batch i+1 is sampled (one blocking size read) before step i is
+    enqueued.  ``prepare(batch)`` (optional) runs on the side stream too, e.g. the feature gather.
 
     ``uses`` names the batch attributes the consumer's kernels read (tensors or objects with ``record_stream``, like
     GraphStructure): they were allocated on the side stream, so they are handed to the current stream with
@@ -137,23 +179,40 @@ class PrefetchLoader:
     def __len__(self):
         return len(self.loader)
 
-    def _load(self, it):
+    def _launch(self, it):
         with torch.cuda.stream(self.side):
-            b = next(it, None)
-            if b is not None and self.prepare is not None:
+            return next(it, None)
+
+    def _finish(self, pending):
+        if pending is None:
+            return None
+        with torch.cuda.stream(self.side):
+            b = pending.result() if isinstance(pending, PendingBatch) else pending
+            if self.prepare is not None:
                 b = self.prepare(b) or b
+            b.ready = torch.cuda.Event()
+            b.ready.record(self.side)
             return b
 
     def __iter__(self):
-        it = iter(self.loader)
-        nxt = self._load(it)
+        pending_iter = getattr(self.loader, "iter_pending", None)
+        it = pending_iter() if pending_iter is not None else iter(self.loader)
+        nxt = self._finish(self._launch(it))
+        ahead = self._launch(it)  # launches in flight, sizes not read yet
         while nxt is not None:
             cur = nxt
             main = torch.cuda.current_stream(self.device)
-            main.wait_stream(self.side)
+            main.wait_event(cur.ready)
+            seen = set()  # one record per allocation: a sampler batch is views of one slab (+ the prepared features)
             for name in self.uses:
                 v = getattr(cur, name, None)
-                if v is not None and (not isinstance(v, Tensor) or v.is_cuda):
-                    v.record_stream(main)
-            nxt = self._load(it)  # before the caller's step: it overlaps the steps still queued on the device
+                if isinstance(v, Tensor):
+                    if v.is_cuda and v.untyped_storage().data_ptr() not in seen:
+                        seen.add(v.untyped_storage().data_ptr())
+                        v.record_stream(main)
+                elif v is not None:
+                    v.record_stream(main, seen)
+            # before the caller's step, so that all of it overlaps the steps still queued on the device
+            nxt = self._finish(ahead)
+            ahead = self._launch(it) if nxt is not None else None
             yield cur

@@ -106,8 +106,11 @@ class GraphStructure:
     def from_csr(cls, rowptr: Tensor, src: Tensor, edge_index: Tensor, num_nodes: int,
                  etype_slot: Optional[Tensor] = None, max_in_degree: Optional[int] = None,
                  max_out_degree: Optional[int] = None, active_rows: Optional[int] = None,
-                 validate: bool = False) -> "GraphStructure":
-        """Adopt a by-target CSR whose slot j IS edge j of `edge_index` (what the HIP sampler emits)."""
+                 validate: bool = False, eid: Optional[Tensor] = None, by_source=None) -> "GraphStructure":
+        """Adopt a by-target CSR whose slot j IS edge j of `edge_index` (what the HIP sampler emits).  ``eid``: the
+        identity slot -> edge map when the caller keeps one (else one is made); ``by_source`` = (rowptr_t, dst_t, eid_t,
+        etype_slot_t, inv_deg): the transposed view when the caller built it already (ensure_transpose is then a
+        no-op)."""
         g = cls(None, num_nodes)
         g.max_in_degree, g.max_out_degree = max_in_degree, max_out_degree
         if active_rows is not None and 0 <= active_rows < num_nodes:
@@ -117,11 +120,13 @@ class GraphStructure:
         g.num_edges = g.slot_capacity = int(src.numel())
         g._edge_index = edge_index
         g.rowptr, g.src = rowptr, src
-        g.eid = torch.arange(g.num_edges, dtype=torch.int32, device=src.device)
+        g.eid = torch.arange(g.num_edges, dtype=torch.int32, device=src.device) if eid is None else eid
         g._bad = None
         if etype_slot is not None:
             g._edge_type = etype_slot  # edge j == slot j
             g.etype_slot = etype_slot
+        if by_source is not None:
+            g.rowptr_t, g.dst_t, g.eid_t, g.etype_slot_t, g.inv_deg = by_source
         return g
 
     @property
@@ -175,12 +180,16 @@ class GraphStructure:
             setattr(self, attr, ops.SplitPlan(self.slot_capacity, self.rowptr.device))
         return getattr(self, attr)
 
-    def record_stream(self, stream) -> None:
+    def record_stream(self, stream, seen: Optional[set] = None) -> None:
         """Tell the caching allocator that `stream` uses this structure's tensors (built on another stream, e.g. by
-        a loader that samples one batch ahead)."""
+        a loader that samples one batch ahead).  ``seen``: storages already recorded by the caller."""
+        seen = set() if seen is None else seen  # a sampler batch keeps its arrays as views of one slab: one record
         for v in vars(self).values():
             if isinstance(v, Tensor) and v.is_cuda:
-                v.record_stream(stream)
+                key = v.untyped_storage().data_ptr()
+                if key not in seen:
+                    seen.add(key)
+                    v.record_stream(stream)
 
     def in_degree(self) -> Tensor:
         return (self.rowptr[1:] - self.rowptr[:-1]).long()

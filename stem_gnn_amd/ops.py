@@ -236,6 +236,90 @@ def sample_batch(rowptr: Tensor, src: Tensor, etype: Optional[Tensor], num_nodes
     return n_id[:nb], b_rowptr[:nb + 1], b_src[:eb], b_type[:eb], coo[:, :eb].contiguous(), nb, eb, ab
 
 
+class _SamplerPlan:
+    """Where every output of stemgnn_sample_batch_views lives inside ONE allocation, for a seed count and fan-outs (the
+    capacities depend on nothing else): byte offsets, 256-aligned, int64 parts first, the kernels' workspace last."""
+    _cache: dict = {}
+
+    def __init__(self, B: int, fanouts):
+        level, cn, ce = B, B, 0
+        for f in fanouts:
+            level *= int(f)
+            cn += level
+            ce += level
+        self.B, self.L, self.cn, self.ce = B, len(fanouts), cn, ce
+        self.fan = (ctypes.c_int32 * self.L)(*[int(f) for f in fanouts])
+        self.ws_bytes = int(lib.stemgnn_sampler_workspace_bytes(B, self.L, max(fanouts)))
+        self.off, at = {}, 0
+        for name, nbytes in (("coo", 16 * ce), ("n_id64", 8 * cn), ("x", 8 * cn), ("type64", 8 * ce), ("n_id", 4 * cn),
+                             ("rowptr", 4 * cn + 4), ("src", 4 * ce), ("type", 4 * ce), ("rowptr_t", 4 * cn + 4),
+                             ("dst_t", 4 * ce), ("eid_t", 4 * ce), ("type_t", 4 * ce), ("inv_deg", 4 * cn),
+                             ("ws", self.ws_bytes)):
+            self.off[name] = at
+            at += (nbytes + 255) // 256 * 256
+        self.total = at
+
+    @classmethod
+    def of(cls, B: int, fanouts) -> "_SamplerPlan":
+        key = (B, tuple(int(f) for f in fanouts))
+        plan = cls._cache.get(key)
+        if plan is None:
+            plan = cls._cache[key] = cls(B, fanouts)
+        return plan
+
+
+class PendingBatchViews:
+    """A batch whose sampler launches are enqueued and whose sizes are on their way to the host: ``result()`` waits for
+    the 12 bytes of sizes only (nothing to wait for when the batch was launched a step ahead) and cuts the views."""
+
+    def __init__(self, plan: _SamplerPlan, slab: Tensor, counts_host: Tensor, event):
+        self.plan, self.slab, self.counts_host, self.event = plan, slab, counts_host, event
+
+    def result(self) -> dict:
+        self.event.synchronize()
+        nb, eb, ab = self.counts_host.tolist()
+        p, off = self.plan, self.plan.off
+        s32, s64, f32 = self.slab.view(torch.int32), self.slab.view(torch.int64), self.slab.view(torch.float32)
+        i32 = lambda name, n: s32[off[name] >> 2:(off[name] >> 2) + n]
+        i64 = lambda name, n: s64[off[name] >> 3:(off[name] >> 3) + n]
+        return dict(nb=nb, eb=eb, ab=ab, cap_nodes=p.cn, cap_edges=p.ce, slab=self.slab, n_id=i32("n_id", nb),
+                    rowptr=i32("rowptr", nb + 1), src=i32("src", eb), type=i32("type", eb),
+                    coo=i64("coo", 2 * eb).view(2, eb), rowptr_t=i32("rowptr_t", nb + 1), dst_t=i32("dst_t", eb),
+                    eid_t=i32("eid_t", eb), type_t=i32("type_t", eb),
+                    inv_deg=f32[off["inv_deg"] >> 2:(off["inv_deg"] >> 2) + nb], n_id64=i64("n_id64", nb),
+                    x=i64("x", nb), type64=i64("type64", eb))
+
+
+def sample_batch_views_launch(rowptr: Tensor, src: Tensor, etype: Optional[Tensor], num_nodes: int, seeds: Tensor,
+                              fanouts, seed: int, offset: int, local_of: Tensor, x: Optional[Tensor] = None,
+                              counts_host: Optional[Tensor] = None) -> PendingBatchViews:
+    """sample_batch plus the by-source CSR, 1 / in-degree and the int64 forms of the batch (n_id, edge types, feature
+    rows x[n_id]) from the same ten-odd launches; ONE allocation holds every output and the kernels' workspace.  The
+    kernels write the sizes straight into ``counts_host`` (pinned int32 [3], device-accessible host memory); nothing
+    here waits for the device."""
+    _req(seeds, torch.int64, "seeds", 1)
+    if x is not None:
+        _req(x, torch.int64, "x", 1)
+    plan = _SamplerPlan.of(seeds.numel(), fanouts)
+    slab = torch.empty(plan.total, dtype=torch.uint8, device=seeds.device)
+    if counts_host is None:
+        counts_host = torch.empty(3, dtype=torch.int32, pin_memory=True)
+    base, off = slab.data_ptr(), plan.off
+    check(lib.stemgnn_sample_batch_views(
+        _p(rowptr), _p(src), _p(etype), num_nodes, _p(seeds), plan.B, plan.fan, plan.L, seed, offset, _p(local_of),
+        plan.cn, plan.ce, base + off["n_id"], base + off["rowptr"], base + off["src"], base + off["type"],
+        base + off["coo"], _p(counts_host), base + off["rowptr_t"], base + off["dst_t"], base + off["eid_t"],
+        base + off["type_t"], base + off["inv_deg"], base + off["n_id64"], base + off["type64"], _p(x), base + off["x"],
+        base + off["ws"], plan.ws_bytes, _stream()), "sample_batch_views")
+    event = torch.cuda.Event()
+    event.record()
+    return PendingBatchViews(plan, slab, counts_host, event)
+
+
+def sample_batch_views(*args, **kwargs) -> dict:
+    return sample_batch_views_launch(*args, **kwargs).result()
+
+
 def inv_degree(rowptr: Tensor) -> Tensor:
     _req(rowptr, torch.int32, "rowptr", 1)
     n = rowptr.numel() - 1
@@ -1350,13 +1434,16 @@ def set_gather_validation(flag: bool) -> None:
     _validate_gather = bool(flag)
 
 
-def gather_rows(table: Tensor, index: Tensor, validate: Optional[bool] = None) -> Tensor:
+def gather_rows(table: Tensor, index: Tensor, validate: Optional[bool] = None, capacity: int = 0) -> Tensor:
     """out[i] = table[index[i]] (device-side node_text_feat[x] of reference pretrain.py:33-38), in the table's dtype
     (fp32, or bf16 when the features are stored as bf16).  Out-of-range indices raise IndexError when validation is on
-    (the default); with validation off their rows read as zeros."""
+    (the default); with validation off their rows read as zeros.  ``capacity`` (rows): the result is the leading part
+    of an allocation of that many rows -- a loader whose batches differ slightly in size then asks the caching
+    allocator for the same block size every time (a request larger than any cached block goes to hipMalloc: ~8 ms)."""
     _req(table, table.dtype if table.dtype == torch.bfloat16 else torch.float32, "table", 2)
     _req(index, torch.int64, "index", 1)
-    out = torch.empty(index.numel(), table.size(1), dtype=table.dtype, device=table.device)
+    out = torch.empty(max(index.numel(), int(capacity)), table.size(1), dtype=table.dtype,
+                      device=table.device)[:index.numel()]
     check_range = _validate_gather if validate is None else validate
     bad = torch.empty(1, dtype=torch.int32, device=table.device) if check_range else None
     check(lib.stemgnn_gather_rows_k(_p(table), _kind(table), table.size(0), table.size(1), _p(index), index.numel(),

@@ -107,6 +107,13 @@ def test_sampler_contract_on_the_20m_edge_graph(dev, c4_graph):
     pos = torch.searchsorted(key_full, key_b).clamp(max=key_full.numel() - 1)
     assert bool((key_full[pos] == key_b).all())
     assert int((s.local_of != -2 ** 31).sum()) == 0
+    # the by-source view, 1 / in-degree and the int64 vectors the sampler emits == the ones derived from the COO
+    from stem_gnn_amd.graph import GraphStructure
+    ref = GraphStructure(b.edge_index.clone(), nb, b.graph.etype_slot.clone()).ensure_transpose()
+    for name in ("rowptr", "src", "rowptr_t", "dst_t", "eid_t", "etype_slot_t", "inv_deg"):
+        assert torch.equal(getattr(b.graph, name), getattr(ref, name)), name
+    assert int((b.graph.rowptr_t[1:] - b.graph.rowptr_t[:-1]).max()) > 1  # rows the segment sort had to order
+    assert torch.equal(b.x, g.x[b.n_id]) and torch.equal(b.xe, b.graph.etype_slot.long())
 
 
 def test_pretrain_step_on_a_real_c4_batch_matches_oracle(dev, c4_graph):

@@ -494,6 +494,44 @@ def test_edge_bce_loss(dev):
 
 
 # ---------------------------------------------------------------------------- neighbour sampler
+def _check_sampler_views(b, g, dev):
+    """What the sampler hands over beside the by-target CSR equals what the consumers used to derive from the COO: the
+    by-source CSR of a stable sort by source (rows in edge order), the types gathered through it, 1 / in-degree, and
+    the int64 id / type / feature-row vectors."""
+    from stem_gnn_amd import ops
+    from stem_gnn_amd.graph import GraphStructure
+    gs, nb = b.graph, b.n_id.numel()
+    assert b.edge_index.is_contiguous() and b.edge_index.dtype == torch.int64
+    ref = GraphStructure(b.edge_index.clone(), nb, gs.etype_slot.clone()).ensure_transpose()
+    for name in ("rowptr", "src", "rowptr_t", "dst_t", "eid_t", "etype_slot_t", "inv_deg"):
+        assert torch.equal(getattr(gs, name), getattr(ref, name)), name
+    assert torch.equal(gs.eid.long(), torch.arange(gs.num_edges, device=dev))
+    assert gs.ensure_transpose().rowptr_t is gs.rowptr_t  # nothing left to build
+    assert torch.equal(b.x, g.x[b.n_id]) and torch.equal(b.xe, gs.etype_slot.long())
+    assert b.n_id.dtype == torch.int64 and b.xe.dtype == torch.int64
+
+
+def test_sampler_plain_entry_point_gives_the_same_batch(dev):
+    """stemgnn_sample_batch (by-target CSR + COO with row stride cap_edges) and stemgnn_sample_batch_views draw the same
+    batch for the same (seed, offset)."""
+    from stem_gnn_amd import ops
+    from stem_gnn_amd.data.sampler import HipNeighborSampler
+    from stem_gnn_amd.data.synthetic import make_graph
+    g = make_graph(3000, 40000, 16, 4, kind="Z", device=dev, graph_seed=5)
+    for fan in ([4, 3], [6], [3, 2, 2]):
+        s = HipNeighborSampler(g.edge_index, g.xe, g.num_nodes, g.x, g.node_text_feat, g.edge_text_feat, fan, seed=3)
+        seeds = torch.randperm(g.num_nodes, device=dev)[:50]
+        seeds[7] = seeds[3]  # a duplicate seed keeps its first position
+        n_id, rowptr, src, etype, coo, nb, eb, ab = ops.sample_batch(s.rowptr, s.src, s.etype, s.num_nodes, seeds, fan,
+                                                                     s.seed, 64, s.local_of)
+        b = s.sample(seeds)  # first call: offset 64
+        assert (nb, eb, ab) == (b.n_id.numel(), b.edge_index.size(1), b.graph.active_rows if b.graph.active_rows is not None else nb)
+        assert torch.equal(n_id.long(), b.n_id) and torch.equal(rowptr, b.graph.rowptr) and torch.equal(src, b.graph.src)
+        assert torch.equal(etype, b.graph.etype_slot) and torch.equal(coo, b.edge_index)
+        _check_sampler_views(b, g, dev)
+        assert int((s.local_of != -2 ** 31).sum()) == 0
+
+
 @pytest.mark.parametrize("impl", ["hip", "torch"])
 def test_neighbor_sampler_contract(dev, impl):
     """NeighborLoader contract (reference pretrain.py:151-153): per hop each newly reached node
@@ -534,6 +572,7 @@ def test_neighbor_sampler_contract(dev, impl):
             assert torch.equal(gs.rowptr.cpu().long(), exp_rowptr)
             assert torch.equal(gs.src.cpu().long(), bei[0]) and torch.equal(gs.etype_slot.cpu().long(), bxe)
             assert bool((bei[1][1:] >= bei[1][:-1]).all())  # edge j == CSR slot j
+            _check_sampler_views(b, g, dev)
     # the scratch map is left clean and draws are uniform: over repeated draws of one high-degree
     # node every in-neighbour slot is picked with frequency ~ fanout / deg
     if impl == "hip":

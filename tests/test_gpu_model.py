@@ -506,6 +506,9 @@ def test_prefetch_loader_yields_the_same_batches(dev):
         assert torch.equal(n_id, n0) and torch.equal(ei, e0) and torch.equal(xe, x0)
         assert torch.equal(feat, g.node_text_feat[n_id])
         assert int(rpt[-1]) == ei.size(1)
+    # a loader without iter_pending() (any iterable of batches) takes the one-deep path
+    again = [b.n_id for b in PrefetchLoader(list(make_loader()), dev)]
+    assert len(again) == 8 and all(torch.equal(a, n0) for a, (n0, _, _) in zip(again, plain))
 
 
 def test_pretrain_step_on_sampler_batch_matches_oracle(dev):
