@@ -88,6 +88,18 @@ int stemgnn_graph_dropout_undirected(const int32_t* rowptr, const int32_t* src, 
                                      int32_t* a_rowptr, int32_t* a_src, int32_t* a_eid, int32_t* a_etype_slot,
                                      int32_t* a_dst_t, int32_t* a_eid_t, int32_t* a_etype_slot_t, float* a_inv_deg,
                                      void* workspace, size_t workspace_bytes, void* stream);
+/* The same for a graph whose rows >= active_rows have no in-edges (a neighbour-sampled batch: only the expanded nodes,
+ * which come first, receive edges).  A surviving edge has source <= target < active_rows, so only rows [0, active_rows)
+ * are examined; the other rows of the augmented views are empty.  active_rows < 0 or > num_nodes: every row.  Two
+ * launches (count + block totals scanned by the last block to finish; offsets + fill). */
+int stemgnn_graph_dropout_undirected_rows(const int32_t* rowptr, const int32_t* src, const int32_t* eid,
+                                          const int32_t* etype_slot, const int32_t* rowptr_t, const int32_t* dst_t,
+                                          const int32_t* eid_t, const int32_t* etype_slot_t, int64_t num_nodes,
+                                          int64_t num_edges, int64_t active_rows, float p, uint64_t seed,
+                                          uint64_t offset, const uint8_t* keep, int32_t* a_rowptr, int32_t* a_src,
+                                          int32_t* a_eid, int32_t* a_etype_slot, int32_t* a_dst_t, int32_t* a_eid_t,
+                                          int32_t* a_etype_slot_t, float* a_inv_deg, void* workspace,
+                                          size_t workspace_bytes, void* stream);
 
 /* randperm(n)[:k] as the reference uses it (model/pt_model.py:55-57,75-78, model/vq.py:1024): k
  * distinct ids of [0, n), the first k outputs of a keyed pseudo-random permutation (Feistel

@@ -76,6 +76,8 @@ _SIGNATURES = {
     "stemgnn_graph_dropout_workspace_bytes": (c_size_t, [I64]),
     "stemgnn_graph_dropout_undirected": (c_int, [P, P, P, P, P, P, P, P, I64, I64, c_float, c_uint64, c_uint64, P,
                                                  P, P, P, P, P, P, P, P, P, c_size_t, P]),
+    "stemgnn_graph_dropout_undirected_rows": (c_int, [P, P, P, P, P, P, P, P, I64, I64, I64, c_float, c_uint64, c_uint64,
+                                                      P, P, P, P, P, P, P, P, P, P, c_size_t, P]),
     "stemgnn_sample_subset": (c_int, [I64, I64, c_uint64, c_uint64, P, P]),
     "stemgnn_mask_columns": (c_int, [P, I64, I64, c_float, c_uint64, c_uint64, P, P]),
     "stemgnn_negative_sample": (c_int, [P, P, P, P, I64, I64, c_uint64, c_uint64, P, P]),

@@ -137,10 +137,13 @@ def graph_dropout_undirected(g, p: float, seed: int, offset: int, keep: Optional
             raise RuntimeError("keep: one flag per edge expected")
         keep_u8 = keep.to(torch.uint8).contiguous()
     ws = _workspace(lib.stemgnn_graph_dropout_workspace_bytes(N), dev)
-    check(lib.stemgnn_graph_dropout_undirected(
+    # rows >= active_rows have no in-edges, and a survivor has source <= target: only rows below it can keep an edge
+    active = -1 if g.active_rows is None else int(g.active_rows)
+    check(lib.stemgnn_graph_dropout_undirected_rows(
         _p(g.rowptr), _p(g.src), _p(g.eid), _p(g.etype_slot), _p(g.rowptr_t), _p(g.dst_t), _p(g.eid_t),
-        _p(g.etype_slot_t), N, E, float(p), seed, offset, _p(keep_u8), _p(a_rowptr), _p(a_src), _p(a_eid), _p(a_type),
-        _p(a_dst_t), _p(a_eid_t), _p(a_type_t), _p(inv_deg), _p(ws), ws.numel(), _stream()), "graph_dropout_undirected")
+        _p(g.etype_slot_t), N, E, active, float(p), seed, offset, _p(keep_u8), _p(a_rowptr), _p(a_src), _p(a_eid),
+        _p(a_type), _p(a_dst_t), _p(a_eid_t), _p(a_type_t), _p(inv_deg), _p(ws), ws.numel(), _stream()),
+        "graph_dropout_undirected")
     return a_rowptr, a_src, a_eid, a_type, a_dst_t, a_eid_t, a_type_t, inv_deg
 
 

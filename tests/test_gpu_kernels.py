@@ -425,7 +425,8 @@ def test_linear_fwd_bwd_and_stats(dev, m, k1, k2, n, bias):
 
 
 # ---------------------------------------------------------------------------- augmentation / sampling
-@pytest.mark.parametrize("n,e,p", [(1, 0, 0.2), (9, 30, 0.0), (50, 400, 0.2), (3000, 40000, 0.5), (100, 3000, 1.0)])
+@pytest.mark.parametrize("n,e,p", [(1, 0, 0.2), (9, 30, 0.0), (50, 400, 0.2), (3000, 40000, 0.5), (100, 3000, 1.0),
+                                   (256, 900, 0.1), (257, 900, 0.1), (70001, 200000, 0.3)])  # 1, 2 and 274 count blocks
 @pytest.mark.parametrize("typed", [False, True])
 def test_dropout_undirected_matches_pyg_semantics(dev, n, e, p, typed):
     """The fused CSR->CSR augmentation equals dropout_adj(force_undirected=True) restated in
@@ -458,6 +459,28 @@ def test_dropout_undirected_matches_pyg_semantics(dev, n, e, p, typed):
     # injected keep mask gives the same graph
     gb = g.dropout_undirected(p, keep=keep.to(dev))
     assert torch.equal(gb.rowptr, ga.rowptr) and torch.equal(gb.src[:live], ga.src[:live])
+
+
+def test_dropout_undirected_on_a_sampled_batch_examines_the_expanded_rows_only(dev):
+    """A sampler batch promises that rows >= active_rows have no in-edges; the augmentation then looks at the leading
+    rows only.  Same result as without the promise (every row examined), array for array."""
+    from stem_gnn_amd import ops
+    from stem_gnn_amd.data.sampler import HipNeighborSampler
+    from stem_gnn_amd.data.synthetic import make_graph
+    from stem_gnn_amd.graph import GraphStructure
+    g = make_graph(20000, 300000, 16, 4, kind="Z", device=dev, graph_seed=2)
+    s = HipNeighborSampler(g.edge_index, g.xe, g.num_nodes, g.x, g.node_text_feat, g.edge_text_feat, [6, 5], seed=1)
+    b = s.sample(torch.randperm(g.num_nodes, device=dev)[:300])
+    ga, nb = b.graph, b.n_id.numel()
+    assert ga.active_rows is not None and 300 < ga.active_rows < nb
+    plain = GraphStructure(b.edge_index.clone(), nb, ga.etype_slot.clone()).ensure_transpose()
+    assert plain.active_rows is None
+    keep = torch.rand(ga.num_edges, device=dev) > 0.25
+    a, c = ga.dropout_undirected(0.25, keep=keep), plain.dropout_undirected(0.25, keep=keep)
+    live = int(c.rowptr[-1])
+    assert live > 0 and torch.equal(a.rowptr, c.rowptr) and torch.equal(a.inv_deg, c.inv_deg)
+    for name in ("src", "eid", "etype_slot", "dst_t", "eid_t", "etype_slot_t"):
+        assert torch.equal(getattr(a, name)[:live], getattr(c, name)[:live]), name
 
 
 def test_negative_sample_properties(dev):
