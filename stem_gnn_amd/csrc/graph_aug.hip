@@ -72,15 +72,38 @@ k_aug_count(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src,
   const int64_t v = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
   int a = 0, b = 0;
   if (v < A) {
-    for (int s = rowptr[v]; s < rowptr[v + 1]; ++s) {
-      const int e = eid[s];
-      const bool k = keep_in ? keep_in[e] != 0 : keep_edge(seed, offset, p, e);
-      a += (k && src[s] <= v) ? 1 : 0;
+    // four slots of a row at a time, their loads in flight together (a one-at-a-time walk is a chain of latencies:
+    // the kernel took as long over 11k rows as over 102k)
+    const int s0 = rowptr[v], s1 = rowptr[v + 1], t0 = rowptr_t[v], t1 = rowptr_t[v + 1];
+    for (int s = s0; s < s1; s += 4) {
+      int e[4], u[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int ss = min(s + j, s1 - 1);
+        e[j] = eid[ss];
+        u[j] = src[ss];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (s + j < s1) {
+          const bool k = keep_in ? keep_in[e[j]] != 0 : keep_edge(seed, offset, p, e[j]);
+          a += (k && u[j] <= v) ? 1 : 0;
+        }
     }
-    for (int t = rowptr_t[v]; t < rowptr_t[v + 1]; ++t) {
-      const int e = eid_t[t];
-      const bool k = keep_in ? keep_in[e] != 0 : keep_edge(seed, offset, p, e);
-      b += (k && v <= dst_t[t]) ? 1 : 0;
+    for (int t = t0; t < t1; t += 4) {
+      int e[4], w[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int tt = min(t + j, t1 - 1);
+        e[j] = eid_t[tt];
+        w[j] = dst_t[tt];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (t + j < t1) {
+          const bool k = keep_in ? keep_in[e[j]] != 0 : keep_edge(seed, offset, p, e[j]);
+          b += (k && v <= w[j]) ? 1 : 0;
+        }
     }
     cnt_a[v] = a;
     deg[v] = a + b;
@@ -129,28 +152,49 @@ k_aug_fill(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src, 
   if (v >= A) return;
   const int na = cnt_a[v];
   int ia = 0, ib = 0;
-  // in-edges of v (u -> v, u <= v): first in the by-target list, second in the by-source list
-  for (int s = rowptr[v]; s < rowptr[v + 1]; ++s) {
-    const int e = eid[s], u = src[s];
-    const bool k = keep_in ? keep_in[e] != 0 : keep_edge(seed, offset, p, e);
-    if (k && u <= v) {
-      const int ty = etype_slot ? etype_slot[s] : 0;
-      const int pd = base + ia, ps = base + (d - na) + ia;
-      a_src[pd] = u; a_eid[pd] = e; if (a_type) a_type[pd] = ty;
-      a_dst_t[ps] = u; a_eid_t[ps] = e; if (a_type_t) a_type_t[ps] = ty;
-      ++ia;
+  // in-edges of v (u -> v, u <= v): first in the by-target list, second in the by-source list; four slots at a time
+  const int s0 = rowptr[v], s1 = rowptr[v + 1], t0 = rowptr_t[v], t1 = rowptr_t[v + 1];
+  for (int s = s0; s < s1; s += 4) {
+    int e[4], u[4], ty[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ss = min(s + j, s1 - 1);
+      e[j] = eid[ss];
+      u[j] = src[ss];
+      ty[j] = etype_slot ? etype_slot[ss] : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (s + j >= s1) break;
+      const bool k = keep_in ? keep_in[e[j]] != 0 : keep_edge(seed, offset, p, e[j]);
+      if (k && u[j] <= v) {
+        const int pd = base + ia, ps = base + (d - na) + ia;
+        a_src[pd] = u[j]; a_eid[pd] = e[j]; if (a_type) a_type[pd] = ty[j];
+        a_dst_t[ps] = u[j]; a_eid_t[ps] = e[j]; if (a_type_t) a_type_t[ps] = ty[j];
+        ++ia;
+      }
     }
   }
   // out-edges of v (v -> w, v <= w): second in the by-target list, first in the by-source list
-  for (int t = rowptr_t[v]; t < rowptr_t[v + 1]; ++t) {
-    const int e = eid_t[t], w = dst_t[t];
-    const bool k = keep_in ? keep_in[e] != 0 : keep_edge(seed, offset, p, e);
-    if (k && v <= w) {
-      const int ty = etype_slot_t ? etype_slot_t[t] : 0;
-      const int pd = base + na + ib, ps = base + ib;
-      a_src[pd] = w; a_eid[pd] = e; if (a_type) a_type[pd] = ty;
-      a_dst_t[ps] = w; a_eid_t[ps] = e; if (a_type_t) a_type_t[ps] = ty;
-      ++ib;
+  for (int t = t0; t < t1; t += 4) {
+    int e[4], w[4], ty[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int tt = min(t + j, t1 - 1);
+      e[j] = eid_t[tt];
+      w[j] = dst_t[tt];
+      ty[j] = etype_slot_t ? etype_slot_t[tt] : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (t + j >= t1) break;
+      const bool k = keep_in ? keep_in[e[j]] != 0 : keep_edge(seed, offset, p, e[j]);
+      if (k && v <= w[j]) {
+        const int pd = base + na + ib, ps = base + ib;
+        a_src[pd] = w[j]; a_eid[pd] = e[j]; if (a_type) a_type[pd] = ty[j];
+        a_dst_t[ps] = w[j]; a_eid_t[ps] = e[j]; if (a_type_t) a_type_t[ps] = ty[j];
+        ++ib;
+      }
     }
   }
 }

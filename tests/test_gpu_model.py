@@ -334,6 +334,30 @@ def test_encoder_fwd_bwd_vs_oracle(dev, attr):
         torch.testing.assert_close(ge(x.to(dev), ei.to(dev), ea_gpu).cpu(), oe(x, ei, ea_cpu), rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("N", [2048 * 3 + 77, 78_336 + 40])
+def test_encoder_batchnorm_statistics_at_many_row_tiles(dev, N):
+    """BatchNorm statistics gathered from the layer product's column-sum slabs at sizes with many row tiles and, at
+    78 376 rows, a second launch of 32-row tail tiles writing into the same slab array (csrc/linear.hip plan_fwd).
+    Output, running statistics and the batch counter against the CPU oracle, over two consecutive forwards."""
+    from stem_gnn_amd import ops
+    D, L, E = 128, 2, 3 * N
+    om, gm = make_models(D, L, 4, 64, D, dev)
+    torch.manual_seed(11)
+    x = torch.randn(N, D) * (1 + torch.arange(D) / 32.0) + torch.arange(D) / 64.0  # per-column scale and offset
+    ei = torch.randint(0, N, (2, E))
+    oe, ge = om.encoder, gm.encoder
+    oe.train(); ge.train()
+    for rep in range(2):
+        with torch.no_grad():
+            zg = ge(x.to(dev), ei.to(dev), None)
+            masks = [ops.dropout_keep_mask(N * D, 0.15, s, o, dev).view(N, D).cpu() for (s, o) in ge.last_dropout_keys]
+            zr = oe(x, ei, None, dropout_masks=masks)
+        torch.testing.assert_close(zg.cpu(), zr, rtol=1e-4, atol=1e-4)
+        for (n1, b1), (n2, b2) in zip(oe.named_buffers(), ge.named_buffers()):
+            assert n1 == n2
+            torch.testing.assert_close(b2.cpu().float(), b1.float(), rtol=1e-5, atol=1e-6, msg=lambda m: f"{n1}: {m}")
+
+
 @pytest.mark.parametrize("D,H,K,attr", [(768, 4, 128, "table"), (96, 2, 40, "dense"), (128, 4, 512, "table"),
                                         (256, 4, 2048, "table")])
 def test_pretrain_step_other_widths(dev, D, H, K, attr):
