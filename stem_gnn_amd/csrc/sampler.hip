@@ -148,17 +148,27 @@ __device__ inline void emit_role(const HopBuf& hb, const EmitOut& o, const Batch
   const int c = hb.s_cnt[i];
   const int base = ctr->edges[hb.hop] + hb.edge_base[i];
   o.b_rowptr[f0 + i] = base;
-  for (int j = 0; j < c; ++j) {
-    const int slot = base + j;
-    if (slot >= o.cap_edges) break;
-    const int64_t p = static_cast<int64_t>(i) * hb.fanout + j;
-    const int32_t ls = local_of[hb.s_src[p]];
-    const int32_t ty = hb.s_type[p];
-    o.b_src[slot] = ls;
-    o.b_type[slot] = ty;
-    if (o.b_type64) o.b_type64[slot] = ty;
-    o.b_dst[slot] = f0 + i;
-    if (o.deg_out) atomicAdd(&o.deg_out[ls], 1);
+  const int64_t p0 = static_cast<int64_t>(i) * hb.fanout;
+  for (int j0 = 0; j0 < c; j0 += 4) {  // four entries at a time: their two dependent reads each overlap
+    int32_t g[4], ty[4], ls[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int j = min(j0 + k, c - 1);
+      g[k] = hb.s_src[p0 + j];
+      ty[k] = hb.s_type[p0 + j];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ls[k] = local_of[g[k]];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int slot = base + j0 + k;
+      if (j0 + k >= c || slot >= o.cap_edges) break;
+      o.b_src[slot] = ls[k];
+      o.b_type[slot] = ty[k];
+      if (o.b_type64) o.b_type64[slot] = ty[k];
+      o.b_dst[slot] = f0 + i;
+      if (o.deg_out) atomicAdd(&o.deg_out[ls[k]], 1);
+    }
   }
 }
 
@@ -214,9 +224,10 @@ k_count_wins(HopBuf hb, const BatchCounters* __restrict__ ctr, int32_t B, const 
 }
 
 // ONE block: exclusive scans of a[0, n) -> a_out (and of b -> b_out when given), n = *n_hi - *n_lo read on the device.
-// Chunks of 4096 elements: four consecutive elements per thread (a wave reads 1 KB contiguous), wave scan by shuffles,
-// the 16 wave totals through LDS.  tot_a[0] = base_a[0] + sum(a) (likewise b); closing: a_out[n] = sum(a).
-constexpr int kScanThreads = 1024;
+// Chunks of kScanThreads * kScanPer elements: consecutive elements per thread (16 ints = four 16-byte loads, all in
+// flight before the first is used), wave scan by shuffles, the 16 wave totals through LDS.  tot_a[0] = base_a[0] +
+// sum(a) (likewise b); closing: a_out[n] = sum(a).
+constexpr int kScanThreads = 1024, kScanPer = 16;
 __global__ void __launch_bounds__(kScanThreads)
 k_scan_block(const int32_t* __restrict__ a, int32_t* __restrict__ a_out, const int32_t* __restrict__ b,
              int32_t* __restrict__ b_out, const int32_t* __restrict__ n_hi, const int32_t* __restrict__ n_lo,
@@ -228,15 +239,21 @@ k_scan_block(const int32_t* __restrict__ a, int32_t* __restrict__ a_out, const i
   if (n < 0) n = 0;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   int32_t ca = 0, cb = 0;  // running totals of the chunks before this one (the same in every thread)
-  for (int base = 0; base < n; base += kScanThreads * 4) {
-    const int i0 = base + t * 4;
-    int32_t va[4], vb[4];
+  for (int base = 0; base < n; base += kScanThreads * kScanPer) {
+    // a short input (a hop's frontier) is spread over all threads instead of filling the first few
+    const int left = n - base;
+    const int per = left >= kScanThreads * kScanPer ? kScanPer : (left + kScanThreads - 1) / kScanThreads;
+    const int i0 = base + t * per;
+    int32_t va[kScanPer], vb[kScanPer];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      va[k] = i0 + k < n ? a[i0 + k] : 0;
-      vb[k] = (b && i0 + k < n) ? b[i0 + k] : 0;
+    for (int k = 0; k < kScanPer; ++k) {
+      const bool in = k < per && i0 + k < n;
+      va[k] = in ? a[i0 + k] : 0;
+      vb[k] = (b && in) ? b[i0 + k] : 0;
     }
-    const int32_t sa = va[0] + va[1] + va[2] + va[3], sb = vb[0] + vb[1] + vb[2] + vb[3];
+    int32_t sa = 0, sb = 0;
+#pragma unroll
+    for (int k = 0; k < kScanPer; ++k) { sa += va[k]; sb += vb[k]; }
     int32_t ia = sa, ib = sb;  // inclusive over the wave
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -254,8 +271,8 @@ k_scan_block(const int32_t* __restrict__ a, int32_t* __restrict__ a_out, const i
     }
     int32_t ea = ca + oa + ia - sa, eb = cb + ob + ib - sb;
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (i0 + k < n) {
+    for (int k = 0; k < kScanPer; ++k)
+      if (k < per && i0 + k < n) {
         a_out[i0 + k] = ea; ea += va[k];
         if (b) { b_out[i0 + k] = eb; eb += vb[k]; }
       }
