@@ -49,6 +49,39 @@ def test_host_side_argument_validation_needs_no_gpu(L):
     assert lib.stemgnn_linear_bwd_weight_workspace_bytes(100000, 128, 128) >= 128 * 128 * 4
 
 
+def test_sampler_argument_validation_and_output_plan(L):
+    """The sampler's host-side checks (fan-out range, capacities, workspace size) and the layout ops.sample_batch_views
+    carves its ONE allocation into: 256-byte aligned, disjoint parts big enough for every output at the batch's
+    capacity, the kernels' workspace last."""
+    lib = L.lib
+    from stem_gnn_amd.ops import _SamplerPlan
+    one = ctypes.c_void_p(8)  # any non-null pointer: validation fails before it would be touched
+    fan = (ctypes.c_int32 * 2)(10, 10)
+    args = lambda cn, ce, ws: (one, one, None, 100, one, 4, fan, 2, 1, 2, one, cn, ce, one, one, one, one, one, one, one, ws, None)
+    need = lib.stemgnn_sampler_workspace_bytes(4, 2, 10)
+    assert need > 0 and lib.stemgnn_sampler_workspace_bytes(4, 2, 33) == 0 and lib.stemgnn_sampler_workspace_bytes(0, 2, 10) == 0
+    assert lib.stemgnn_sample_batch(*args(443, 440, need)) == -3        # cap_nodes < 4 * (1 + 10 + 100)
+    assert lib.stemgnn_sample_batch(*args(444, 439, need)) == -3        # cap_edges < 4 * (10 + 100)
+    assert lib.stemgnn_sample_batch(*args(444, 440, need - 1)) == -3    # workspace one byte short
+    bad = (ctypes.c_int32 * 2)(10, 0)
+    assert lib.stemgnn_sample_batch(one, one, None, 100, one, 4, bad, 2, 1, 2, one, 444, 440, one, one, one, one, one,
+                                    one, one, need, None) == -1         # fan-out 0
+    assert lib.stemgnn_sample_batch_views(*args(444, 440, need)[:19], None, one, one, one, one, None, None, None, None,
+                                          one, need, None) == -1        # by-source arrays are not optional
+    assert lib.stemgnn_graph_dropout_undirected_rows(None, None, None, None, None, None, None, None, -1, 0, 0, 0.2, 1, 2,
+                                                     None, one, None, None, None, None, None, None, None, None, 0,
+                                                     None) == -1
+    plan = _SamplerPlan.of(1024, [10, 10])
+    assert (plan.cn, plan.ce) == (1024 * 111, 1024 * 110) and plan.ws_bytes == lib.stemgnn_sampler_workspace_bytes(1024, 2, 10)
+    want = dict(coo=16 * plan.ce, n_id64=8 * plan.cn, x=8 * plan.cn, type64=8 * plan.ce, n_id=4 * plan.cn,
+                rowptr=4 * plan.cn + 4, src=4 * plan.ce, type=4 * plan.ce, rowptr_t=4 * plan.cn + 4, dst_t=4 * plan.ce,
+                eid_t=4 * plan.ce, type_t=4 * plan.ce, inv_deg=4 * plan.cn, ws=plan.ws_bytes)
+    spans = sorted((plan.off[k], plan.off[k] + n) for k, n in want.items())
+    assert set(plan.off) == set(want) and all(a % 256 == 0 for a, _ in spans)
+    assert all(e0 <= b1 for (_, e0), (b1, _) in zip(spans, spans[1:])) and spans[-1][1] <= plan.total
+    assert _SamplerPlan.of(1024, (10, 10)) is plan  # cached per (seeds, fan-outs)
+
+
 def test_ops_refuse_cpu_tensors():
     from stem_gnn_amd import ops
     with pytest.raises(RuntimeError, match="no CPU path"):
