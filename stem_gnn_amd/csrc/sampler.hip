@@ -224,60 +224,79 @@ k_count_wins(HopBuf hb, const BatchCounters* __restrict__ ctr, int32_t B, const 
 }
 
 // ONE block: exclusive scans of a[0, n) -> a_out (and of b -> b_out when given), n = *n_hi - *n_lo read on the device.
-// Chunks of kScanThreads * kScanPer elements: consecutive elements per thread (16 ints = four 16-byte loads, all in
-// flight before the first is used), wave scan by shuffles, the 16 wave totals through LDS.  tot_a[0] = base_a[0] +
-// sum(a) (likewise b); closing: a_out[n] = sum(a).
-constexpr int kScanThreads = 1024, kScanPer = 16;
+// Rounds of kScanGroups * 4096 elements: a thread takes four consecutive elements (one 16-byte load: a wave reads 1 KB
+// in a piece) of each of the round's groups, all loads in flight together; the groups are scanned side by side (wave
+// scans by shuffles, one exchange of the 16 x kScanGroups wave totals through LDS, two barriers per round).
+// (A thread taking 16 consecutive elements -- 64-byte stride between lanes -- made every load instruction touch 64
+// cache lines: 85 us for the 102k out-degrees of a C4 batch.)  tot_a[0] = base_a[0] + sum(a) (likewise b); closing:
+// a_out[n] = sum(a).
+constexpr int kScanThreads = 1024, kScanGroups = 4, kScanGroupElems = kScanThreads * 4;
+// `al`: the array starts on a 16-byte boundary (the library's own buffers do; a caller's output array need not)
+__device__ __forceinline__ int4 scan_load4(const int32_t* __restrict__ p, int i, int n, bool al) {
+  if (al && i + 3 < n) return *reinterpret_cast<const int4*>(p + i);
+  return make_int4(i < n ? p[i] : 0, i + 1 < n ? p[i + 1] : 0, i + 2 < n ? p[i + 2] : 0, i + 3 < n ? p[i + 3] : 0);
+}
+__device__ __forceinline__ void scan_store4(int32_t* __restrict__ p, int i, int n, int32_t e, int4 v, bool al) {
+  const int4 o = make_int4(e, e + v.x, e + v.x + v.y, e + v.x + v.y + v.z);
+  if (al && i + 3 < n) { *reinterpret_cast<int4*>(p + i) = o; return; }
+  if (i < n) p[i] = o.x;
+  if (i + 1 < n) p[i + 1] = o.y;
+  if (i + 2 < n) p[i + 2] = o.z;
+  if (i + 3 < n) p[i + 3] = o.w;
+}
 __global__ void __launch_bounds__(kScanThreads)
 k_scan_block(const int32_t* __restrict__ a, int32_t* __restrict__ a_out, const int32_t* __restrict__ b,
              int32_t* __restrict__ b_out, const int32_t* __restrict__ n_hi, const int32_t* __restrict__ n_lo,
              int32_t n_cap, int32_t* __restrict__ tot_a, const int32_t* __restrict__ base_a, int32_t* __restrict__ tot_b,
              const int32_t* __restrict__ base_b, bool closing) {
-  __shared__ int32_t wa[kScanThreads / 64], wb[kScanThreads / 64];
+  __shared__ int32_t wa[kScanGroups][kScanThreads / 64], wb[kScanGroups][kScanThreads / 64];
   int n = n_hi[0] - n_lo[0];
   if (n > n_cap) n = n_cap;
   if (n < 0) n = 0;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  int32_t ca = 0, cb = 0;  // running totals of the chunks before this one (the same in every thread)
-  for (int base = 0; base < n; base += kScanThreads * kScanPer) {
-    // a short input (a hop's frontier) is spread over all threads instead of filling the first few
-    const int left = n - base;
-    const int per = left >= kScanThreads * kScanPer ? kScanPer : (left + kScanThreads - 1) / kScanThreads;
-    const int i0 = base + t * per;
-    int32_t va[kScanPer], vb[kScanPer];
+  const auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  const bool al_a = al16(a), al_b = al16(b), al_ao = al16(a_out), al_bo = al16(b_out);
+  int32_t ca = 0, cb = 0;  // running totals of the rounds before this one (the same in every thread)
+  for (int base = 0; base < n; base += kScanGroups * kScanGroupElems) {
+    int4 va[kScanGroups], vb[kScanGroups];
 #pragma unroll
-    for (int k = 0; k < kScanPer; ++k) {
-      const bool in = k < per && i0 + k < n;
-      va[k] = in ? a[i0 + k] : 0;
-      vb[k] = (b && in) ? b[i0 + k] : 0;
+    for (int g = 0; g < kScanGroups; ++g) {
+      const int i = base + g * kScanGroupElems + 4 * t;
+      va[g] = scan_load4(a, i, n, al_a);
+      vb[g] = b ? scan_load4(b, i, n, al_b) : make_int4(0, 0, 0, 0);
     }
-    int32_t sa = 0, sb = 0;
+    int32_t sa[kScanGroups], sb[kScanGroups], ia[kScanGroups], ib[kScanGroups];
 #pragma unroll
-    for (int k = 0; k < kScanPer; ++k) { sa += va[k]; sb += vb[k]; }
-    int32_t ia = sa, ib = sb;  // inclusive over the wave
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int32_t x = __shfl_up(ia, o), y = __shfl_up(ib, o);
-      if (lane >= o) { ia += x; ib += y; }
+    for (int g = 0; g < kScanGroups; ++g) {
+      ia[g] = sa[g] = va[g].x + va[g].y + va[g].z + va[g].w;
+      ib[g] = sb[g] = vb[g].x + vb[g].y + vb[g].z + vb[g].w;
     }
-    if (lane == 63) { wa[w] = ia; wb[w] = ib; }
-    __syncthreads();
-    int32_t oa = 0, ob = 0, ta = 0, tb = 0;
 #pragma unroll
-    for (int k = 0; k < kScanThreads / 64; ++k) {
-      const int32_t x = wa[k], y = wb[k];
-      if (k < w) { oa += x; ob += y; }
-      ta += x; tb += y;
-    }
-    int32_t ea = ca + oa + ia - sa, eb = cb + ob + ib - sb;
+    for (int o = 1; o < 64; o <<= 1)
 #pragma unroll
-    for (int k = 0; k < kScanPer; ++k)
-      if (k < per && i0 + k < n) {
-        a_out[i0 + k] = ea; ea += va[k];
-        if (b) { b_out[i0 + k] = eb; eb += vb[k]; }
+      for (int g = 0; g < kScanGroups; ++g) {  // inclusive over the wave, the groups' chains interleaved
+        const int32_t x = __shfl_up(ia[g], o), y = __shfl_up(ib[g], o);
+        if (lane >= o) { ia[g] += x; ib[g] += y; }
       }
-    ca += ta; cb += tb;
-    __syncthreads();  // wa / wb are rewritten by the next chunk
+    if (lane == 63)
+#pragma unroll
+      for (int g = 0; g < kScanGroups; ++g) { wa[g][w] = ia[g]; wb[g][w] = ib[g]; }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < kScanGroups; ++g) {
+      int32_t oa = 0, ob = 0, ta = 0, tb = 0;
+#pragma unroll
+      for (int k = 0; k < kScanThreads / 64; ++k) {
+        const int32_t x = wa[g][k], y = wb[g][k];
+        if (k < w) { oa += x; ob += y; }
+        ta += x; tb += y;
+      }
+      const int i = base + g * kScanGroupElems + 4 * t;
+      scan_store4(a_out, i, n, ca + oa + ia[g] - sa[g], va[g], al_ao);
+      if (b) scan_store4(b_out, i, n, cb + ob + ib[g] - sb[g], vb[g], al_bo);
+      ca += ta; cb += tb;  // the next group starts behind this one
+    }
+    __syncthreads();  // wa / wb are rewritten by the next round
   }
   if (t == 0) {
     if (tot_a) tot_a[0] = (base_a ? base_a[0] : 0) + ca;

@@ -553,6 +553,31 @@ def test_sampler_plain_entry_point_gives_the_same_batch(dev):
         assert torch.equal(etype, b.graph.etype_slot) and torch.equal(coo, b.edge_index)
         _check_sampler_views(b, g, dev)
         assert int((s.local_of != -2 ** 31).sum()) == 0
+    # a caller's output arrays need not start on 16-byte boundaries (the scans take 16-byte loads where they may)
+    import ctypes
+    from stem_gnn_amd._lib import lib, check
+    fan = [4, 3]
+    s = HipNeighborSampler(g.edge_index, g.xe, g.num_nodes, g.x, g.node_text_feat, g.edge_text_feat, fan, seed=3)
+    seeds = torch.randperm(g.num_nodes, device=dev)[:50]
+    ref = s.sample(seeds)
+    cn, ce = 50 * (1 + 4 + 12), 50 * (4 + 12)
+    i32 = lambda n: torch.empty(n + 1, dtype=torch.int32, device=dev)[1:]  # 4 bytes past an aligned start
+    n_id, rp, src, ty, rpt, dst_t, eid_t, ty_t = i32(cn), i32(cn + 1), i32(ce), i32(ce), i32(cn + 1), i32(ce), i32(ce), i32(ce)
+    inv = torch.empty(cn + 1, dtype=torch.float32, device=dev)[1:]
+    coo = torch.empty(2 * ce, dtype=torch.int64, device=dev)
+    counts = torch.empty(3, dtype=torch.int32, device=dev)
+    ws = torch.empty(int(lib.stemgnn_sampler_workspace_bytes(50, 2, 4)), dtype=torch.uint8, device=dev)
+    check(lib.stemgnn_sample_batch_views(
+        s.rowptr.data_ptr(), s.src.data_ptr(), s.etype.data_ptr(), s.num_nodes, seeds.data_ptr(), 50,
+        (ctypes.c_int32 * 2)(*fan), 2, s.seed, 64, s.local_of.data_ptr(), cn, ce, n_id.data_ptr(), rp.data_ptr(),
+        src.data_ptr(), ty.data_ptr(), coo.data_ptr(), counts.data_ptr(), rpt.data_ptr(), dst_t.data_ptr(),
+        eid_t.data_ptr(), ty_t.data_ptr(), inv.data_ptr(), None, None, None, None, ws.data_ptr(), ws.numel(),
+        torch.cuda.current_stream().cuda_stream), "sample_batch_views")
+    nb, eb, _ = counts.tolist()
+    assert (nb, eb) == (ref.n_id.numel(), ref.edge_index.size(1))
+    assert torch.equal(rp[:nb + 1], ref.graph.rowptr) and torch.equal(rpt[:nb + 1], ref.graph.rowptr_t)
+    assert torch.equal(dst_t[:eb], ref.graph.dst_t) and torch.equal(eid_t[:eb], ref.graph.eid_t)
+    assert torch.equal(coo[:2 * eb].view(2, eb), ref.edge_index) and torch.equal(inv[:nb], ref.graph.inv_deg)
 
 
 @pytest.mark.parametrize("impl", ["hip", "torch"])
