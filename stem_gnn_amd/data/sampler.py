@@ -42,8 +42,9 @@ class HipNeighborSampler:
         self.num_nodes = num_nodes
         self.fanouts = [int(f) for f in num_neighbors]
         rowptr, src, eid, _ = ops.csr_build(edge_index.contiguous(), num_nodes, 1)
-        self.rowptr, self.src = rowptr, src
-        self.etype = ops.gather_i32(xe.to(torch.int32).contiguous(), eid)
+        # a graph without edges still gets a one-slot array: the library takes a null source array for a bad argument
+        self.rowptr, self.src = rowptr, (src if src.numel() else torch.zeros(1, dtype=torch.int32, device=src.device))
+        self.etype = ops.gather_i32(xe.to(torch.int32).contiguous(), eid) if eid.numel() else None
         self.x, self.ntf, self.etf = x.contiguous(), node_text_feat, edge_text_feat
         self._slots = None  # identity slot -> edge map, shared by every batch (slices of one arange)
         self._sizes = None  # pinned landing zone of the batches' sizes

@@ -461,6 +461,33 @@ def test_dropout_undirected_matches_pyg_semantics(dev, n, e, p, typed):
     assert torch.equal(gb.rowptr, ga.rowptr) and torch.equal(gb.src[:live], ga.src[:live])
 
 
+def test_sampler_and_augmentation_on_graphs_without_edges(dev):
+    """Seeds whose nodes have no in-edges: the batch is the seeds alone, both CSR views are empty, nothing is expanded
+    (active_rows = 0 of B rows -> the augmentation's count launch is skipped), and the step-side helpers accept it."""
+    from stem_gnn_amd.data.sampler import HipNeighborSampler
+    n, d = 300, 16
+    ei = torch.zeros(2, 0, dtype=torch.int64, device=dev)
+    xe = torch.zeros(0, dtype=torch.int64, device=dev)
+    feat = torch.randn(n, d, device=dev)
+    s = HipNeighborSampler(ei, xe, n, torch.arange(n, device=dev), feat, torch.randn(1, d, device=dev), [4, 3], seed=2)
+    seeds = torch.tensor([5, 17, 5, 299], device=dev)
+    b = s.sample(seeds)
+    assert torch.equal(b.n_id, seeds) and tuple(b.edge_index.shape) == (2, 0) and b.xe.numel() == 0
+    g = b.graph
+    assert g.num_nodes == 4 and g.num_edges == 0 and g.active_rows in (None, 0, 4)
+    assert torch.equal(g.rowptr, torch.zeros(5, dtype=torch.int32, device=dev)) and torch.equal(g.rowptr_t, g.rowptr)
+    assert torch.equal(g.inv_deg, torch.ones(4, device=dev))
+    a = g.dropout_undirected(0.3)
+    assert int(a.rowptr[-1]) == 0 and torch.equal(a.rowptr, g.rowptr) and torch.equal(a.inv_deg, g.inv_deg)
+    assert int((s.local_of != -2 ** 31).sum()) == 0
+    # ... and a graph whose only edges leave the seeds (nothing points at them): same batch
+    ei2 = torch.stack([torch.tensor([5, 17, 299], device=dev), torch.tensor([1, 2, 3], device=dev)])
+    s2 = HipNeighborSampler(ei2, torch.zeros(3, dtype=torch.int64, device=dev), n, torch.arange(n, device=dev), feat,
+                            torch.randn(1, d, device=dev), [4, 3], seed=2)
+    b2 = s2.sample(seeds)
+    assert torch.equal(b2.n_id, seeds) and b2.edge_index.size(1) == 0
+
+
 def test_dropout_undirected_on_a_sampled_batch_examines_the_expanded_rows_only(dev):
     """A sampler batch promises that rows >= active_rows have no in-edges; the augmentation then looks at the leading
     rows only.  Same result as without the promise (every row examined), array for array."""
