@@ -58,6 +58,11 @@ __device__ inline int block_exclusive_scan(int x, int& total) {
   return before + inc - x;
 }
 
+// Both launches give a row to FOUR neighbouring lanes (lane j takes slots j, j + 4, ... of the row's two lists): a row
+// walked by one thread is a chain of ~20 dependent reads and as many Philox blocks -- 11-14 us whether 11k or 102k rows
+// were walked.  A block covers kRows = 64 rows.
+constexpr int kRowLanes = 4, kRows = kThreads / kRowLanes;
+
 // Launch 1 of 2: the survivors per node (rows [0, A): only those can keep an edge, see the entry point), each block's
 // total, and -- by whichever block finishes last (common.h: ticket_last) -- the exclusive scan of the block totals and
 // the grand total.  Launch 2 redoes the scan inside its block from the per-node counts.  This replaces count + a
@@ -69,47 +74,32 @@ k_aug_count(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src,
             const uint8_t* __restrict__ keep_in, int32_t* __restrict__ cnt_a, int32_t* __restrict__ deg,
             int32_t* __restrict__ block_sum, int32_t* __restrict__ block_off, int32_t* __restrict__ total_out,
             unsigned int* __restrict__ counter) {
-  const int64_t v = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+  const int sub = threadIdx.x & (kRowLanes - 1);
+  const int64_t v = static_cast<int64_t>(blockIdx.x) * kRows + (threadIdx.x >> 2);
   int a = 0, b = 0;
   if (v < A) {
-    // four slots of a row at a time, their loads in flight together (a one-at-a-time walk is a chain of latencies:
-    // the kernel took as long over 11k rows as over 102k)
-    const int s0 = rowptr[v], s1 = rowptr[v + 1], t0 = rowptr_t[v], t1 = rowptr_t[v + 1];
-    for (int s = s0; s < s1; s += 4) {
-      int e[4], u[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int ss = min(s + j, s1 - 1);
-        e[j] = eid[ss];
-        u[j] = src[ss];
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (s + j < s1) {
-          const bool k = keep_in ? keep_in[e[j]] != 0 : keep_edge(seed, offset, p, e[j]);
-          a += (k && u[j] <= v) ? 1 : 0;
-        }
+    const int s1 = rowptr[v + 1], t1 = rowptr_t[v + 1];
+    for (int s = rowptr[v] + sub; s < s1; s += kRowLanes) {
+      const int e = eid[s];
+      const bool k = keep_in ? keep_in[e] != 0 : keep_edge(seed, offset, p, e);
+      a += (k && src[s] <= v) ? 1 : 0;
     }
-    for (int t = t0; t < t1; t += 4) {
-      int e[4], w[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int tt = min(t + j, t1 - 1);
-        e[j] = eid_t[tt];
-        w[j] = dst_t[tt];
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (t + j < t1) {
-          const bool k = keep_in ? keep_in[e[j]] != 0 : keep_edge(seed, offset, p, e[j]);
-          b += (k && v <= w[j]) ? 1 : 0;
-        }
+    for (int t = rowptr_t[v] + sub; t < t1; t += kRowLanes) {
+      const int e = eid_t[t];
+      const bool k = keep_in ? keep_in[e] != 0 : keep_edge(seed, offset, p, e);
+      b += (k && v <= dst_t[t]) ? 1 : 0;
     }
+  }
+  a += __shfl_xor(a, 1);
+  a += __shfl_xor(a, 2);
+  b += __shfl_xor(b, 1);
+  b += __shfl_xor(b, 2);
+  if (v < A && sub == 0) {
     cnt_a[v] = a;
     deg[v] = a + b;
   }
   int total;
-  (void)block_exclusive_scan(a + b, total);
+  (void)block_exclusive_scan(sub == 0 ? a + b : 0, total);
   if (threadIdx.x == 0) {
     st_agent(&block_sum[blockIdx.x], total);
     wait_stores();
@@ -129,7 +119,8 @@ k_aug_count(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src,
 }
 
 // Launch 2 of 2, over ALL N nodes: row offsets (rows >= A are empty: they close at the total), 1 / degree, and the
-// survivors of rows < A written to both augmented views.
+// survivors of rows < A written to both augmented views.  The four lanes of a row look at four consecutive slots at a
+// time; a survivor's position is the row's running count + the survivors among the lanes before it (one ballot).
 __global__ void __launch_bounds__(kThreads)
 k_aug_fill(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src, const int32_t* __restrict__ eid,
            const int32_t* __restrict__ etype_slot, const int32_t* __restrict__ rowptr_t,
@@ -140,62 +131,60 @@ k_aug_fill(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src, 
            int32_t* __restrict__ a_src, int32_t* __restrict__ a_eid, int32_t* __restrict__ a_type,
            int32_t* __restrict__ a_dst_t, int32_t* __restrict__ a_eid_t, int32_t* __restrict__ a_type_t,
            float* __restrict__ inv_deg) {
-  const int64_t v = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
-  const int64_t block0 = static_cast<int64_t>(blockIdx.x) * kThreads;
+  const int lane = threadIdx.x & 63, sub = threadIdx.x & (kRowLanes - 1), shift = lane & ~(kRowLanes - 1);
+  const int64_t block0 = static_cast<int64_t>(blockIdx.x) * kRows;
+  const int64_t v = block0 + (threadIdx.x >> 2);
   const int d = v < A ? deg[v] : 0;
   int block_total;
-  const int ex = block_exclusive_scan(d, block_total);
-  if (v >= N) return;
-  const int base = (block0 < A ? block_off[blockIdx.x] : arowptr[N]) + ex;
-  arowptr[v] = base;
-  inv_deg[v] = 1.0f / static_cast<float>(d < 1 ? 1 : d);
-  if (v >= A) return;
-  const int na = cnt_a[v];
-  int ia = 0, ib = 0;
-  // in-edges of v (u -> v, u <= v): first in the by-target list, second in the by-source list; four slots at a time
-  const int s0 = rowptr[v], s1 = rowptr[v + 1], t0 = rowptr_t[v], t1 = rowptr_t[v + 1];
-  for (int s = s0; s < s1; s += 4) {
-    int e[4], u[4], ty[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int ss = min(s + j, s1 - 1);
-      e[j] = eid[ss];
-      u[j] = src[ss];
-      ty[j] = etype_slot ? etype_slot[ss] : 0;
+  const int ex = block_exclusive_scan(sub == 0 ? d : 0, block_total);  // lane 0 of the row holds the row's offset
+  const int base = (block0 < A ? block_off[blockIdx.x] : arowptr[N]) + __shfl(ex, shift);
+  if (v < N && sub == 0) {
+    arowptr[v] = base;
+    inv_deg[v] = 1.0f / static_cast<float>(d < 1 ? 1 : d);
+  }
+  const bool live = v < A;
+  const int na = live ? cnt_a[v] : 0;
+  const int s0 = live ? rowptr[v] : 0, s1 = live ? rowptr[v + 1] : 0;
+  const int t0 = live ? rowptr_t[v] : 0, t1 = live ? rowptr_t[v + 1] : 0;
+  // in-edges of v (u -> v, u <= v): first in the by-target list, second in the by-source list
+  int ia = 0;
+  for (int s = s0 + sub; __any(s - sub < s1); s += kRowLanes) {
+    int e = 0, u = 0, ty = 0;
+    bool f = false;
+    if (s < s1) {
+      e = eid[s];
+      u = src[s];
+      ty = etype_slot ? etype_slot[s] : 0;
+      f = (keep_in ? keep_in[e] != 0 : keep_edge(seed, offset, p, e)) && u <= v;
     }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (s + j >= s1) break;
-      const bool k = keep_in ? keep_in[e[j]] != 0 : keep_edge(seed, offset, p, e[j]);
-      if (k && u[j] <= v) {
-        const int pd = base + ia, ps = base + (d - na) + ia;
-        a_src[pd] = u[j]; a_eid[pd] = e[j]; if (a_type) a_type[pd] = ty[j];
-        a_dst_t[ps] = u[j]; a_eid_t[ps] = e[j]; if (a_type_t) a_type_t[ps] = ty[j];
-        ++ia;
-      }
+    const unsigned four = static_cast<unsigned>(__ballot(f) >> shift) & 15u;
+    if (f) {
+      const int q = ia + __popc(four & ((1u << sub) - 1u));
+      const int pd = base + q, ps = base + (d - na) + q;
+      a_src[pd] = u; a_eid[pd] = e; if (a_type) a_type[pd] = ty;
+      a_dst_t[ps] = u; a_eid_t[ps] = e; if (a_type_t) a_type_t[ps] = ty;
     }
+    ia += __popc(four);
   }
   // out-edges of v (v -> w, v <= w): second in the by-target list, first in the by-source list
-  for (int t = t0; t < t1; t += 4) {
-    int e[4], w[4], ty[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int tt = min(t + j, t1 - 1);
-      e[j] = eid_t[tt];
-      w[j] = dst_t[tt];
-      ty[j] = etype_slot_t ? etype_slot_t[tt] : 0;
+  int ib = 0;
+  for (int t = t0 + sub; __any(t - sub < t1); t += kRowLanes) {
+    int e = 0, w = 0, ty = 0;
+    bool f = false;
+    if (t < t1) {
+      e = eid_t[t];
+      w = dst_t[t];
+      ty = etype_slot_t ? etype_slot_t[t] : 0;
+      f = (keep_in ? keep_in[e] != 0 : keep_edge(seed, offset, p, e)) && v <= w;
     }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (t + j >= t1) break;
-      const bool k = keep_in ? keep_in[e[j]] != 0 : keep_edge(seed, offset, p, e[j]);
-      if (k && v <= w[j]) {
-        const int pd = base + na + ib, ps = base + ib;
-        a_src[pd] = w[j]; a_eid[pd] = e[j]; if (a_type) a_type[pd] = ty[j];
-        a_dst_t[ps] = w[j]; a_eid_t[ps] = e[j]; if (a_type_t) a_type_t[ps] = ty[j];
-        ++ib;
-      }
+    const unsigned four = static_cast<unsigned>(__ballot(f) >> shift) & 15u;
+    if (f) {
+      const int q = ib + __popc(four & ((1u << sub) - 1u));
+      const int pd = base + na + q, ps = base + q;
+      a_src[pd] = w; a_eid[pd] = e; if (a_type) a_type[pd] = ty;
+      a_dst_t[ps] = w; a_eid_t[ps] = e; if (a_type_t) a_type_t[ps] = ty;
     }
+    ib += __popc(four);
   }
 }
 
@@ -381,7 +370,7 @@ extern "C" {
 
 size_t stemgnn_graph_dropout_workspace_bytes(int64_t N) {
   if (N < 0) return 0;
-  const size_t blocks = static_cast<size_t>((N + kThreads - 1) / kThreads) + 1;
+  const size_t blocks = static_cast<size_t>((N + kRows - 1) / kRows) + 1;
   return 2 * align_up(static_cast<size_t>(N + 1) * sizeof(int32_t), 256) + 2 * align_up(blocks * sizeof(int32_t), 256) + 512;
 }
 
@@ -408,7 +397,7 @@ int stemgnn_graph_dropout_undirected_rows(const int32_t* rowptr, const int32_t* 
   const int64_t A = (active_rows < 0 || active_rows > N) ? N : active_rows;
   uintptr_t base = align_up(reinterpret_cast<uintptr_t>(workspace), 256);
   const size_t arr = align_up(static_cast<size_t>(N + 1) * sizeof(int32_t), 256);
-  const size_t blocks = static_cast<size_t>((N + kThreads - 1) / kThreads) + 1;
+  const size_t blocks = static_cast<size_t>((N + kRows - 1) / kRows) + 1;
   int32_t* cnt_a = reinterpret_cast<int32_t*>(base);
   int32_t* deg = reinterpret_cast<int32_t*>(base + arr);
   int32_t* block_sum = reinterpret_cast<int32_t*>(base + 2 * arr);
@@ -416,14 +405,14 @@ int stemgnn_graph_dropout_undirected_rows(const int32_t* rowptr, const int32_t* 
   if (A > 0) {
     unsigned int* counter = ticket_counter(st);
     if (!counter) return STEMGNN_ERR_HIP;
-    k_aug_count<<<static_cast<unsigned>((A + kThreads - 1) / kThreads), kThreads, 0, st>>>(
+    k_aug_count<<<static_cast<unsigned>((A + kRows - 1) / kRows), kThreads, 0, st>>>(
         rowptr, src, eid, rowptr_t, dst_t, eid_t, A, p, seed, offset, keep, cnt_a, deg, block_sum, block_off, a_rowptr + N,
         counter);
     STEMGNN_LAUNCH_CHECK();
   } else {
     STEMGNN_HIP_TRY(hipMemsetAsync(a_rowptr + N, 0, sizeof(int32_t), st));
   }
-  k_aug_fill<<<static_cast<unsigned>((N + kThreads - 1) / kThreads), kThreads, 0, st>>>(
+  k_aug_fill<<<static_cast<unsigned>((N + kRows - 1) / kRows), kThreads, 0, st>>>(
       rowptr, src, eid, etype_slot, rowptr_t, dst_t, eid_t, etype_slot_t, N, A, p, seed, offset, keep, cnt_a, deg, block_off,
       a_rowptr, a_src, a_eid, etype_slot ? a_etype_slot : nullptr, a_dst_t, a_eid_t, etype_slot ? a_etype_slot_t : nullptr,
       a_inv_deg);
