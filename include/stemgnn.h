@@ -161,8 +161,10 @@ int stemgnn_sample_batch(const int32_t* rowptr, const int32_t* src, const int32_
  * x_out[i] = x[n_id[i]] (x = the dataset's node -> feature-row table, int64 [num_nodes]; NULL: x_out = n_id).
  * Here b_coo is written as a CONTIGUOUS [2, E_b] (row stride E_b, not cap_edges), and `counts` is only ever written
  * (by one thread of the last-but-one launch): it may be device-accessible pinned host memory (hipHostMalloc), which
- * saves the size copy -- the caller then waits for an event recorded behind the call instead.  n_id64 / type64 / x_out may each
- * be NULL. */
+ * saves the size copy -- the caller then waits for an event recorded behind the call instead.  n_id64 / type64 /
+ * x_out may each be NULL.  rowptr_t / dst_t / eid_t / type_t may ALL be NULL: no by-source view is built (its per-row
+ * ordering pass is quadratic in a row's length: callers skip it for graphs whose out-degrees are not small and sort
+ * the COO instead, stemgnn_csr_build). */
 int stemgnn_sample_batch_views(const int32_t* rowptr, const int32_t* src, const int32_t* etype, int64_t num_nodes,
                                const int64_t* seeds, int64_t batch_size, const int32_t* fanouts_host, int64_t hops,
                                uint64_t seed, uint64_t offset, int32_t* local_of, int64_t cap_nodes, int64_t cap_edges,
@@ -170,6 +172,39 @@ int stemgnn_sample_batch_views(const int32_t* rowptr, const int32_t* src, const 
                                int32_t* counts, int32_t* rowptr_t, int32_t* dst_t, int32_t* eid_t, int32_t* type_t,
                                float* inv_deg, int64_t* n_id64, int64_t* type64, const int64_t* x, int64_t* x_out,
                                void* workspace, size_t workspace_bytes, void* stream);
+
+/* Fan-out -1 (every in-neighbour: the reference's evaluation loaders, utils/loader.py:18-25, finetune.py:237) or any
+ * per-hop mix of -1 and positive fan-outs.  A hop's entries are as many as its frontier's in-degrees add up to, so the
+ * batch is built in steps and the HOST reads one size per hop:
+ *   begin(seeds)  ->  per hop h: hop_sizes (entries per frontier node, their exclusive scan, *total)  -> the caller
+ *   allocates s_src / s_type [total] and makes sure n_id holds n_cap >= nodes so far + min(total, num_nodes) entries  ->
+ *   hop_expand (copy / sample the entries, number the new nodes; *nodes_after, if given, = nodes known now)  ->  after
+ *   the last hop the caller reads state[hops + 1] = N_b and state[16 + hops] = E_b, allocates the outputs at exactly
+ *   those sizes  ->  finish (by-target CSR, contiguous COO [2, E_b], 1 / in-degree, the int64 vectors; the scratch map
+ *   is left clean; no by-source view: an evaluation batch has no backward).
+ * state: 32 int32 on the device, owned by the caller for the duration of the batch.  frontier_cap: an upper bound of the
+ * hop's frontier (hop 0: batch_size; then min(previous total, num_nodes)).  cnt / ent_base / wins / new_base:
+ * [frontier_cap] int32 each; the arrays given to hop_expand are handed to finish again (host arrays of device
+ * pointers, one per hop).  total / nodes_after / counts may be device-accessible pinned host memory. */
+int stemgnn_sampler_full_begin(const int64_t* seeds, int64_t batch_size, int64_t num_nodes, int32_t* local_of,
+                               int32_t* n_id, int32_t* state, void* stream);
+int stemgnn_sampler_full_hop_sizes(const int32_t* rowptr, const int32_t* n_id, int32_t* state, int32_t hop,
+                                   int32_t fanout, int64_t frontier_cap, int32_t* cnt, int32_t* ent_base,
+                                   int32_t* total, void* stream);
+int stemgnn_sampler_full_hop_expand(const int32_t* rowptr, const int32_t* src, const int32_t* etype, int32_t* n_id,
+                                    int64_t n_cap, int32_t* state, int32_t hop, int32_t fanout, uint64_t seed,
+                                    uint64_t offset, int64_t batch_size, int64_t frontier_cap, int64_t entries,
+                                    int32_t* cnt, const int32_t* ent_base, int32_t* s_src, int32_t* s_type,
+                                    int32_t* wins, int32_t* new_base, int32_t* local_of, int32_t* nodes_after,
+                                    void* stream);
+size_t stemgnn_sampler_full_finish_workspace_bytes(int64_t num_batch_edges);
+int stemgnn_sampler_full_finish(int32_t* state, int32_t hops, const int32_t* fanouts_host,
+                                const int64_t* frontier_caps_host, int32_t* const* cnt_h, int32_t* const* ent_base_h,
+                                int32_t* const* s_src_h, int32_t* const* s_type_h, int32_t* local_of, const int32_t* n_id,
+                                int64_t num_batch_nodes, int64_t num_batch_edges, int32_t* b_rowptr, int32_t* b_src,
+                                int32_t* b_type, int64_t* b_coo, float* inv_deg, int64_t* n_id64, int64_t* type64,
+                                const int64_t* x, int64_t* x_out, int32_t* counts, void* workspace,
+                                size_t workspace_bytes, void* stream);
 
 /* out[i] = table[index[i]] for int32 tables (edge-type id per CSR slot = xe[eid[slot]]). */
 int stemgnn_gather_i32(const int32_t* table, const int32_t* index, int64_t n, int32_t* out, void* stream);

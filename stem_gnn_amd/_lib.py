@@ -89,6 +89,13 @@ _SIGNATURES = {
     "stemgnn_sampler_workspace_bytes": (c_size_t, [I64, I64, I64]),
     "stemgnn_sample_batch": (c_int, [P, P, P, I64, P, I64, P, I64, c_uint64, c_uint64, P, I64, I64, P, P, P, P, P, P, P,
                                      c_size_t, P]),
+    "stemgnn_sampler_full_begin": (c_int, [P, I64, I64, P, P, P, P]),
+    "stemgnn_sampler_full_hop_sizes": (c_int, [P, P, P, I32, I32, I64, P, P, P, P]),
+    "stemgnn_sampler_full_hop_expand": (c_int, [P, P, P, P, I64, P, I32, I32, c_uint64, c_uint64, I64, I64, I64, P,
+                                                P, P, P, P, P, P, P, P]),
+    "stemgnn_sampler_full_finish_workspace_bytes": (c_size_t, [I64]),
+    "stemgnn_sampler_full_finish": (c_int, [P, I32, P, P, P, P, P, P, P, P, I64, I64, P, P, P, P, P, P, P, P, P, P, P,
+                                            c_size_t, P]),
     "stemgnn_sample_batch_views": (c_int, [P, P, P, I64, P, I64, P, I64, c_uint64, c_uint64, P, I64, I64, P, P, P, P, P, P,
                                            P, P, P, P, P, P, P, P, P, P, c_size_t, P]),
     "stemgnn_gather_i32": (c_int, [P, P, I64, P, P]),

@@ -6,11 +6,12 @@
 // WITHOUT replacement (Floyd's algorithm on a Philox stream), the subgraph keeps every sampled
 // edge (neighbour -> node), local numbering puts the seeds first, then new nodes hop by hop in
 // order of first appearance.  The full graph's by-target CSR (int32) stays resident in HBM; a
-// batch costs a dozen small launches and ONE 12-byte device->host copy (its node / edge counts).
+// batch costs 13 small launches (two hops); its sizes (12 bytes) are the only thing the host reads.
 // Because the sampler walks targets in local order, it emits the batch's by-target CSR directly
 // (no sort); edge j of the batch is slot j of that CSR.
 //
-// Round 3: 21 launches (of which 8 inside four rocPRIM scans over the hop's ENTRIES) -> 11 for two hops.  Per hop:
+// Round 3: 21 launches (of which 8 inside four rocPRIM scans over the hop's ENTRIES) -> 13 for two hops, by-source
+// view included.  Per hop:
 //   sample + claim (one thread per frontier node; fused with the PREVIOUS hop's edge emission, whose inputs it does
 //   not touch) -> wins per frontier node -> ONE single-block scan over the frontier NODES (new-node offsets and edge
 //   offsets at once: a tenth of the entries) -> assign the new local ids -> emit the hop's edges.
@@ -59,9 +60,8 @@ __device__ inline int sample_row(const int32_t* __restrict__ rowptr, const int32
                                  const int32_t* __restrict__ etype, int32_t v, int fanout, uint64_t seed, uint64_t offset,
                                  int i, int32_t* __restrict__ s_src, int32_t* __restrict__ s_type, int64_t out0) {
   const int beg = rowptr[v], deg = rowptr[v + 1] - beg;
-  if (fanout < 0 || deg <= fanout) {  // the whole row (capped at the widest fan-out the buffers hold)
-    int c = deg < kMaxFanout ? deg : kMaxFanout;
-    if (fanout >= 0 && c > fanout) c = fanout;
+  if (fanout < 0 || deg <= fanout) {  // the whole row (fan-out -1: every in-neighbour; the caller sized the entries)
+    const int c = deg;
     for (int j = 0; j < c; ++j) {
       s_src[out0 + j] = src[beg + j];
       s_type[out0 + j] = etype ? etype[beg + j] : 0;
@@ -124,9 +124,13 @@ __device__ inline int sample_row(const int32_t* __restrict__ rowptr, const int32
   return c;
 }
 
-// One hop's scratch: the sampled entries of its frontier nodes (entry p = i * fanout + j) and the per-node offsets
+// One hop's scratch: the sampled entries of its frontier nodes (entry p = entry0(i) + j) and the per-node offsets
+__device__ __forceinline__ int64_t entry0(const int32_t* __restrict__ ent_base, int i, int fanout) {
+  return ent_base ? static_cast<int64_t>(ent_base[i]) : static_cast<int64_t>(i) * fanout;
+}
 struct HopBuf {
   int32_t *s_src, *s_type, *s_cnt;  // [cap * fanout] global ids / edge types, [cap] counts
+  const int32_t* ent_base;          // first entry of frontier node i (sized-per-hop path); NULL: i * fanout
   int32_t *wins, *new_base, *edge_base;  // [cap]: new nodes a frontier node wins, and the exclusive scans
   int32_t cap;                           // frontier capacity of the hop
   int32_t fanout, hop;
@@ -148,7 +152,7 @@ __device__ inline void emit_role(const HopBuf& hb, const EmitOut& o, const Batch
   const int c = hb.s_cnt[i];
   const int base = ctr->edges[hb.hop] + hb.edge_base[i];
   o.b_rowptr[f0 + i] = base;
-  const int64_t p0 = static_cast<int64_t>(i) * hb.fanout;
+  const int64_t p0 = entry0(hb.ent_base, i, hb.fanout);
   for (int j0 = 0; j0 < c; j0 += 4) {  // four entries at a time: their two dependent reads each overlap
     int32_t g[4], ty[4], ls[4];
 #pragma unroll
@@ -181,7 +185,7 @@ __device__ inline void sample_role(const HopBuf& hb, const int32_t* __restrict__
   if (i >= hb.cap) return;
   const int f0 = ctr->nodes[hb.hop], f1 = ctr->nodes[hb.hop + 1];
   if (i >= f1 - f0) { hb.s_cnt[i] = 0; return; }
-  const int64_t out0 = static_cast<int64_t>(i) * hb.fanout;
+  const int64_t out0 = entry0(hb.ent_base, i, hb.fanout);
   const int c = sample_row(rowptr, src, etype, n_id[f0 + i], hb.fanout, seed, offset, i, hb.s_src, hb.s_type, out0);
   hb.s_cnt[i] = c;
   for (int j = 0; j < c; ++j) {
@@ -217,7 +221,7 @@ k_count_wins(HopBuf hb, const BatchCounters* __restrict__ ctr, int32_t B, const 
   int w = 0;
   if (i < nf) {
     const int c = hb.s_cnt[i];
-    const int32_t p0 = i * hb.fanout;
+    const int32_t p0 = static_cast<int32_t>(entry0(hb.ent_base, i, hb.fanout));
     for (int j = 0; j < c; ++j) w += local_of[hb.s_src[p0 + j]] == -(p0 + j + 2) ? 1 : 0;
   }
   hb.wins[i] = w;
@@ -229,7 +233,7 @@ k_count_wins(HopBuf hb, const BatchCounters* __restrict__ ctr, int32_t B, const 
 // scans by shuffles, one exchange of the 16 x kScanGroups wave totals through LDS, two barriers per round).
 // (A thread taking 16 consecutive elements -- 64-byte stride between lanes -- made every load instruction touch 64
 // cache lines: 85 us for the 102k out-degrees of a C4 batch.)  tot_a[0] = base_a[0] + sum(a) (likewise b); closing:
-// a_out[n] = sum(a).
+// a_out[n] = sum(a).  b_out may be NULL (only b's total is wanted).
 constexpr int kScanThreads = 1024, kScanGroups = 4, kScanGroupElems = kScanThreads * 4;
 // `al`: the array starts on a 16-byte boundary (the library's own buffers do; a caller's output array need not)
 __device__ __forceinline__ int4 scan_load4(const int32_t* __restrict__ p, int i, int n, bool al) {
@@ -293,7 +297,7 @@ k_scan_block(const int32_t* __restrict__ a, int32_t* __restrict__ a_out, const i
       }
       const int i = base + g * kScanGroupElems + 4 * t;
       scan_store4(a_out, i, n, ca + oa + ia[g] - sa[g], va[g], al_ao);
-      if (b) scan_store4(b_out, i, n, cb + ob + ib[g] - sb[g], vb[g], al_bo);
+      if (b && b_out) scan_store4(b_out, i, n, cb + ob + ib[g] - sb[g], vb[g], al_bo);
       ca += ta; cb += tb;  // the next group starts behind this one
     }
     __syncthreads();  // wa / wb are rewritten by the next round
@@ -308,14 +312,16 @@ k_scan_block(const int32_t* __restrict__ a, int32_t* __restrict__ a_out, const i
 // New local ids: the winners of frontier node i, in slot order, from nodes[hop + 1] + new_base[i]
 __global__ void __launch_bounds__(kThreads)
 k_assign_new(HopBuf hb, int32_t cap_nodes, const BatchCounters* __restrict__ ctr, int32_t* __restrict__ local_of,
-             int32_t* __restrict__ n_id, int32_t* __restrict__ deg_out, int32_t* __restrict__ cursor) {
+             int32_t* __restrict__ n_id, int32_t* __restrict__ deg_out, int32_t* __restrict__ cursor,
+             int32_t* __restrict__ nodes_after /* may be NULL or pinned host memory */) {
   const int i = blockIdx.x * kThreads + threadIdx.x;
+  if (i == 0 && nodes_after) nodes_after[0] = ctr->nodes[hb.hop + 2];
   if (i >= hb.cap) return;
   const int nf = ctr->nodes[hb.hop + 1] - ctr->nodes[hb.hop];
   if (i >= nf) return;
   int id = ctr->nodes[hb.hop + 1] + hb.new_base[i];
   const int c = hb.s_cnt[i];
-  const int32_t p0 = i * hb.fanout;
+  const int32_t p0 = static_cast<int32_t>(entry0(hb.ent_base, i, hb.fanout));
   for (int j = 0; j < c; ++j) {
     const int32_t g = hb.s_src[p0 + j];
     if (local_of[g] == -(p0 + j + 2)) {
@@ -450,6 +456,7 @@ int sample_impl(const int32_t* rowptr, const int32_t* src, const int32_t* etype,
     buf[k].wins = carve(cp.cap_frontier_max * 4);
     buf[k].new_base = carve(cp.cap_frontier_max * 4);
     buf[k].edge_base = carve(cp.cap_frontier_max * 4);
+    buf[k].ent_base = nullptr;
   }
   // local ids never reach need_nodes (every frontier node adds at most its fan-out), whatever cap_nodes the caller holds
   int32_t* deg_out = carve(static_cast<size_t>(cp.need_nodes) * 4);
@@ -494,7 +501,7 @@ int sample_impl(const int32_t* rowptr, const int32_t* src, const int32_t* etype,
                                              ctr->edges + hop + 1, ctr->edges + hop, false);
     STEMGNN_LAUNCH_CHECK();
     k_assign_new<<<grid_for(h.cap), kThreads, 0, st>>>(h, static_cast<int32_t>(cap_nodes), ctr, local_of, n_id,
-                                                       want_view ? deg_out : nullptr, want_view ? cursor : nullptr);
+                                                       want_view ? deg_out : nullptr, want_view ? cursor : nullptr, nullptr);
     STEMGNN_LAUNCH_CHECK();
     cap_frontier *= fanouts_host[hop];
   }
@@ -505,7 +512,6 @@ int sample_impl(const int32_t* rowptr, const int32_t* src, const int32_t* etype,
     STEMGNN_LAUNCH_CHECK();
   }
   view.cursor = cursor;
-  view.compact_coo = want_view;
   if (!want_view) view.rowptr_t = view.dst_t = view.eid_t = view.type_t = nullptr;
   k_finish<<<grid_for(std::max<int64_t>(cap_edges, cap_nodes + 1)), kThreads, 0, st>>>(
       static_cast<int>(hops), ctr, static_cast<int32_t>(cap_nodes), static_cast<int32_t>(cap_edges), n_id, local_of,
@@ -518,6 +524,22 @@ int sample_impl(const int32_t* rowptr, const int32_t* src, const int32_t* etype,
     STEMGNN_LAUNCH_CHECK();
   }
   return STEMGNN_OK;
+}
+
+// Entries per frontier node of a hop: min(deg, fanout), or deg for fanout < 0 (every in-neighbour)
+__global__ void __launch_bounds__(kThreads)
+k_hop_counts(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ n_id, const BatchCounters* __restrict__ ctr,
+             int hop, int fanout, int32_t cap, int32_t* __restrict__ s_cnt) {
+  const int i = blockIdx.x * kThreads + threadIdx.x;
+  if (i >= cap) return;
+  const int f0 = ctr->nodes[hop], nf = ctr->nodes[hop + 1] - f0;
+  int c = 0;
+  if (i < nf) {
+    const int32_t v = n_id[f0 + i];
+    const int deg = rowptr[v + 1] - rowptr[v];
+    c = (fanout < 0 || deg <= fanout) ? deg : fanout;
+  }
+  s_cnt[i] = c;
 }
 
 }  // namespace
@@ -566,11 +588,121 @@ int stemgnn_sample_batch_views(const int32_t* rowptr, const int32_t* src, const 
                                int32_t* counts, int32_t* rowptr_t, int32_t* dst_t, int32_t* eid_t, int32_t* type_t,
                                float* inv_deg, int64_t* n_id64, int64_t* type64, const int64_t* x, int64_t* x_out,
                                void* workspace, size_t workspace_bytes, void* stream_) {
-  if (!rowptr_t || !dst_t || !eid_t || !type_t || !inv_deg) return STEMGNN_ERR_INVALID_ARG;
+  const bool want_view = rowptr_t || dst_t || eid_t || type_t;  // all four or none
+  if (!inv_deg || (want_view && (!rowptr_t || !dst_t || !eid_t || !type_t))) return STEMGNN_ERR_INVALID_ARG;
   ViewOut v{rowptr_t, dst_t, eid_t, type_t, nullptr, true, inv_deg, n_id64, x_out, x};
   return sample_impl(rowptr, src, etype, num_nodes, seeds, batch_size, fanouts_host, hops, seed, offset, local_of,
-                     cap_nodes, cap_edges, n_id, b_rowptr, b_src, b_type, type64, b_coo, counts, v, true, workspace,
+                     cap_nodes, cap_edges, n_id, b_rowptr, b_src, b_type, type64, b_coo, counts, v, want_view, workspace,
                      workspace_bytes, static_cast<hipStream_t>(stream_));
+}
+
+// ---- fan-out -1 (every in-neighbour; reference utils/loader.py:18-25, finetune.py:237: the evaluation loaders) -------
+// The entries of a hop are as many as its frontier's in-degrees add up to: no bound is known before the hop runs.  The
+// batch is therefore built in steps, with one 4-byte size read by the host per hop (entries) -- an evaluation path, not
+// the training loop's: begin -> per hop [sizes -> (host allocates the hop's entries) -> expand] -> (host allocates the
+// outputs at their exact size) -> finish.  Same kernels, same numbering as stemgnn_sample_batch; the entries of frontier
+// node i start at the exclusive scan of the counts instead of at i * fanout.  `state`: 32 int32 on the device.
+
+int stemgnn_sampler_full_begin(const int64_t* seeds, int64_t batch_size, int64_t num_nodes, int32_t* local_of,
+                               int32_t* n_id, int32_t* state, void* stream_) {
+  if (batch_size <= 0 || !seeds || !local_of || !n_id || !state) return STEMGNN_ERR_INVALID_ARG;
+  if (!fits_i32(num_nodes) || !fits_i32(batch_size)) return STEMGNN_ERR_TOO_LARGE;
+  const int32_t B = static_cast<int32_t>(batch_size);
+  k_seed_init<<<grid_for(B), kThreads, 0, static_cast<hipStream_t>(stream_)>>>(
+      seeds, B, num_nodes, local_of, n_id, reinterpret_cast<BatchCounters*>(state), nullptr, nullptr);
+  STEMGNN_LAUNCH_CHECK();
+  return STEMGNN_OK;
+}
+
+int stemgnn_sampler_full_hop_sizes(const int32_t* rowptr, const int32_t* n_id, int32_t* state, int32_t hop,
+                                   int32_t fanout, int64_t frontier_cap, int32_t* cnt, int32_t* ent_base,
+                                   int32_t* total, void* stream_) {
+  if (!rowptr || !n_id || !state || !cnt || !ent_base || !total || hop < 0 || hop > 13 || frontier_cap <= 0 ||
+      fanout == 0)
+    return STEMGNN_ERR_INVALID_ARG;
+  if (!fits_i32(frontier_cap)) return STEMGNN_ERR_TOO_LARGE;
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  BatchCounters* ctr = reinterpret_cast<BatchCounters*>(state);
+  const int32_t cap = static_cast<int32_t>(frontier_cap);
+  k_hop_counts<<<grid_for(cap), kThreads, 0, st>>>(rowptr, n_id, ctr, hop, fanout, cap, cnt);
+  STEMGNN_LAUNCH_CHECK();
+  k_scan_block<<<1, kScanThreads, 0, st>>>(cnt, ent_base, nullptr, nullptr, ctr->nodes + hop + 1, ctr->nodes + hop, cap,
+                                           total, nullptr, nullptr, nullptr, false);
+  STEMGNN_LAUNCH_CHECK();
+  return STEMGNN_OK;
+}
+
+int stemgnn_sampler_full_hop_expand(const int32_t* rowptr, const int32_t* src, const int32_t* etype, int32_t* n_id,
+                                    int64_t n_cap, int32_t* state, int32_t hop, int32_t fanout,
+                                    uint64_t seed, uint64_t offset, int64_t batch_size, int64_t frontier_cap,
+                                    int64_t entries, int32_t* cnt, const int32_t* ent_base, int32_t* s_src,
+                                    int32_t* s_type, int32_t* wins, int32_t* new_base, int32_t* local_of,
+                                    int32_t* nodes_after, void* stream_) {
+  if (!rowptr || !src || !n_id || !state || !cnt || !ent_base || !wins || !new_base || !local_of || hop < 0 || hop > 13 ||
+      frontier_cap <= 0 || entries < 0 || fanout == 0 || (entries > 0 && (!s_src || !s_type)))
+    return STEMGNN_ERR_INVALID_ARG;
+  if (!fits_i32(frontier_cap) || !fits_i32(entries + 2) || !fits_i32(n_cap)) return STEMGNN_ERR_TOO_LARGE;
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  BatchCounters* ctr = reinterpret_cast<BatchCounters*>(state);
+  HopBuf h{};
+  h.s_src = s_src; h.s_type = s_type; h.s_cnt = cnt; h.ent_base = ent_base;
+  h.wins = wins; h.new_base = new_base; h.edge_base = const_cast<int32_t*>(ent_base);
+  h.cap = static_cast<int32_t>(frontier_cap); h.fanout = fanout; h.hop = hop;
+  const int32_t B = static_cast<int32_t>(batch_size);
+  k_emit_and_sample<<<grid_for(h.cap), kThreads, 0, st>>>(HopBuf{}, EmitOut{}, 0, h, rowptr, src, etype, n_id, ctr, seed,
+                                                         offset + static_cast<uint64_t>(hop) * 1000003ull, local_of);
+  STEMGNN_LAUNCH_CHECK();
+  k_count_wins<<<grid_for(std::max<int64_t>(h.cap, hop == 0 ? B : 0)), kThreads, 0, st>>>(h, ctr, B, n_id, local_of);
+  STEMGNN_LAUNCH_CHECK();
+  k_scan_block<<<1, kScanThreads, 0, st>>>(wins, new_base, cnt, nullptr, ctr->nodes + hop + 1, ctr->nodes + hop, h.cap,
+                                           ctr->nodes + hop + 2, ctr->nodes + hop + 1, ctr->edges + hop + 1,
+                                           ctr->edges + hop, false);
+  STEMGNN_LAUNCH_CHECK();
+  k_assign_new<<<grid_for(h.cap), kThreads, 0, st>>>(h, static_cast<int32_t>(n_cap), ctr, local_of, n_id, nullptr, nullptr,
+                                                     nodes_after);
+  STEMGNN_LAUNCH_CHECK();
+  return STEMGNN_OK;
+}
+
+size_t stemgnn_sampler_full_finish_workspace_bytes(int64_t num_edges) {
+  return num_edges < 0 ? 0 : align_up(static_cast<size_t>(num_edges < 1 ? 1 : num_edges) * 4, 256) + 256;
+}
+
+int stemgnn_sampler_full_finish(int32_t* state, int32_t hops, const int32_t* fanouts_host, const int64_t* frontier_caps_host,
+                                int32_t* const* cnt_h, int32_t* const* ent_base_h, int32_t* const* s_src_h,
+                                int32_t* const* s_type_h, int32_t* local_of, const int32_t* n_id, int64_t num_batch_nodes,
+                                int64_t num_batch_edges, int32_t* b_rowptr, int32_t* b_src, int32_t* b_type,
+                                int64_t* b_coo, float* inv_deg, int64_t* n_id64, int64_t* type64, const int64_t* x,
+                                int64_t* x_out, int32_t* counts, void* workspace, size_t workspace_bytes, void* stream_) {
+  if (!state || hops <= 0 || hops > 14 || !fanouts_host || !frontier_caps_host || !cnt_h || !ent_base_h || !s_src_h ||
+      !s_type_h || !local_of || !n_id || num_batch_nodes <= 0 || num_batch_edges < 0 || !b_rowptr || !inv_deg || !counts ||
+      !workspace || (num_batch_edges > 0 && (!b_src || !b_type || !b_coo)))
+    return STEMGNN_ERR_INVALID_ARG;
+  if (!fits_i32(num_batch_nodes) || !fits_i32(num_batch_edges)) return STEMGNN_ERR_TOO_LARGE;
+  if (workspace_bytes < stemgnn_sampler_full_finish_workspace_bytes(num_batch_edges)) return STEMGNN_ERR_WORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  BatchCounters* ctr = reinterpret_cast<BatchCounters*>(state);
+  int32_t* b_dst = reinterpret_cast<int32_t*>(align_up(reinterpret_cast<uintptr_t>(workspace), 256));
+  EmitOut eo{b_rowptr, b_src, b_type, b_dst, type64, nullptr, static_cast<int32_t>(num_batch_edges)};
+  for (int hop = 0; hop < hops; ++hop) {
+    if (frontier_caps_host[hop] <= 0 || !cnt_h[hop] || !ent_base_h[hop]) return STEMGNN_ERR_INVALID_ARG;
+    HopBuf h{};
+    h.s_src = s_src_h[hop]; h.s_type = s_type_h[hop]; h.s_cnt = cnt_h[hop]; h.ent_base = ent_base_h[hop];
+    h.edge_base = ent_base_h[hop];
+    h.cap = static_cast<int32_t>(frontier_caps_host[hop]); h.fanout = fanouts_host[hop]; h.hop = hop;
+    const int blocks = static_cast<int>(grid_for(h.cap));
+    k_emit_and_sample<<<static_cast<unsigned>(blocks), kThreads, 0, st>>>(h, eo, blocks, HopBuf{}, nullptr, nullptr, nullptr,
+                                                                         n_id, ctr, 0, 0, local_of);
+    STEMGNN_LAUNCH_CHECK();
+  }
+  ViewOut v{};
+  v.compact_coo = true;
+  v.inv_deg = inv_deg; v.n_id64 = n_id64; v.x_out = x_out; v.x = x;
+  k_finish<<<grid_for(std::max<int64_t>(num_batch_edges, num_batch_nodes + 1)), kThreads, 0, st>>>(
+      hops, ctr, static_cast<int32_t>(num_batch_nodes), static_cast<int32_t>(num_batch_edges), n_id, local_of, b_rowptr,
+      b_src, b_type, b_dst, b_coo, v, counts);
+  STEMGNN_LAUNCH_CHECK();
+  return STEMGNN_OK;
 }
 
 }  // extern "C"

@@ -11,7 +11,7 @@ contract lives in tests/torch_sampler.py as a test aid.
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import List
+from typing import List, Optional
 
 import torch
 from torch import Tensor
@@ -33,8 +33,8 @@ class Batch:
 
 class HipNeighborSampler:
     """The same contract on the fused HIP sampler (csrc/sampler.hip): the full graph's by-target
-    CSR and edge types stay resident in HBM, a batch is 11 launches (two hops) + one 12-byte
-    device->host copy, and the batch arrives with BOTH CSR views, 1 / in-degree and its int64 id / type / feature-row
+    CSR and edge types stay resident in HBM, a batch is 13 launches (two hops) whose sizes (12 bytes) land in pinned
+    host memory, and the batch arrives with BOTH CSR views, 1 / in-degree and its int64 id / type / feature-row
     vectors already built (``Batch.graph``): no launch is left for the consumer but the feature gather."""
 
     def __init__(self, edge_index: Tensor, xe: Tensor, num_nodes: int, x: Tensor, node_text_feat: Tensor,
@@ -60,15 +60,35 @@ class HipNeighborSampler:
         cap = max((f if f >= 0 else d_in) for f in self.fanouts) if self.fanouts else 0
         self.batch_max_in_degree, self.batch_max_out_degree = int(min(cap, d_in)), int(d_out)
 
+    def with_fanouts(self, num_neighbors: List[int]) -> "HipNeighborSampler":
+        """A sampler over the SAME resident graph (CSR, edge types, scratch map shared) with other fan-outs -- the
+        reference builds its training loader ([10] * L or [30] * L) and its evaluation loader ([-1] * L) over one ``data``
+        object (utils/loader.py:10-25)."""
+        other = object.__new__(HipNeighborSampler)
+        other.__dict__.update(self.__dict__)
+        other.fanouts = [int(f) for f in num_neighbors]
+        d_in = int((self.rowptr[1:] - self.rowptr[:-1]).max()) if self.num_nodes else 0
+        cap = max((f if f >= 0 else d_in) for f in other.fanouts) if other.fanouts else 0
+        other.batch_max_in_degree = int(min(cap, d_in))
+        other._slots = other._sizes = None
+        return other
+
     def sample_async(self, seeds: Tensor) -> "PendingBatch":
         """Enqueue the batch's launches on the current stream and return at once; ``result()`` waits for its sizes
-        (12 bytes) only.  A loader that keeps one batch in flight beyond the one being prepared never waits."""
+        (12 bytes) only.  A loader that keeps one batch in flight beyond the one being prepared never waits.
+        (Fan-outs with a -1 take the sized-per-hop path, which reads one size per hop: ``result()`` is immediate.)"""
         self.calls += 1
+        if any(f < 0 for f in self.fanouts):
+            o = ops.sample_batch_full(self.rowptr, self.src, self.etype, self.num_nodes, seeds.contiguous(), self.fanouts,
+                                      self.seed, self.calls * 64, self.local_of, self.x)
+            return PendingBatch(self, _Ready(o), seeds.numel())
         if self._sizes is None:
             self._sizes = torch.empty(8, 3, dtype=torch.int32, pin_memory=True)  # ring: at most a few batches in flight
+        # the by-source view's ordering pass walks a row in one thread: only for graphs whose out-rows are short
         pend = ops.sample_batch_views_launch(self.rowptr, self.src, self.etype, self.num_nodes, seeds.contiguous(),
                                              self.fanouts, self.seed, self.calls * 64, self.local_of, self.x,
-                                             counts_host=self._sizes[self.calls % 8])
+                                             counts_host=self._sizes[self.calls % 8],
+                                             by_source=self.batch_max_out_degree <= 128)
         return PendingBatch(self, pend, seeds.numel())
 
     def _adopt(self, o: dict, batch_size: int) -> Batch:
@@ -77,7 +97,7 @@ class HipNeighborSampler:
         if self._slots is None or self._slots.numel() < eb:
             cap, level = 0, batch_size
             for f in self.fanouts:
-                level *= f
+                level *= max(f, 0)  # a -1 hop has no bound: the identity map just grows with the largest batch seen
                 cap += level
             self._slots = torch.arange(max(cap, eb), dtype=torch.int32, device=o["src"].device)
         b = Batch(batch_size=batch_size, n_id=o["n_id64"], x=o["x"], edge_index=o["coo"], xe=o["type64"],
@@ -86,11 +106,20 @@ class HipNeighborSampler:
                                           max_in_degree=self.batch_max_in_degree,
                                           max_out_degree=self.batch_max_out_degree, active_rows=o["ab"],
                                           eid=self._slots[:eb],
-                                          by_source=(o["rowptr_t"], o["dst_t"], o["eid_t"], o["type_t"], o["inv_deg"]))
+                                          by_source=None if o["rowptr_t"] is None else
+                                          (o["rowptr_t"], o["dst_t"], o["eid_t"], o["type_t"], o["inv_deg"]))
         return b
 
     def sample(self, seeds: Tensor) -> Batch:
         return self.sample_async(seeds).result()
+
+
+class _Ready:
+    def __init__(self, o: dict):
+        self.o = o
+
+    def result(self) -> dict:
+        return self.o
 
 
 class PendingBatch:
@@ -102,11 +131,13 @@ class PendingBatch:
 
 
 class NeighborLoader:
-    """Iterates shuffled seed batches (one epoch), sharded round-robin across ranks."""
+    """Iterates shuffled seed batches (one epoch), sharded round-robin across ranks.  ``y`` (optional, one row per node
+    of the full graph): every batch carries ``batch.y = y[batch.n_id]``, what PyG's loader does with a node-level
+    attribute of ``data`` (the finetune loops read ``batch.y[:batch_size]``, reference task/node.py:28,77)."""
 
     def __init__(self, sampler, input_nodes: Tensor, batch_size: int, shuffle: bool = True,
-                 rank: int = 0, world_size: int = 1, seed: int = 0):
-        self.sampler, self.batch_size = sampler, batch_size
+                 rank: int = 0, world_size: int = 1, seed: int = 0, y: Optional[Tensor] = None):
+        self.sampler, self.batch_size, self.y = sampler, batch_size, y
         nodes = input_nodes
         if shuffle:
             g = torch.Generator(device=nodes.device).manual_seed(seed)  # shared seed: same order on all ranks
@@ -118,12 +149,46 @@ class NeighborLoader:
 
     def __iter__(self):
         for i in range(0, self.nodes.numel(), self.batch_size):
-            yield self.sampler.sample(self.nodes[i:i + self.batch_size])
+            b = self.sampler.sample(self.nodes[i:i + self.batch_size])
+            if self.y is not None:
+                b.y = self.y.to(b.n_id.device)[b.n_id]
+            yield b
 
     def iter_pending(self):
         """The same batches as handles whose launches are enqueued (``result()`` -> Batch): see PrefetchLoader."""
         for i in range(0, self.nodes.numel(), self.batch_size):
             yield self.sampler.sample_async(self.nodes[i:i + self.batch_size])
+
+
+class LinkNeighborLoader:
+    """LinkNeighborLoader as the reference uses it (utils/loader.py:28-48; task/link.py:55-61 reads ``edge_label_index``
+    and ``edge_label``): batches of LABELLED EDGES; the seeds of a batch are the distinct endpoints of its edges, their
+    neighbourhoods are sampled like a node batch's, and ``batch.edge_label_index`` addresses the batch's local node ids
+    (``batch.input_id`` = positions of the batch's edges in ``edge_label_index``)."""
+
+    def __init__(self, sampler, edge_label_index: Tensor, edge_label: Tensor, batch_size: int, shuffle: bool = True,
+                 seed: int = 0):
+        self.sampler, self.batch_size = sampler, batch_size
+        self.edge_label_index, self.edge_label = edge_label_index, edge_label
+        ids = torch.arange(edge_label_index.size(1), device=edge_label_index.device)
+        if shuffle:
+            g = torch.Generator(device=ids.device).manual_seed(seed)
+            ids = ids[torch.randperm(ids.numel(), generator=g, device=ids.device)]
+        self.ids = ids
+
+    def __len__(self):
+        return (self.ids.numel() + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        for i in range(0, self.ids.numel(), self.batch_size):
+            ids = self.ids[i:i + self.batch_size]
+            pairs = self.edge_label_index[:, ids]
+            seeds, inverse = torch.unique(pairs.reshape(-1), return_inverse=True)
+            b = self.sampler.sample(seeds)
+            b.edge_label_index = inverse.view(2, -1)
+            b.edge_label = self.edge_label.to(ids.device)[ids]
+            b.input_id = ids
+            yield b
 
 
 class MixLoader:

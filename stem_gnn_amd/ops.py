@@ -275,8 +275,8 @@ class PendingBatchViews:
     """A batch whose sampler launches are enqueued and whose sizes are on their way to the host: ``result()`` waits for
     the 12 bytes of sizes only (nothing to wait for when the batch was launched a step ahead) and cuts the views."""
 
-    def __init__(self, plan: _SamplerPlan, slab: Tensor, counts_host: Tensor, event):
-        self.plan, self.slab, self.counts_host, self.event = plan, slab, counts_host, event
+    def __init__(self, plan: _SamplerPlan, slab: Tensor, counts_host: Tensor, event, by_source: bool = True):
+        self.plan, self.slab, self.counts_host, self.event, self.by_source = plan, slab, counts_host, event, by_source
 
     def result(self) -> dict:
         self.event.synchronize()
@@ -285,21 +285,25 @@ class PendingBatchViews:
         s32, s64, f32 = self.slab.view(torch.int32), self.slab.view(torch.int64), self.slab.view(torch.float32)
         i32 = lambda name, n: s32[off[name] >> 2:(off[name] >> 2) + n]
         i64 = lambda name, n: s64[off[name] >> 3:(off[name] >> 3) + n]
-        return dict(nb=nb, eb=eb, ab=ab, cap_nodes=p.cn, cap_edges=p.ce, slab=self.slab, n_id=i32("n_id", nb),
-                    rowptr=i32("rowptr", nb + 1), src=i32("src", eb), type=i32("type", eb),
-                    coo=i64("coo", 2 * eb).view(2, eb), rowptr_t=i32("rowptr_t", nb + 1), dst_t=i32("dst_t", eb),
-                    eid_t=i32("eid_t", eb), type_t=i32("type_t", eb),
-                    inv_deg=f32[off["inv_deg"] >> 2:(off["inv_deg"] >> 2) + nb], n_id64=i64("n_id64", nb),
-                    x=i64("x", nb), type64=i64("type64", eb))
+        out = dict(nb=nb, eb=eb, ab=ab, cap_nodes=p.cn, cap_edges=p.ce, slab=self.slab, n_id=i32("n_id", nb),
+                   rowptr=i32("rowptr", nb + 1), src=i32("src", eb), type=i32("type", eb),
+                   coo=i64("coo", 2 * eb).view(2, eb), rowptr_t=None,
+                   inv_deg=f32[off["inv_deg"] >> 2:(off["inv_deg"] >> 2) + nb], n_id64=i64("n_id64", nb),
+                   x=i64("x", nb), type64=i64("type64", eb))
+        if self.by_source:
+            out.update(rowptr_t=i32("rowptr_t", nb + 1), dst_t=i32("dst_t", eb), eid_t=i32("eid_t", eb),
+                       type_t=i32("type_t", eb))
+        return out
 
 
 def sample_batch_views_launch(rowptr: Tensor, src: Tensor, etype: Optional[Tensor], num_nodes: int, seeds: Tensor,
                               fanouts, seed: int, offset: int, local_of: Tensor, x: Optional[Tensor] = None,
-                              counts_host: Optional[Tensor] = None) -> PendingBatchViews:
+                              counts_host: Optional[Tensor] = None, by_source: bool = True) -> PendingBatchViews:
     """sample_batch plus the by-source CSR, 1 / in-degree and the int64 forms of the batch (n_id, edge types, feature
     rows x[n_id]) from the same ten-odd launches; ONE allocation holds every output and the kernels' workspace.  The
     kernels write the sizes straight into ``counts_host`` (pinned int32 [3], device-accessible host memory); nothing
-    here waits for the device."""
+    here waits for the device.  ``by_source=False`` leaves the by-source CSR out (graphs with long out-rows: its
+    ordering pass walks a row in one thread); ``GraphStructure.ensure_transpose`` then sorts when somebody asks."""
     _req(seeds, torch.int64, "seeds", 1)
     if x is not None:
         _req(x, torch.int64, "x", 1)
@@ -311,16 +315,69 @@ def sample_batch_views_launch(rowptr: Tensor, src: Tensor, etype: Optional[Tenso
     check(lib.stemgnn_sample_batch_views(
         _p(rowptr), _p(src), _p(etype), num_nodes, _p(seeds), plan.B, plan.fan, plan.L, seed, offset, _p(local_of),
         plan.cn, plan.ce, base + off["n_id"], base + off["rowptr"], base + off["src"], base + off["type"],
-        base + off["coo"], _p(counts_host), base + off["rowptr_t"], base + off["dst_t"], base + off["eid_t"],
-        base + off["type_t"], base + off["inv_deg"], base + off["n_id64"], base + off["type64"], _p(x), base + off["x"],
+        base + off["coo"], _p(counts_host), *((base + off["rowptr_t"], base + off["dst_t"], base + off["eid_t"],
+                                               base + off["type_t"]) if by_source else (None,) * 4),
+        base + off["inv_deg"], base + off["n_id64"], base + off["type64"], _p(x), base + off["x"],
         base + off["ws"], plan.ws_bytes, _stream()), "sample_batch_views")
     event = torch.cuda.Event()
     event.record()
-    return PendingBatchViews(plan, slab, counts_host, event)
+    return PendingBatchViews(plan, slab, counts_host, event, by_source)
 
 
 def sample_batch_views(*args, **kwargs) -> dict:
     return sample_batch_views_launch(*args, **kwargs).result()
+
+
+def sample_batch_full(rowptr: Tensor, src: Tensor, etype: Optional[Tensor], num_nodes: int, seeds: Tensor, fanouts,
+                      seed: int, offset: int, local_of: Tensor, x: Optional[Tensor] = None) -> dict:
+    """A batch whose fan-outs include -1 (every in-neighbour; the reference's evaluation loaders): built hop by hop, the
+    host reading one size per hop to allocate the hop's entries (stemgnn_sampler_full_*).  Same keys as
+    ``sample_batch_views(...)``, without the by-source view (an evaluation batch has no backward; ``ensure_transpose``
+    sorts on demand)."""
+    _req(seeds, torch.int64, "seeds", 1)
+    if x is not None:
+        _req(x, torch.int64, "x", 1)
+    B, L, dev, st = seeds.numel(), len(fanouts), seeds.device, _stream()
+    i32 = dict(dtype=torch.int32, device=dev)
+    state = torch.empty(32, **i32)
+    size = torch.empty(1, dtype=torch.int32, pin_memory=True)
+    n_id = torch.empty(B, **i32)
+    check(lib.stemgnn_sampler_full_begin(_p(seeds), B, num_nodes, _p(local_of), _p(n_id), _p(state), st), "sampler_full_begin")
+    cap, known, hops = B, B, []
+    for h, f in enumerate(int(f) for f in fanouts):
+        cnt, ent, wins, base = (torch.empty(cap, **i32) for _ in range(4))
+        check(lib.stemgnn_sampler_full_hop_sizes(_p(rowptr), _p(n_id), _p(state), h, f, cap, _p(cnt), _p(ent), _p(size), st),
+              "sampler_full_hop_sizes")
+        torch.cuda.current_stream(dev).synchronize()
+        total = int(size[0])
+        s_src, s_type = torch.empty(max(total, 1), **i32), torch.empty(max(total, 1), **i32)
+        n_cap = known + min(total, num_nodes)
+        if n_cap > n_id.numel():
+            grown = torch.empty(n_cap, **i32)
+            grown[:known] = n_id[:known]
+            n_id = grown
+        check(lib.stemgnn_sampler_full_hop_expand(_p(rowptr), _p(src), _p(etype), _p(n_id), n_cap, _p(state), h, f, seed,
+                                                  offset, B, cap, total, _p(cnt), _p(ent), _p(s_src), _p(s_type), _p(wins),
+                                                  _p(base), _p(local_of), None, st), "sampler_full_hop_expand")
+        hops.append((cap, cnt, ent, s_src, s_type, wins, base))
+        cap, known = max(min(total, num_nodes), 1), n_cap
+    counts = state.tolist()  # nodes[0..15] | edges[0..15]: the one read the outputs' sizes need
+    nb, eb, ab = counts[L + 1], counts[16 + L], min(counts[L], counts[L + 1])
+    rp, inv = torch.empty(nb + 1, **i32), torch.empty(nb, dtype=torch.float32, device=dev)
+    b_src, b_type = torch.empty(eb, **i32), torch.empty(eb, **i32)
+    even = lambda n: n + (n & 1)  # every part starts on a 16-byte boundary (what the kernels' vector loads want)
+    o1, o2, o3 = 2 * eb, 2 * eb + even(nb), 2 * eb + 2 * even(nb)
+    s64 = torch.empty(o3 + eb, dtype=torch.int64, device=dev)
+    coo, n_id64, x_out, type64 = s64[:2 * eb], s64[o1:o1 + nb], s64[o2:o2 + nb], s64[o3:o3 + eb]
+    ws = _workspace(lib.stemgnn_sampler_full_finish_workspace_bytes(eb), dev)
+    sizes = torch.empty(3, **i32)  # (N_b, E_b, A_b) once more, for callers of the C entry point; known here already
+    ptrs = lambda k: (ctypes.c_void_p * L)(*[_p(hp[k]) for hp in hops])
+    check(lib.stemgnn_sampler_full_finish(
+        _p(state), L, (ctypes.c_int32 * L)(*[int(f) for f in fanouts]), (ctypes.c_int64 * L)(*[hp[0] for hp in hops]),
+        ptrs(1), ptrs(2), ptrs(3), ptrs(4), _p(local_of), _p(n_id), nb, eb, _p(rp), _p(b_src), _p(b_type), _p(coo), _p(inv),
+        _p(n_id64), _p(type64), _p(x), _p(x_out), _p(sizes), _p(ws), ws.numel(), st), "sampler_full_finish")
+    return dict(nb=nb, eb=eb, ab=ab, cap_nodes=nb, cap_edges=eb, slab=s64, n_id=n_id[:nb], rowptr=rp, src=b_src, type=b_type,
+                coo=coo.view(2, eb), rowptr_t=None, inv_deg=inv, n_id64=n_id64, x=x_out, type64=type64)
 
 
 def inv_degree(rowptr: Tensor) -> Tensor:

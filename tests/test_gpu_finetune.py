@@ -138,6 +138,120 @@ def test_minibatch_finetune_and_eval_run_on_the_hip_loader(dev):
     assert 0.0 <= res["test"] <= 100.0 and res["train"] > 100.0 / C  # better than chance on the nodes it trained on
 
 
+def test_get_loader_node_task_full_neighbourhood_eval_equals_full_batch(dev):
+    """utils/loader.get_loader (reference utils/loader.py:9-26): [10] * L training loader, [-1] * L evaluation loader in
+    batches of 512.  With every in-neighbour of every hop in the batch, a seed's L-layer embedding is the full graph's:
+    evaluation through the loader must reproduce the full-batch predictions (eval mode: running statistics, no
+    dropout) -- row for row, in node order."""
+    from stem_gnn_amd.task.node import ft_node, eval_node, _accumulate_minibatch_predictions, _run_full_batch
+    from stem_gnn_amd.utils.loader import get_loader
+    D, L, H, K, C = 128, 2, 4, 64, 7
+    params = {"separate_decoder_for_each_head": True, "decoder_jac_coeff": 0.0, "use_vq": 1, "setting": "standard",
+              "task": "node", "num_layers": L, "batch_size": 64}
+    data, labels, split = cora_like(seed=2, d=D, t=3)
+    _, gm = build_pair(D, L, H, K, C, dev, params, dropout=0.0, normalize="batch")
+    train_loader, subgraph_loader = get_loader(data, split, labels, params, device=dev)
+    assert len(train_loader) == 3 and len(subgraph_loader) == (2708 + 511) // 512
+    b = next(iter(train_loader))
+    assert b.batch_size == 64 and torch.equal(b.y, labels.to(dev)[b.n_id]) and bool(split["train"].to(dev)[b.n_id[:64]].all())
+    opt = torch.optim.AdamW(gm.parameters(), lr=5e-3)
+    losses = [ft_node(gm, data, train_loader, opt, split, labels, params)["loss"] for _ in range(6)]
+    assert losses[-1] < losses[0]
+    gm.eval()
+    with torch.no_grad():
+        pred_l, y_l = _accumulate_minibatch_predictions(gm, subgraph_loader, dev)
+        z, y_f = _run_full_batch(gm, data, labels, split, params)
+        pred_f = gm.get_lin_logits(z).mean(1).softmax(dim=-1)
+    assert torch.equal(y_l, y_f)
+    torch.testing.assert_close(pred_l, pred_f, rtol=1e-4, atol=1e-5)
+    res_l = eval_node(gm, data, subgraph_loader, split, labels, params)
+    res_f = eval_node(gm, data, None, split, labels, params)
+    for k in ("train", "val", "test"):
+        assert abs(res_l[k] - res_f[k]) < 1e-6, (k, res_l, res_f)
+
+
+def test_get_loader_link_task_full_neighbourhood_eval_equals_full_batch(dev):
+    """The link loaders (reference utils/loader.py:27-46): LinkNeighborLoader [30] * L over the training edges,
+    [-1] * L over every edge in batches of 4 096; seeds = the distinct endpoints of a batch's edges,
+    ``edge_label_index`` in local ids.  Full-neighbourhood evaluation through the loader = full-batch evaluation."""
+    from stem_gnn_amd.task.link import ft_link, eval_link
+    from stem_gnn_amd.utils.loader import get_loader
+    D, L, H, K, C = 128, 2, 4, 64, 5
+    params = {"separate_decoder_for_each_head": True, "decoder_jac_coeff": 0.0, "use_vq": 1, "setting": "standard",
+              "task": "link", "lamda_env": 0.0, "num_layers": L, "batch_size": 1024}
+    data, _, _ = cora_like(seed=4, n=2000, e=9000, d=D, c=C, t=C)
+    data.x = torch.arange(2000)
+    E = data.edge_index.size(1)
+    labels = data.xe.clone()
+    perm = torch.randperm(E, generator=torch.Generator().manual_seed(1))
+    split = {}
+    for name, lo, hi in (("train", 0, 4000), ("valid", 4000, 5000), ("test", 5000, 8000)):
+        m = torch.zeros(E, dtype=torch.bool)
+        m[perm[lo:hi]] = True
+        split[name] = m
+    _, gm = build_pair(D, L, H, K, C, dev, params, dropout=0.0, normalize="batch")
+    train_loader, subgraph_loader = get_loader(data, split, labels, params, device=dev)
+    assert len(train_loader) == 4 and len(subgraph_loader) == (E + 4095) // 4096
+    b = next(iter(train_loader))
+    mask = split["train"].to(dev)
+    ei_tr, y_tr = data.edge_index.to(dev)[:, mask], labels.to(dev)[mask]   # what the training loader was given
+    assert torch.equal(b.n_id[b.edge_label_index], ei_tr[:, b.input_id])   # local ids address the batch's nodes
+    assert torch.equal(b.edge_label, y_tr[b.input_id]) and b.input_id.numel() == 1024
+    assert b.batch_size == b.edge_label_index.unique().numel()             # seeds = the distinct endpoints
+    opt = torch.optim.AdamW(gm.parameters(), lr=5e-3)
+    losses = [ft_link(gm, data, train_loader, opt, split, labels, params)["loss"] for _ in range(4)]
+    assert losses[-1] < losses[0]
+    res_l = eval_link(gm, data, subgraph_loader, split, labels, params)
+    res_f = eval_link(gm, data, None, split, labels, params)
+    for k in ("train", "val", "test"):
+        assert abs(res_l[k] - res_f[k]) <= 2 * 100.0 / int(split["valid" if k == "val" else k].sum()) + 1e-6, (k, res_l, res_f)
+
+
+def test_get_loader_graph_task_batches_are_disjoint_unions(dev):
+    """The graph-task loaders (reference utils/loader.py:48-72): one DataLoader per split; a batch is the disjoint
+    union of its graphs (features and edge rows concatenated, endpoints shifted, ``batch`` = owner graph, ``y`` per
+    graph) and runs through ft_graph / eval_graph."""
+    from stem_gnn_amd.task.graph import ft_graph, eval_graph
+    from stem_gnn_amd.utils.loader import get_loader
+    D, L, H, K, T = 64, 2, 4, 32, 3
+    params = {"separate_decoder_for_each_head": True, "decoder_jac_coeff": 0.0, "use_vq": 1, "setting": "standard",
+              "task": "graph", "lamda_env": 0.0, "num_layers": L, "batch_size": 16}
+    g = torch.Generator().manual_seed(0)
+    ntab = torch.nn.functional.normalize(torch.randn(40, D, generator=g), dim=-1)   # shared text rows (atom / bond kinds)
+    etab = torch.nn.functional.normalize(torch.randn(5, D, generator=g), dim=-1)
+    graphs = []
+    for _ in range(60):
+        n = int(torch.randint(6, 20, (1,), generator=g))
+        e = int(torch.randint(n, 3 * n, (1,), generator=g))
+        d = Data()
+        d.x = torch.randint(0, 40, (n,), generator=g)
+        d.xe = torch.randint(0, 5, (e,), generator=g)
+        d.edge_index = torch.randint(0, n, (2, e), generator=g)
+        d.node_text_feat, d.edge_text_feat = ntab, etab
+        d.y = (torch.rand(T, generator=g) < 0.5).float()
+        graphs.append(d)
+    split = {"train": torch.arange(0, 40), "valid": torch.arange(40, 50), "test": torch.arange(50, 60)}
+    tr, va, te = get_loader(graphs, split, None, params, device=dev)
+    assert (len(tr), len(va), len(te)) == (3, 1, 1)
+    b = next(iter(va))
+    part = graphs[40:50]
+    sizes = [p.x.numel() for p in part]
+    assert b.node_text_feat.size(0) == sum(sizes) and tuple(b.y.shape) == (10, T) and b.batch.max().item() == 9
+    off = 0
+    for k, p in enumerate(part):   # graph k's rows, edges and label sit where the union puts them
+        assert torch.equal(b.node_text_feat[off:off + sizes[k]].cpu(), ntab[p.x]) and torch.equal(b.y[k].cpu(), p.y)
+        sel = (b.batch[b.edge_index[1]] == k).cpu()
+        assert torch.equal(b.edge_index[:, sel.to(dev)].cpu() - off, p.edge_index)
+        assert torch.equal(b.edge_text_feat[sel.to(dev)].cpu(), etab[p.xe])
+        off += sizes[k]
+    _, gm = build_pair(D, L, H, K, T, dev, params, normalize="batch", dropout=0.0)
+    opt = torch.optim.AdamW(gm.parameters(), lr=2e-3)
+    losses = [ft_graph(gm, None, tr, opt, None, None, params)["loss"] for _ in range(5)]
+    assert losses[-1] < losses[0]
+    res = eval_graph(gm, None, [tr, va, te], None, None, params)
+    assert res["metric"] == "auc" and all(0.0 <= res[k] <= 100.0 for k in ("train", "val", "test"))
+
+
 def test_eval_metrics_match_their_definitions(dev):
     from stem_gnn_amd.utils.eval import eval_acc, eval_auc
     torch.manual_seed(0)

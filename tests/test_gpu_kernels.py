@@ -552,6 +552,8 @@ def _check_sampler_views(b, g, dev):
     from stem_gnn_amd.graph import GraphStructure
     gs, nb = b.graph, b.n_id.numel()
     assert b.edge_index.is_contiguous() and b.edge_index.dtype == torch.int64
+    if gs.rowptr_t is None:  # graphs with long out-rows: the sampler leaves the by-source view to a sort on demand
+        gs.ensure_transpose()
     ref = GraphStructure(b.edge_index.clone(), nb, gs.etype_slot.clone()).ensure_transpose()
     for name in ("rowptr", "src", "rowptr_t", "dst_t", "eid_t", "etype_slot_t", "inv_deg"):
         assert torch.equal(getattr(gs, name), getattr(ref, name)), name
@@ -567,14 +569,16 @@ def test_sampler_plain_entry_point_gives_the_same_batch(dev):
     from stem_gnn_amd import ops
     from stem_gnn_amd.data.sampler import HipNeighborSampler
     from stem_gnn_amd.data.synthetic import make_graph
-    g = make_graph(3000, 40000, 16, 4, kind="Z", device=dev, graph_seed=5)
+    g = make_graph(3000, 40000, 16, 4, kind="U", device=dev, graph_seed=5)  # uniform: short out-rows, by-source view built
     for fan in ([4, 3], [6], [3, 2, 2]):
         s = HipNeighborSampler(g.edge_index, g.xe, g.num_nodes, g.x, g.node_text_feat, g.edge_text_feat, fan, seed=3)
+        assert s.batch_max_out_degree <= 128
         seeds = torch.randperm(g.num_nodes, device=dev)[:50]
         seeds[7] = seeds[3]  # a duplicate seed keeps its first position
         n_id, rowptr, src, etype, coo, nb, eb, ab = ops.sample_batch(s.rowptr, s.src, s.etype, s.num_nodes, seeds, fan,
                                                                      s.seed, 64, s.local_of)
         b = s.sample(seeds)  # first call: offset 64
+        assert b.graph.rowptr_t is not None
         assert (nb, eb, ab) == (b.n_id.numel(), b.edge_index.size(1), b.graph.active_rows if b.graph.active_rows is not None else nb)
         assert torch.equal(n_id.long(), b.n_id) and torch.equal(rowptr, b.graph.rowptr) and torch.equal(src, b.graph.src)
         assert torch.equal(etype, b.graph.etype_slot) and torch.equal(coo, b.edge_index)
@@ -607,8 +611,9 @@ def test_sampler_plain_entry_point_gives_the_same_batch(dev):
     assert torch.equal(coo[:2 * eb].view(2, eb), ref.edge_index) and torch.equal(inv[:nb], ref.graph.inv_deg)
 
 
+@pytest.mark.parametrize("fan", [[5, 3], [-1, -1], [4, -1]])
 @pytest.mark.parametrize("impl", ["hip", "torch"])
-def test_neighbor_sampler_contract(dev, impl):
+def test_neighbor_sampler_contract(dev, impl, fan):
     """NeighborLoader contract (reference pretrain.py:151-153): per hop each newly reached node
     draws min(deg, fanout) of its in-neighbours without replacement; every sampled edge is a real
     edge of the full graph with its edge type; seeds first; last-hop nodes have no in-edges."""
@@ -618,7 +623,7 @@ def test_neighbor_sampler_contract(dev, impl):
     from torch_sampler import NeighborSampler  # tests/torch_sampler.py: the torch-op restatement of the contract
     g = make_graph(5000, 60000, 16, 4, kind="Z", device=dev, graph_seed=3)
     cls = HipNeighborSampler if impl == "hip" else NeighborSampler
-    fan = [5, 3]
+    lim = [f if f >= 0 else 10 ** 9 for f in fan]  # -1: every in-neighbour (the evaluation loaders, utils/loader.py:18-25)
     s = cls(g.edge_index, g.xe, g.num_nodes, g.x, g.node_text_feat, g.edge_text_feat, fan, seed=11)
     ei, xe = g.edge_index.cpu(), g.xe.cpu()
     full = Counter(zip(ei[0].tolist(), ei[1].tolist(), xe.tolist()))
@@ -636,8 +641,8 @@ def test_neighbor_sampler_contract(dev, impl):
         # expanded nodes (dst side) received exactly min(deg, fanout) edges; hop structure
         cnt = torch.bincount(bei[1], minlength=nb)
         hop1_end = 64 + int((cnt[:64]).sum() * 0 + (bei[0][bei[1] < 64].unique() >= 64).sum())
-        assert torch.equal(cnt[:64], torch.minimum(indeg[n_id[:64]], torch.tensor(fan[0])))
-        assert torch.equal(cnt[64:hop1_end], torch.minimum(indeg[n_id[64:hop1_end]], torch.tensor(fan[1])))
+        assert torch.equal(cnt[:64], torch.minimum(indeg[n_id[:64]], torch.tensor(lim[0])))
+        assert torch.equal(cnt[64:hop1_end], torch.minimum(indeg[n_id[64:hop1_end]], torch.tensor(lim[1])))
         assert int(cnt[hop1_end:].sum()) == 0
         if impl == "hip":
             gs = b.graph
@@ -648,10 +653,22 @@ def test_neighbor_sampler_contract(dev, impl):
             assert torch.equal(gs.src.cpu().long(), bei[0]) and torch.equal(gs.etype_slot.cpu().long(), bxe)
             assert bool((bei[1][1:] >= bei[1][:-1]).all())  # edge j == CSR slot j
             _check_sampler_views(b, g, dev)
+            if fan[0] < 0 and fan[1] < 0 and rep == 0:
+                # with every in-neighbour taken nothing is drawn: the batch is a function of the seeds alone.  The torch
+                # restatement numbers a hop's new nodes by global id, this sampler by first appearance: the same nodes
+                # per hop and the same edges, up to that relabelling
+                t = NeighborSampler(g.edge_index, g.xe, g.num_nodes, g.x, g.node_text_feat, g.edge_text_feat, fan, seed=1)
+                bt = t.sample(seeds)
+                tn, te, tx = bt.n_id.cpu(), bt.edge_index.cpu(), bt.xe.cpu()
+                assert tn.numel() == nb and te.size(1) == eb
+                assert torch.equal(tn[:64], n_id[:64]) and torch.equal(tn[64:hop1_end].sort().values, n_id[64:hop1_end].sort().values)
+                assert torch.equal(tn[hop1_end:].sort().values, n_id[hop1_end:].sort().values)
+                assert Counter(zip(tn[te[0]].tolist(), tn[te[1]].tolist(), tx.tolist())) == got
     # the scratch map is left clean and draws are uniform: over repeated draws of one high-degree
     # node every in-neighbour slot is picked with frequency ~ fanout / deg
     if impl == "hip":
         assert int((s.local_of != -2 ** 31).sum()) == 0
+    if impl == "hip" and min(fan) > 0:
         v = int(indeg.argmax())
         deg = int(indeg[v])
         hits = Counter()
