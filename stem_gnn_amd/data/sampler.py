@@ -123,11 +123,17 @@ class _Ready:
 
 
 class PendingBatch:
+    """A batch whose launches are enqueued; ``result()`` -> Batch.  ``post`` (optional): what the loader still attaches
+    to the finished batch (labels)."""
+
     def __init__(self, sampler: HipNeighborSampler, pend, batch_size: int):
-        self.sampler, self.pend, self.batch_size = sampler, pend, batch_size
+        self.sampler, self.pend, self.batch_size, self.post = sampler, pend, batch_size, None
 
     def result(self) -> Batch:
-        return self.sampler._adopt(self.pend.result(), self.batch_size)
+        b = self.sampler._adopt(self.pend.result(), self.batch_size)
+        if self.post is not None:
+            self.post(b)
+        return b
 
 
 class NeighborLoader:
@@ -147,17 +153,20 @@ class NeighborLoader:
     def __len__(self):
         return (self.nodes.numel() + self.batch_size - 1) // self.batch_size
 
+    def _attach(self, b: Batch) -> None:
+        if self.y is not None:
+            b.y = self.y.to(b.n_id.device)[b.n_id]
+
     def __iter__(self):
-        for i in range(0, self.nodes.numel(), self.batch_size):
-            b = self.sampler.sample(self.nodes[i:i + self.batch_size])
-            if self.y is not None:
-                b.y = self.y.to(b.n_id.device)[b.n_id]
-            yield b
+        for p in self.iter_pending():
+            yield p.result()
 
     def iter_pending(self):
         """The same batches as handles whose launches are enqueued (``result()`` -> Batch): see PrefetchLoader."""
         for i in range(0, self.nodes.numel(), self.batch_size):
-            yield self.sampler.sample_async(self.nodes[i:i + self.batch_size])
+            p = self.sampler.sample_async(self.nodes[i:i + self.batch_size])
+            p.post = self._attach
+            yield p
 
 
 class LinkNeighborLoader:

@@ -328,7 +328,7 @@ def sample_batch_views(*args, **kwargs) -> dict:
     return sample_batch_views_launch(*args, **kwargs).result()
 
 
-def sample_batch_full(rowptr: Tensor, src: Tensor, etype: Optional[Tensor], num_nodes: int, seeds: Tensor, fanouts,
+def _sample_batch_full(rowptr: Tensor, src: Tensor, etype: Optional[Tensor], num_nodes: int, seeds: Tensor, fanouts,
                       seed: int, offset: int, local_of: Tensor, x: Optional[Tensor] = None) -> dict:
     """A batch whose fan-outs include -1 (every in-neighbour; the reference's evaluation loaders): built hop by hop, the
     host reading one size per hop to allocate the hop's entries (stemgnn_sampler_full_*).  Same keys as
@@ -378,6 +378,17 @@ def sample_batch_full(rowptr: Tensor, src: Tensor, etype: Optional[Tensor], num_
         _p(n_id64), _p(type64), _p(x), _p(x_out), _p(sizes), _p(ws), ws.numel(), st), "sampler_full_finish")
     return dict(nb=nb, eb=eb, ab=ab, cap_nodes=nb, cap_edges=eb, slab=s64, n_id=n_id[:nb], rowptr=rp, src=b_src, type=b_type,
                 coo=coo.view(2, eb), rowptr_t=None, inv_deg=inv, n_id64=n_id64, x=x_out, type64=type64)
+
+
+def sample_batch_full(rowptr: Tensor, src: Tensor, etype: Optional[Tensor], num_nodes: int, seeds: Tensor, fanouts,
+                      seed: int, offset: int, local_of: Tensor, x: Optional[Tensor] = None) -> dict:
+    """``_sample_batch_full`` with the scratch map restored if a step fails half-way (an allocation that does not fit,
+    a bad argument): claimed-but-unnumbered entries would otherwise corrupt every later batch of the sampler."""
+    try:
+        return _sample_batch_full(rowptr, src, etype, num_nodes, seeds, fanouts, seed, offset, local_of, x)
+    except BaseException:
+        check(lib.stemgnn_sampler_init_map(_p(local_of), local_of.numel(), _stream()), "sampler_init_map")
+        raise
 
 
 def inv_degree(rowptr: Tensor) -> Tensor:

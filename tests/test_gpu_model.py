@@ -509,10 +509,11 @@ def test_prefetch_loader_yields_the_same_batches(dev):
     from stem_gnn_amd.data.sampler import HipNeighborSampler, NeighborLoader, PrefetchLoader
     from stem_gnn_amd.data.synthetic import make_graph
     g = make_graph(20_000, 200_000, 32, 3, kind="U", device=dev)
+    node_labels = torch.arange(20_000, device=dev) % 7   # a node-level attribute: batches carry y = labels[n_id]
 
     def make_loader():
         s = HipNeighborSampler(g.edge_index, g.xe, g.num_nodes, g.x, g.node_text_feat, g.edge_text_feat, [5, 5], seed=3)
-        return NeighborLoader(s, torch.arange(4096, device=dev), 512, shuffle=True, seed=1)
+        return NeighborLoader(s, torch.arange(4096, device=dev), 512, shuffle=True, seed=1, y=node_labels)
 
     plain = [(b.n_id.clone(), b.edge_index.clone(), b.xe.clone()) for b in make_loader()]
 
@@ -523,6 +524,7 @@ def test_prefetch_loader_yields_the_same_batches(dev):
     got = []
     for b in PrefetchLoader(make_loader(), dev, prepare):
         junk = torch.randn(1 << 20, device=dev).sum()          # allocator + stream traffic between hand-over and use
+        assert torch.equal(b.y, node_labels[b.n_id])
         got.append((b.n_id, b.edge_index, b.xe, b.feat, b.graph.rowptr_t, junk))
     torch.cuda.synchronize()
     assert len(got) == len(plain) == 8
