@@ -515,13 +515,30 @@ k_vq_assign_ws(const float* __restrict__ xp, int64_t N, int H, const float* __re
       }
       __syncthreads();
     }
-    // ---- epilogue: similarities to the staging tile [row][code]; a lane holds code 32 wn + (its 16 register rows)
-    // of data row tm * 32 + lj (operands swapped relative to the product kernel: the accumulator's rows are codes)
+    // ---- epilogue: the arg-max straight from the accumulators.  Operands are swapped relative to the product kernel
+    // (the accumulator's rows are codes): lane (lj, hi) of wave wn holds, for data row tm * 32 + lj, the 16 codes
+    // 32 wn + 4 hi + (r & 3) + 8 (r >> 2) -- ascending in r.  Strict '>' keeps the lowest index, as torch.argmax does;
+    // the two lane halves meet through one shuffle, the four waves through 2 KB of LDS (the similarity tile used to
+    // travel through a 33 KB staging tile: 32 scattered stores and eight 16-byte loads per lane and tile).
+    float* const s_best = tile;                                           // [4 waves][64 rows]
+    int* const s_code = reinterpret_cast<int*>(tile + 4 * kTileM);        // [4 waves][64 rows]
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
+    for (int tm = 0; tm < 2; ++tm) {
+      float best = -INFINITY;
+      int bi = 0;
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        tile[(tm * 32 + lj) * kLdT + 32 * wn + 4 * hi + (r & 3) + 8 * (r >> 2)] = acc[tm][r];
+      for (int r = 0; r < 16; ++r) {
+        const float v = acc[tm][r];
+        if (v > best) { best = v; bi = 32 * wn + 4 * hi + (r & 3) + 8 * (r >> 2); }
+      }
+      const float ov = __shfl_xor(best, 32, 64);
+      const int oi = __shfl_xor(bi, 32, 64);
+      if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+      if (hi == 0) {
+        s_best[wn * kTileM + tm * 32 + lj] = best;
+        s_code[wn * kTileM + tm * 32 + lj] = bi;
+      }
+    }
     {
       float v0 = ssq[0], v1 = ssq[1];
       v0 += __shfl_xor(v0, 1, 64); v0 += __shfl_xor(v0, 2, 64); v0 += __shfl_xor(v0, 4, 64);
@@ -531,34 +548,21 @@ k_vq_assign_ws(const float* __restrict__ xp, int64_t N, int H, const float* __re
       ssq_next[0] = ssq_next[1] = 0.f;
     }
     __syncthreads();
-    {
-      // four lanes per row, 32 codes each in ascending order; strict '>' keeps the lowest index, as torch.argmax does
-      const int row = tid >> 2, part = tid & 3;
-      float best = -INFINITY;
-      int bi = 0;
+    if ((tid & 3) == 0) {  // one thread per row (the thread that summed this row's commitment terms before: same sums)
+      const int row = tid >> 2;
+      float best = s_best[row];
+      int bi = s_code[row];
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const float4 v = ld4(tile + row * kLdT + part * 32 + 4 * c);
-        const int code = part * 32 + 4 * c;
-        if (v.x > best) { best = v.x; bi = code; }
-        if (v.y > best) { best = v.y; bi = code + 1; }
-        if (v.z > best) { best = v.z; bi = code + 2; }
-        if (v.w > best) { best = v.w; bi = code + 3; }
-      }
-#pragma unroll
-      for (int o = 1; o < 4; o <<= 1) {
-        const float ov = __shfl_xor(best, o, 64);
-        const int oi = __shfl_xor(bi, o, 64);
-        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+      for (int w = 1; w < 4; ++w) {  // waves in ascending code order: strict '>' keeps the lowest index
+        const float ov = s_best[w * kTileM + row];
+        if (ov > best) { best = ov; bi = s_code[w * kTileM + row]; }
       }
       const float nrm = sqrtf(s_ssq[row]);
       const float inv = 1.0f / fmaxf(nrm, kNormEps), xn2 = nrm * inv;
       const int64_t m = m0 + row < N ? m0 + row : N - 1;  // a row past N is a copy of row N - 1: the same values again
-      if (part == 0) {
-        ind_out[m * H + h] = static_cast<int64_t>(bi);
-        norm_out[m * H + h] = nrm;
-        if (m0 + row < N) sq_acc += esq[static_cast<int64_t>(h) * K + bi] + xn2 * xn2 - 2.0f * best * inv;
-      }
+      ind_out[m * H + h] = static_cast<int64_t>(bi);
+      norm_out[m * H + h] = nrm;
+      if (m0 + row < N) sq_acc += esq[static_cast<int64_t>(h) * K + bi] + xn2 * xn2 - 2.0f * best * inv;
     }
   }
   // ---- the block's commitment sum; the last block to arrive adds all of them in index order (common.h: ticket_last)
