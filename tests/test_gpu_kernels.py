@@ -563,6 +563,60 @@ def _check_sampler_views(b, g, dev):
     assert b.n_id.dtype == torch.int64 and b.xe.dtype == torch.int64
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_sampler_randomised_graphs_fanouts_and_seed_lists(dev, seed):
+    """Random small graphs (uniform / skewed, with self-loops and repeated edges), random fan-out lists (1-3 hops, values
+    up to 32 and -1) and seed lists with repeats: every batch edge is a real edge with its type, every expanded node got
+    min(in-degree, fan-out) of them, nodes are numbered hop by hop, the CSR views agree with the COO, and the scratch
+    map comes back clean."""
+    from collections import Counter
+    from stem_gnn_amd.data.sampler import HipNeighborSampler
+    rng = torch.Generator().manual_seed(100 + seed)
+    n = int(torch.randint(50, 3000, (1,), generator=rng))
+    e = int(torch.randint(n, 12 * n, (1,), generator=rng))
+    src = torch.randint(0, n, (e,), generator=rng)
+    dst = (torch.rand(e, generator=rng) ** (1 + seed % 3) * n).long().clamp(max=n - 1)  # seed % 3 > 0: skewed in-degrees
+    src[:5] = dst[:5]                      # self-loops
+    src[5:10], dst[5:10] = src[0], dst[1]  # one edge five times over
+    ei = torch.stack([src, dst]).to(dev)
+    xe = torch.randint(0, 3, (e,), generator=rng).to(dev)
+    feat = torch.randn(n, 8, device=dev)
+    hops = 1 + seed % 3
+    fan = [int(f) for f in torch.randint(1, 33, (hops,), generator=rng)]
+    if seed % 2:
+        fan[int(torch.randint(0, hops, (1,), generator=rng))] = -1
+    s = HipNeighborSampler(ei, xe, n, torch.arange(n, device=dev), feat, torch.randn(3, 8, device=dev), fan, seed=seed)
+    indeg = torch.bincount(dst, minlength=n)
+    full = Counter(zip(src.tolist(), dst.tolist(), xe.cpu().tolist()))
+    for rep in range(3):
+        b_sz = int(torch.randint(1, 200, (1,), generator=rng))
+        seeds = torch.randint(0, n, (b_sz,), generator=rng).to(dev)  # repeats are likely
+        b = s.sample(seeds)
+        n_id, bei, bxe = b.n_id.cpu(), b.edge_index.cpu(), b.xe.cpu()
+        nb = n_id.numel()
+        assert torch.equal(n_id[:b_sz], seeds.cpu())
+        assert n_id[b_sz:].unique().numel() == nb - b_sz and not bool(torch.isin(n_id[b_sz:], seeds.cpu()).any())
+        got = Counter(zip(n_id[bei[0]].tolist(), n_id[bei[1]].tolist(), bxe.tolist()))
+        cnt = torch.bincount(bei[1], minlength=nb)
+        # a node is expanded in the hop after the one that reached it: walk the hops through the counts
+        lo, hi = 0, b_sz
+        for f in fan:
+            lim = f if f >= 0 else 10 ** 9
+            assert torch.equal(cnt[lo:hi], torch.clamp(indeg[n_id[lo:hi]], max=lim)), (fan, lo, hi)
+            reached = bei[0][(bei[1] >= lo) & (bei[1] < hi)]
+            lo, hi = hi, max(hi, int(reached.max()) + 1 if reached.numel() else hi)
+        assert int(cnt[lo:].sum()) == 0 or lo == hi
+        # repeated seeds draw separately, so an edge may appear once per copy of its target: multiplicity bound
+        mult = Counter(seeds.cpu().tolist())
+        assert all(c <= full[k] * max(mult.get(k[1], 1), 1) for k, c in got.items())
+        gs = b.graph
+        if gs.rowptr_t is None:
+            gs.ensure_transpose()
+        order = torch.argsort(bei[0], stable=True)
+        assert torch.equal(gs.dst_t.cpu().long(), bei[1][order]) and torch.equal(gs.eid_t.cpu().long(), order)
+        assert int((s.local_of != -2 ** 31).sum()) == 0
+
+
 def test_sampler_plain_entry_point_gives_the_same_batch(dev):
     """stemgnn_sample_batch (by-target CSR + COO with row stride cap_edges) and stemgnn_sample_batch_views draw the same
     batch for the same (seed, offset)."""
