@@ -351,6 +351,12 @@ int stemgnn_dropout_keep_mask(int64_t n, float p, uint64_t seed, uint64_t offset
  * queries.  Returns the previous mode.  The tile plan (stemgnn_linear_stats_blocks) depends on the mode: set it
  * before sizing buffers.  STEMGNN_GEMM=f32 / bf16 in the environment starts the process in mode 0 / 2. */
 int stemgnn_linear_set_mode(int mode);
+/* Mode 2 only: large products (>= 8 192 rows, >= 2.5e10 flop) take a rounding pass + hipblasLtMatmul (bf16 operands, fp32
+ * accumulation and output: the same product the tile kernel forms, 2.2-2.4x faster at the D = 768 shapes) unless
+ * switched off here (on = 0; 1 = default; any other value only queries).  Returns the previous setting. */
+int stemgnn_linear_set_library_gemm(int on);
+/* Products the vendor library has served in this process so far (tests prove the path was taken with it). */
+int64_t stemgnn_linear_library_calls(void);
 
 /* y [M, N] = x1 [M, K1] w1[N, K1]^T (+ x2 [M, K2] w2 [N, K2]^T when K2 > 0) + bias [N] (NULL: none).
  * stats_partial (may be NULL): receives per-row-block column sums / sums of squares of y,

@@ -165,6 +165,8 @@ _SIGNATURES = {
     "stemgnn_grad_norm_coef": (c_int, [P, P, I32, c_float, P, P, c_size_t, P]),
     "stemgnn_adamw_step": (c_int, [P, P, P, P, P, I32, c_float, c_float, c_float, c_float, c_float, I64, P, P]),
     "stemgnn_linear_set_mode": (c_int, [c_int]),
+    "stemgnn_linear_set_library_gemm": (c_int, [c_int]),
+    "stemgnn_linear_library_calls": (I64, []),
     "stemgnn_linear_bwd_data": (c_int, [P, P, I64, I64, I64, P, P]),
     "stemgnn_linear_fwd": (c_int, [P, P, I64, P, P, I64, P, I64, I64, P, P, P, I64, P]),
     "stemgnn_linear_fwd_rows": (c_int, [P, P, I64, P, P, I64, P, I64, I64, P, P, P, I64, I64, P]),

@@ -13,7 +13,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libstemgnn_hip.so")
-SOURCES = ["graph_build.hip", "sage_agg.hip", "bn_act.hip", "vq.hip", "edge_ops.hip", "linear.hip", "graph_aug.hip", "sampler.hip", "loss_ops.hip", "optim_ops.hip", "phases.hip", "heads.hip", "wsgemm.hip"]
+SOURCES = ["graph_build.hip", "sage_agg.hip", "bn_act.hip", "vq.hip", "edge_ops.hip", "linear.hip", "graph_aug.hip", "sampler.hip", "loss_ops.hip", "optim_ops.hip", "phases.hip", "heads.hip", "wsgemm.hip", "blaslt.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-fno-gpu-rdc", "-munsafe-fp-atomics"]
@@ -43,7 +43,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
     if procs or not os.path.exists(LIB_PATH):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *objs]
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *objs, "-L/opt/rocm/lib", "-lhipblaslt",
+               "-Wl,-rpath,/opt/rocm/lib"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -178,6 +178,18 @@ __device__ __forceinline__ floatx16 mfma_x3_b1(const bf16x8 (&a)[3], const bf16x
   return c;
 }
 
+// csrc/blaslt.hip: the bf16 GEMM mode's large products on the vendor library (a rounding pass + hipblasLtMatmul).
+// lt_gemm_ok: the product is large enough for that to beat the tile kernel; the lt_linear_* return STEMGNN_ERR_INVALID_ARG
+// when the library has no kernel for the shape and STEMGNN_ERR_HIP when it or an allocation failed -- the callers then
+// take the tile kernels.
+bool lt_gemm_ok(int64_t M, int64_t N, int64_t K);
+int lt_linear_fwd(const float* x1, const float* w1, int64_t K1, const void* x2, int x2_kind, const float* w2, int64_t K2,
+                  const float* bias, int64_t M, int64_t N, float* y, int64_t x1_rows, float* stats_partial,
+                  int64_t stats_slabs, hipStream_t st);
+int lt_linear_bwd_data(const float* dy, const float* w, int64_t M, int64_t N, int64_t K, float* dx, hipStream_t st);
+int lt_linear_bwd_weight(const float* dy, const void* x, int x_kind, int64_t M, int64_t N, int64_t K, float* dw, float* db,
+                         hipStream_t st);
+
 // csrc/wsgemm.hip: the weight-stationary dense product (K == 128): rows row_base.. of  y = x w^T + b  (bt: y = x w with w
 // given as [K][N]); stats_partial[stats_block0 + tile][2][N] takes the column sums / sums of squares per 128-row tile
 bool linear_ws_ok(int64_t M, int64_t N, int64_t K);

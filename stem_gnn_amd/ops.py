@@ -798,6 +798,12 @@ def linear_set_mode(mode: int) -> int:
     return int(lib.stemgnn_linear_set_mode(int(mode)))
 
 
+def linear_set_library_gemm(on: int) -> int:
+    """bf16 GEMM mode only: large products on the vendor library (default) or on the tile kernels (0).  Returns the
+    previous setting (any argument but 0 / 1 only queries)."""
+    return int(lib.stemgnn_linear_set_library_gemm(int(on)))
+
+
 def linear_fwd(x1: Tensor, w1: Tensor, x2: Optional[Tensor], w2: Optional[Tensor], bias: Optional[Tensor],
                want_stats: bool = False, x1_rows: int = -1):
     """y = x1 w1^T (+ x2 w2^T) + bias; optionally the per-row-block column partials of y.  ``x1_rows`` >= 0

@@ -1061,6 +1061,46 @@ def test_bf16_gemm_mode_is_the_product_of_the_rounded_operands(dev, m, k1, k2, n
     torch.testing.assert_close(db.double(), dy.double().sum(0), rtol=1e-5, atol=1e-4 * float(dy.abs().sum(0).max()))
 
 
+@pytest.mark.parametrize("m,k1,k2,n,rows", [(32768, 768, 0, 768, -1), (20000, 512, 512, 1024, 4000), (9000, 512, 0, 3072, -1)])
+def test_bf16_gemm_mode_large_products_on_the_vendor_library(dev, m, k1, k2, n, rows):
+    """Mode 2's large products take a rounding pass + hipblasLtMatmul (csrc/blaslt.hip) instead of the tile kernel that
+    rounds while it stages: the same product -- rounded operands, fp32 accumulation --, checked against torch on the
+    rounded operands in fp64 AND against the tile kernels (library switched off), with bias, the two-operand form with
+    zero leading rows, the BatchNorm column sums, backward-data, weight and bias gradients."""
+    from stem_gnn_amd import ops
+    torch.manual_seed(m + n)
+    r = lambda t: t.bfloat16().double()  # noqa: E731
+    a = torch.randn(m, k1, device=dev) * (1 + 3 * torch.rand(m, 1, device=dev))
+    w = torch.randn(n, k1, device=dev) * 0.2
+    a2 = torch.randn(m, k2, device=dev) if k2 else None
+    w2 = torch.randn(n, k2, device=dev) * 0.2 if k2 else None
+    b = torch.randn(n, device=dev)
+    if rows >= 0:
+        a[rows:] = 0
+    dy = torch.randn(m, n, device=dev)
+    prev = ops.linear_set_mode(2)
+    out = {}
+    try:
+        from stem_gnn_amd._lib import lib
+        for lib_on in (1, 0):
+            was = ops.linear_set_library_gemm(lib_on)
+            served = lib.stemgnn_linear_library_calls()
+            y, part, blocks = ops.linear_fwd(a, w, a2, w2, b, True, rows)
+            out[lib_on] = (y, part[:blocks].double().sum(0), ops.linear_bwd_data(dy, w), *ops.linear_bwd_weight(dy, a, True))
+            took = lib.stemgnn_linear_library_calls() - served  # forward, backward-data, weight gradient
+            assert took == 0 if not lib_on else (took == 3 if k2 == 0 else took >= 1), took
+            ops.linear_set_library_gemm(was)
+    finally:
+        ops.linear_set_mode(prev)
+    ref = r(a) @ r(w).t() + (r(a2) @ r(w2).t() if k2 else 0) + b.double()
+    refs = (ref, torch.stack([ref.sum(0), (ref * ref).sum(0)]), r(dy) @ r(w), r(dy).t() @ r(a), dy.double().sum(0))
+    for name, got_lib, got_tile, want in zip(("y", "column sums", "dx", "dw", "db"), out[1], out[0], refs):
+        tol = 2e-5 * float(want.abs().max())
+        torch.testing.assert_close(got_lib.double(), want, rtol=1e-5, atol=tol, msg=lambda s_: f"{name} (library): {s_}")
+        torch.testing.assert_close(got_lib.double(), got_tile.double(), rtol=1e-5, atol=tol,
+                                   msg=lambda s_: f"{name} (library vs tile kernel): {s_}")
+
+
 def test_deterministic_mode_makes_steps_bit_reproducible(dev):
     """stemgnn_set_deterministic(1): the decoders' backward scatters add in a fixed order (edges grouped by node)
     instead of with fp32 atomics -- the only order-dependent arithmetic on the path.  Two runs of three optimiser steps
