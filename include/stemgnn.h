@@ -463,8 +463,11 @@ int stemgnn_transpose(const float* in, int64_t rows, int64_t cols, float* out, v
  * ------------------------------------------------------------------------------------ */
 size_t stemgnn_vq_workspace_bytes(int64_t num_rows, int64_t heads, int64_t code_dim, int64_t codebook_size);
 /* Which kernel the calling thread's most recent stemgnn_vq_assign_fwd / _lean call launched: 0 none yet, 1 the tile
- * form (k_vq_assign), 2 the weight-stationary form (k_vq_assign_ws: K = Dc = 128, >= 16 384 rows).  The golden tests
- * use it to make sure a production-shape fixture was served by the production kernel. */
+ * form (k_vq_assign), 2 the weight-stationary form (k_vq_assign_ws: K = Dc = 128, >= 16 384 rows), 3 the large-codebook
+ * form (lean assignment, K >= 512, Dc >= 256, >= 8 192 rows: the six exact piece products as one hipBLASLt GEMM over a
+ * contraction of 6 Dc, then arg-max and commitment terms off the similarity matrix; stemgnn_linear_set_library_gemm(0)
+ * keeps it on the tile form).  The golden tests use it to make sure a production-shape fixture was served by the
+ * production kernel. */
 int stemgnn_vq_assign_last_path(void);
 
 int stemgnn_vq_assign_fwd(const float* xp, int64_t num_rows, int64_t heads, int64_t code_dim,

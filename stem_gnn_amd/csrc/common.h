@@ -189,6 +189,15 @@ int lt_linear_fwd(const float* x1, const float* w1, int64_t K1, const void* x2, 
 int lt_linear_bwd_data(const float* dy, const float* w, int64_t M, int64_t N, int64_t K, float* dx, hipStream_t st);
 int lt_linear_bwd_weight(const float* dy, const void* x, int x_kind, int64_t M, int64_t N, int64_t K, float* dw, float* db,
                          hipStream_t st);
+// the quantiser's code assignment at large codebooks: the exact six-piece similarity product as ONE library GEMM over
+// a contraction of 6 Dc, then arg-max + commitment terms off the similarity matrix (same outputs as k_vq_assign; quant ==
+// NULL: its lean form)
+bool lt_vq_assign_ok(int64_t N, int64_t H, int64_t Dc, int64_t K);
+int lt_vq_assign(const float* xp, int64_t N, int64_t H, int64_t Dc, const float* embed, const float* esq, int64_t K,
+                 int training, float* xn, float* norm, int64_t* ind, float* quant, float* sqerr, double sq_scale,
+                 hipStream_t st);
+bool library_gemm_enabled();  // csrc/linear.hip: stemgnn_linear_set_library_gemm
+void library_gemm_served();   // counts a product the library served (stemgnn_linear_library_calls)
 
 // csrc/wsgemm.hip: the weight-stationary dense product (K == 128): rows row_base.. of  y = x w^T + b  (bt: y = x w with w
 // given as [K][N]); stats_partial[stats_block0 + tile][2][N] takes the column sums / sums of squares per 128-row tile

@@ -1330,6 +1330,13 @@ int stemgnn_linear_set_ws(int min_tiles) {
   return prev;
 }
 
+}  // extern "C"
+namespace stemgnn {
+bool library_gemm_enabled() { return g_library_gemm.load(std::memory_order_relaxed) != 0; }
+void library_gemm_served() { g_library_calls.fetch_add(1, std::memory_order_relaxed); }
+}  // namespace stemgnn
+extern "C" {
+
 int64_t stemgnn_linear_library_calls(void) { return g_library_calls.load(std::memory_order_relaxed); }
 
 int stemgnn_linear_set_library_gemm(int on) {

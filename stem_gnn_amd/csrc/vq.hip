@@ -813,6 +813,13 @@ static int vq_assign_impl(const float* xp, int64_t N, int64_t H, int64_t Dc, con
     g_last_assign_path = 2;
     return vq_assign_ws_launch(xp, N, H, embed, esq, norm, ind, partial, counter, sq_scale, sqerr, st);
   }
+  // a large codebook: the exact six-piece similarity product as one library GEMM (csrc/blaslt.hip)
+  if (x3 && library_gemm_enabled() && lt_vq_assign_ok(N, H, Dc, K) &&
+      lt_vq_assign(xp, N, H, Dc, embed, esq, K, training, xn, norm, ind, quant, sqerr, sq_scale, st) == STEMGNN_OK) {
+    g_last_assign_path = 3;
+    library_gemm_served();
+    return STEMGNN_OK;
+  }
   g_last_assign_path = 1;
 #define STEMGNN_VQ_LAUNCH(CG)                                                                                         \
   do {                                                                                                                \

@@ -1090,6 +1090,80 @@ def test_vq_assign_weight_stationary_matches_the_tile_form(dev, N, H):
     assert int((i1 == 90).sum()) == 0 or bool(((i1 == 90) <= (ref != 17)).all())
 
 
+@pytest.mark.parametrize("N,H,K,Dc", [(9000, 2, 512, 256), (8192, 3, 2048, 768)])
+def test_vq_assign_large_codebook_on_the_vendor_library(dev, N, H, K, Dc):
+    """The lean code assignment at large codebooks (K >= 512, Dc >= 256, N >= 8 192: BASELINE configs 3 / 5) as ONE
+    library GEMM over the six exact piece products (csrc/blaslt.hip: lt_vq_assign_lean) against the fused tile kernel
+    (library switched off) and against torch: indices (lowest index among equals; a duplicated code and a zero row
+    included), row norms, commitment sum.  The two sum their fp32 products in different orders: an index may differ
+    only where the top-2 similarity gap is at rounding level."""
+    from stem_gnn_amd._lib import lib, check
+    torch.manual_seed(N + K)
+    st = torch.cuda.current_stream().cuda_stream
+    xp = torch.randn(N, H * Dc, device=dev) * (0.5 + torch.rand(N, 1, device=dev))
+    xp[7] = 0
+    embed = torch.nn.functional.normalize(torch.randn(H, K, Dc, device=dev), dim=-1) * (1 + 0.05 * torch.rand(H, K, 1, device=dev))
+    embed[:, 90] = embed[:, 17]  # a tie wherever code 17 wins
+    embed = embed.contiguous()
+    esq = (embed * embed).sum(-1).contiguous()
+
+    def run():
+        norm = torch.empty(N, H, device=dev)
+        ind = torch.empty(N, H, dtype=torch.int64, device=dev)
+        sq = torch.empty(1, device=dev)
+        ws = torch.empty(int(lib.stemgnn_vq_workspace_bytes(N, H, Dc, K)), dtype=torch.uint8, device=dev)
+        check(lib.stemgnn_vq_assign_lean(xp.data_ptr(), N, H, Dc, embed.data_ptr(), esq.data_ptr(), K, norm.data_ptr(),
+                                         ind.data_ptr(), sq.data_ptr(), 0.25, ws.data_ptr(), ws.numel(), st))
+        return norm, ind, sq, lib.stemgnn_vq_assign_last_path()
+
+    prev = lib.stemgnn_linear_set_library_gemm(0)
+    try:
+        n0, i0, s0, p0 = run()
+        lib.stemgnn_linear_set_library_gemm(1)
+        n1, i1, s1, p1 = run()
+    finally:
+        lib.stemgnn_linear_set_library_gemm(prev)
+    assert (p0, p1) == (1, 3)  # the tile kernel, then the library
+    xh = xp.view(N, H, Dc)
+    sim = torch.einsum("nhd,hkd->nhk", xh.double(), embed.double())
+    top2 = sim.topk(2, dim=-1).values
+    gap = ((top2[..., 0] - top2[..., 1]) / xh.double().norm(dim=-1).clamp_min(1e-30))
+    differ = i1 != i0
+    assert float(differ.float().mean()) < 1e-3 and bool((gap[differ] < 1e-5).all())
+    assert int((i1 == 90).sum()) == 0  # the duplicate never wins: the lowest index does
+    assert bool((i1[7] == i0[7]).all())  # the zero row: every similarity equal, index 0
+    torch.testing.assert_close(n1, n0, rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(n1, xh.norm(dim=-1), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(s1, s0, rtol=1e-5, atol=1e-6)
+
+    # the form that hands the codes on (what the module-level path of the bf16 GEMM mode calls): straight-through rows,
+    # normalised rows, the commitment sum from the gathered codes
+    def run_full(training):
+        xn, q = torch.empty_like(xp), torch.empty_like(xp)
+        norm = torch.empty(N, H, device=dev)
+        ind = torch.empty(N, H, dtype=torch.int64, device=dev)
+        sq = torch.empty(1, device=dev)
+        ws = torch.empty(int(lib.stemgnn_vq_workspace_bytes(N, H, Dc, K)), dtype=torch.uint8, device=dev)
+        check(lib.stemgnn_vq_assign_fwd(xp.data_ptr(), N, H, Dc, embed.data_ptr(), K, training, xn.data_ptr(), norm.data_ptr(),
+                                        ind.data_ptr(), q.data_ptr(), sq.data_ptr(), 0.25, ws.data_ptr(), ws.numel(), st))
+        return xn, q, ind, sq, lib.stemgnn_vq_assign_last_path()
+
+    for training in (1, 0):
+        lib.stemgnn_linear_set_library_gemm(0)
+        try:
+            xn0, q0, j0, t0, p0 = run_full(training)
+            lib.stemgnn_linear_set_library_gemm(1)
+            xn1, q1, j1, t1, p1 = run_full(training)
+        finally:
+            lib.stemgnn_linear_set_library_gemm(prev)
+        assert (p0, p1) == (1, 3)
+        same = (j1 == j0).unsqueeze(-1).expand(N, H, Dc).reshape(N, H * Dc)
+        assert float((j1 != j0).float().mean()) < 1e-3
+        torch.testing.assert_close(xn1, xn0, rtol=1e-6, atol=1e-7)
+        torch.testing.assert_close(q1[same], q0[same], rtol=1e-6, atol=1e-6)
+        torch.testing.assert_close(t1, t0, rtol=1e-4, atol=1e-6)
+
+
 @pytest.mark.parametrize("n,e,d", [(300, 2000, 64), (1000, 9000, 128), (50, 0, 32), (40, 300, 256)])
 def test_deterministic_decoder_scatters_match_the_atomic_ones(dev, n, e, d):
     """stemgnn_edge_dot_bwd_det / stemgnn_edge_concat_bwd_det (edges grouped by node, fixed order) against the atomic
