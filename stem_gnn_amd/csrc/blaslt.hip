@@ -170,10 +170,10 @@ int lt_matmul(LtState* s, hipblasOperation_t ta, hipblasOperation_t tb, int64_t 
     if (hipblasLtMatrixLayoutCreate(&lc, HIP_R_32F, m, n, ldc) != HIPBLAS_STATUS_SUCCESS) break;
     hipblasLtMatmulHeuristicResult_t res;
     // batches differ in their row counts by a few per cent from step to step: a kernel is chosen per size BUCKET (the
-    // leading five bits of every large extent), not per size -- the choice is re-made only when a bucket is new
+    // leading four bits of every large extent: 6-12 % wide), not per size -- the choice is re-made only when a bucket is new
     const auto bucket = [](int64_t v) {
       int sh = 0;
-      while ((v >> sh) >= 32) ++sh;
+      while ((v >> sh) >= 16) ++sh;
       return v < 4096 ? v : ((v >> sh) << sh);
     };
     const AlgoKey key{static_cast<int>(ta), static_cast<int>(tb), bucket(m), bucket(n), bucket(k), bias ? 1 : 0};
@@ -321,8 +321,12 @@ int lt_linear_bwd_weight(const float* dy, const void* x, int x_kind, int64_t M, 
     k_round_cat<<<round_grid(M * (N / 4)), kThreads, 0, st>>>(dy, static_cast<int>(N), M, nullptr, kF32, 0, M, gr);
   }
   STEMGNN_LAUNCH_CHECK();
-  k_round_cat<<<round_grid(M * (K / 4)), kThreads, 0, st>>>(nullptr, 0, 0, x, x_kind, static_cast<int>(K), M, xr);
-  STEMGNN_LAUNCH_CHECK();
+  if (x_kind == kBF16) {
+    xr = const_cast<uint16_t*>(static_cast<const uint16_t*>(x));  // stored as bf16 already: the operand as it is
+  } else {
+    k_round_cat<<<round_grid(M * (K / 4)), kThreads, 0, st>>>(nullptr, 0, 0, x, x_kind, static_cast<int>(K), M, xr);
+    STEMGNN_LAUNCH_CHECK();
+  }
   // dw^T (column-major [K, N]) = x^T (column-major [K, M]) dy (column-major [N, M], transposed)
   const int rc = lt_matmul(s, HIPBLAS_OP_N, HIPBLAS_OP_T, K, N, M, xr, K, gr, N, dw, K, nullptr, st);
   if (rc != STEMGNN_OK) return rc;

@@ -1099,6 +1099,26 @@ def test_bf16_gemm_mode_large_products_on_the_vendor_library(dev, m, k1, k2, n, 
         torch.testing.assert_close(got_lib.double(), want, rtol=1e-5, atol=tol, msg=lambda s_: f"{name} (library): {s_}")
         torch.testing.assert_close(got_lib.double(), got_tile.double(), rtol=1e-5, atol=tol,
                                    msg=lambda s_: f"{name} (library vs tile kernel): {s_}")
+    # an operand stored as bf16 (feature_kind 1: C5's hidden activations) goes to the library as it is
+    from stem_gnn_amd._lib import lib, check
+    xb = a.bfloat16().contiguous()
+    st = torch.cuda.current_stream().cuda_stream
+    prev = ops.linear_set_mode(2)
+    try:
+        dws = []
+        for lib_on in (1, 0):
+            was = ops.linear_set_library_gemm(lib_on)
+            dw = torch.empty(n, k1, device=dev)
+            ws = torch.empty(int(lib.stemgnn_linear_bwd_weight_workspace_bytes(m, n, k1)), dtype=torch.uint8, device=dev)
+            check(lib.stemgnn_linear_bwd_weight_k(dy.data_ptr(), xb.data_ptr(), 1, m, n, k1, dw.data_ptr(), None, ws.data_ptr(),
+                                                  ws.numel(), st))
+            dws.append(dw)
+            ops.linear_set_library_gemm(was)
+    finally:
+        ops.linear_set_mode(prev)
+    want = r(dy).t() @ xb.double()
+    torch.testing.assert_close(dws[0].double(), want, rtol=1e-5, atol=2e-5 * float(want.abs().max()))
+    torch.testing.assert_close(dws[0], dws[1], rtol=1e-5, atol=2e-5 * float(want.abs().max()))
 
 
 def test_deterministic_mode_makes_steps_bit_reproducible(dev):
