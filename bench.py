@@ -63,6 +63,9 @@ def parse():
     ap.add_argument("--pmc-traffic", default="auto", choices=["auto", "off"],
                     help="auto (N = 1, c4): measure roofline.traffic live -- two short child runs of this script under "
                          "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes); off: quote profiles/step_traffic.json")
+    ap.add_argument("--preheat", default="auto", choices=["auto", "off"],
+                    help="auto: untimed steps until the step time has settled (>= 0.3 s, <= 1 s), before the counted "
+                         "--warmup; off: the counted warm-up only")
     ap.add_argument("--no-extra", action="store_true", help="skip the K1 legs at C2 / C3 size and the dense-product leg")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
     return ap.parse_args()
@@ -150,7 +153,7 @@ def pmc_step_traffic(args, timeout_s=300):
         d = tempfile.mkdtemp(prefix="stemgnn_pmc_", dir="/tmp")
         cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", counter, "--", sys.executable,
                os.path.abspath(__file__), "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-extra",
-               "--e2e-steps", "0", "--pmc-traffic", "off", "--workload", args.workload, "--batch-size",
+               "--e2e-steps", "0", "--pmc-traffic", "off", "--preheat", "off", "--workload", args.workload, "--batch-size",
                str(args.batch_size), "--gemm", args.gemm, "--feature-dtype", args.feature_dtype]
         try:
             r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
@@ -410,19 +413,52 @@ def main():
     if not wl["full_batch"]:
         pool = torch.empty(6 << 30, dtype=torch.uint8, device=dev)
         del pool
+    # Time-based pre-heat (disclosed as config.preheat_steps / preheat_s; untimed, in ADDITION to the counted --warmup):
+    # on a fresh lease five warm-up steps are 8 ms -- the clocks of a device that has idled through graph generation
+    # have not ramped by then and the first timed steps pay for it (round 3: 1.871 ms on the driver's fresh box
+    # against 1.50-1.60 for the same process a second later).  Untimed steps run in windows of five until at least
+    # PREHEAT_MIN_S have passed AND two consecutive windows agree within 2 %, capped at PREHEAT_MAX_S.  Under DDP
+    # every rank runs the same number of windows (the decision is all-reduced), or the reducers would not pair up.
+    PREHEAT_MIN_S, PREHEAT_MAX_S, WIN = 0.3, 1.0, 5
+    preheat_steps, t_pre, prev_win = 0, time.perf_counter(), None
+    while args.preheat != "off":
+        torch.cuda.synchronize()
+        tw = time.perf_counter()
+        for j in range(WIN):
+            step((preheat_steps + j) % total)
+        torch.cuda.synchronize()
+        now = time.perf_counter()
+        win = now - tw
+        preheat_steps += WIN
+        settled = prev_win is not None and abs(win - prev_win) <= 0.02 * min(win, prev_win)
+        prev_win = win
+        more = 0.0 if (now - t_pre >= PREHEAT_MAX_S or (now - t_pre >= PREHEAT_MIN_S and settled)) else 1.0
+        if world > 1:
+            flag = torch.tensor([more], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            more = float(flag.item())
+        if more == 0.0:
+            break
+    preheat_s = time.perf_counter() - t_pre
     for i in range(args.warmup):
         step(i)
     ops.k1_timer.reset(True)
+    # one HIP event in front of every timed step and one behind the last, on the stream the step's kernels run on
+    # (the library launches on torch's current stream): step_ms / step_ms_median beside the wall mean
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.warmup, total):
+        marks[i - args.warmup].record()
         step(i)
+    marks[args.steps].record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
     gc.enable()
     k1_rows = ops.k1_timer.collect_each()
     ops.k1_timer.reset(False)
@@ -522,9 +558,13 @@ def main():
                        "codebook_size": params["codebook_size"], "code_dim": params["code_dim"],
                        "seeds_per_rank": nb[3], "batch_nodes": int(nb[0].size(0)), "batch_edges": int(nb[1].num_edges),
                        "parallelism": f"dp{world}", "edge_attr": "type-indexed (4E + T*D*4 bytes)",
+                       "preheat_steps": preheat_steps, "preheat_s": round(preheat_s, 3),
                        "loader_ms_per_batch_outside_timed_region": round(sampler_ms, 3),
                        "ms_per_step_with_loader_in_loop": None if e2e_ms is None else round(e2e_ms, 3)},
             "roofline": roofline,
+            # per-step device time (HIP events around every timed step, rank 0); ms_per_step above is the wall mean
+            "step_ms_median": sorted(step_ms)[len(step_ms) // 2] if step_ms else None,
+            "step_ms": [round(v, 4) for v in step_ms],
         }
         # Step-level roofline: the algorithmic bytes of ONE step of this batch shape over the step time
         gs = nb[1]

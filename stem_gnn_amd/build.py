@@ -42,6 +42,9 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
+    if verbose:
+        print(f"compiled {len(procs)} of {len(objs)} sources" + (" (clean build)" if force else
+              ": " + (", ".join(s for s, _ in procs) or "all objects up to date")), flush=True)
     if procs or not os.path.exists(LIB_PATH):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *objs, "-L/opt/rocm/lib", "-lhipblaslt",
                "-Wl,-rpath,/opt/rocm/lib"]

@@ -618,7 +618,7 @@ int stemgnn_sampler_full_hop_sizes(const int32_t* rowptr, const int32_t* n_id, i
                                    int32_t fanout, int64_t frontier_cap, int32_t* cnt, int32_t* ent_base,
                                    int32_t* total, void* stream_) {
   if (!rowptr || !n_id || !state || !cnt || !ent_base || !total || hop < 0 || hop > 13 || frontier_cap <= 0 ||
-      fanout == 0)
+      fanout == 0 || fanout > kMaxFanout)
     return STEMGNN_ERR_INVALID_ARG;
   if (!fits_i32(frontier_cap)) return STEMGNN_ERR_TOO_LARGE;
   hipStream_t st = static_cast<hipStream_t>(stream_);
@@ -639,7 +639,7 @@ int stemgnn_sampler_full_hop_expand(const int32_t* rowptr, const int32_t* src, c
                                     int32_t* s_type, int32_t* wins, int32_t* new_base, int32_t* local_of,
                                     int32_t* nodes_after, void* stream_) {
   if (!rowptr || !src || !n_id || !state || !cnt || !ent_base || !wins || !new_base || !local_of || hop < 0 || hop > 13 ||
-      frontier_cap <= 0 || entries < 0 || fanout == 0 || (entries > 0 && (!s_src || !s_type)))
+      frontier_cap <= 0 || entries < 0 || fanout == 0 || fanout > kMaxFanout || (entries > 0 && (!s_src || !s_type)))
     return STEMGNN_ERR_INVALID_ARG;
   if (!fits_i32(frontier_cap) || !fits_i32(entries + 2) || !fits_i32(n_cap)) return STEMGNN_ERR_TOO_LARGE;
   hipStream_t st = static_cast<hipStream_t>(stream_);

@@ -31,6 +31,18 @@ class Batch:
     cap_nodes: int = 0        # the most nodes a batch of this many seeds / these fan-outs can have (buffer sizing)
 
 
+MAX_FANOUT = 32  # csrc/sampler.hip kMaxFanout: a row's picks live in a register array of this size
+
+
+def _check_fanouts(num_neighbors) -> List[int]:
+    """-1 (every in-neighbour) or 1 .. MAX_FANOUT per hop; anything else is rejected here, before a launch."""
+    f = [int(v) for v in num_neighbors]
+    bad = [v for v in f if v == 0 or v < -1 or v > MAX_FANOUT]
+    if bad:
+        raise ValueError(f"fan-out must be -1 or 1..{MAX_FANOUT} per hop, got {f}")
+    return f
+
+
 class HipNeighborSampler:
     """The same contract on the fused HIP sampler (csrc/sampler.hip): the full graph's by-target
     CSR and edge types stay resident in HBM, a batch is 13 launches (two hops) whose sizes (12 bytes) land in pinned
@@ -40,7 +52,7 @@ class HipNeighborSampler:
     def __init__(self, edge_index: Tensor, xe: Tensor, num_nodes: int, x: Tensor, node_text_feat: Tensor,
                  edge_text_feat: Tensor, num_neighbors: List[int], seed: int = 0):
         self.num_nodes = num_nodes
-        self.fanouts = [int(f) for f in num_neighbors]
+        self.fanouts = _check_fanouts(num_neighbors)
         rowptr, src, eid, _ = ops.csr_build(edge_index.contiguous(), num_nodes, 1)
         # a graph without edges still gets a one-slot array: the library takes a null source array for a bad argument
         self.rowptr, self.src = rowptr, (src if src.numel() else torch.zeros(1, dtype=torch.int32, device=src.device))
@@ -61,12 +73,16 @@ class HipNeighborSampler:
         self.batch_max_in_degree, self.batch_max_out_degree = int(min(cap, d_in)), int(d_out)
 
     def with_fanouts(self, num_neighbors: List[int]) -> "HipNeighborSampler":
-        """A sampler over the SAME resident graph (CSR, edge types, scratch map shared) with other fan-outs -- the
-        reference builds its training loader ([10] * L or [30] * L) and its evaluation loader ([-1] * L) over one ``data``
-        object (utils/loader.py:10-25)."""
+        """A sampler over the SAME resident graph (CSR and edge types shared) with other fan-outs -- the reference
+        builds its training loader ([10] * L or [30] * L) and its evaluation loader ([-1] * L) over one ``data`` object
+        (utils/loader.py:10-25).  The derived sampler gets its OWN scratch map and draw counter: a training loader's
+        prefetched batch may still be in flight on its side stream when the evaluation sampler starts claiming entries
+        on the main stream, and nothing orders the two."""
         other = object.__new__(HipNeighborSampler)
         other.__dict__.update(self.__dict__)
-        other.fanouts = [int(f) for f in num_neighbors]
+        other.fanouts = _check_fanouts(num_neighbors)
+        other.local_of = ops.sampler_init_map(self.num_nodes, self.rowptr.device)
+        other.seed, other.calls = self.seed + 0x9E3779B1, 0
         d_in = int((self.rowptr[1:] - self.rowptr[:-1]).max()) if self.num_nodes else 0
         cap = max((f if f >= 0 else d_in) for f in other.fanouts) if other.fanouts else 0
         other.batch_max_in_degree = int(min(cap, d_in))
@@ -274,20 +290,26 @@ class PrefetchLoader:
         it = pending_iter() if pending_iter is not None else iter(self.loader)
         nxt = self._finish(self._launch(it))
         ahead = self._launch(it)  # launches in flight, sizes not read yet
-        while nxt is not None:
-            cur = nxt
-            main = torch.cuda.current_stream(self.device)
-            main.wait_event(cur.ready)
-            seen = set()  # one record per allocation: a sampler batch is views of one slab (+ the prepared features)
-            for name in self.uses:
-                v = getattr(cur, name, None)
-                if isinstance(v, Tensor):
-                    if v.is_cuda and v.untyped_storage().data_ptr() not in seen:
-                        seen.add(v.untyped_storage().data_ptr())
-                        v.record_stream(main)
-                elif v is not None:
-                    v.record_stream(main, seen)
-            # before the caller's step, so that all of it overlaps the steps still queued on the device
-            nxt = self._finish(ahead)
-            ahead = self._launch(it) if nxt is not None else None
-            yield cur
+        try:
+            while nxt is not None:
+                cur = nxt
+                main = torch.cuda.current_stream(self.device)
+                main.wait_event(cur.ready)
+                seen = set()  # one record per allocation: a sampler batch is views of one slab (+ the prepared features)
+                for name in self.uses:
+                    v = getattr(cur, name, None)
+                    if isinstance(v, Tensor):
+                        if v.is_cuda and v.untyped_storage().data_ptr() not in seen:
+                            seen.add(v.untyped_storage().data_ptr())
+                            v.record_stream(main)
+                    elif v is not None:
+                        v.record_stream(main, seen)
+                # before the caller's step, so that all of it overlaps the steps still queued on the device
+                nxt = self._finish(ahead)
+                ahead = self._launch(it) if nxt is not None else None
+                yield cur
+        finally:
+            # a consumer that stops early (break, exception, generator closed) leaves batches in flight on the side
+            # stream; whoever uses the sampler next -- on any stream -- must come after them: the sampler's scratch map is
+            # only back in its idle state when a batch's last launch has run
+            torch.cuda.current_stream(self.device).wait_stream(self.side)

@@ -15,6 +15,9 @@ CASES = {
     # of the weight-stationary assignment kernel (csrc/wsgemm.hip: K = Dc = 128, N >= 16 384) with a ragged last tile
     "k512": (1000, 128, 4, 512, 128, 32),
     "ws": (16500, 128, 4, 128, 128, 32),
+    # round 4: reaches the large-codebook assignment (K >= 512 and Dc >= 256 with >= 8 192 rows: BASELINE configs 3 / 5
+    # take that path), ragged in its last 128-row and 256-row tiles
+    "big": (9000, 256, 2, 512, 256, 32),
 }
 
 

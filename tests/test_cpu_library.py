@@ -71,6 +71,18 @@ def test_sampler_argument_validation_and_output_plan(L):
     assert lib.stemgnn_graph_dropout_undirected_rows(None, None, None, None, None, None, None, None, -1, 0, 0, 0.2, 1, 2,
                                                      None, one, None, None, None, None, None, None, None, None, 0,
                                                      None) == -1
+    # the sized-per-hop (fan-out -1) path bounds a positive fan-out like the fixed path does (advisor, round 3: a
+    # fan-out of 33 mixed with a -1 overran the per-row pick array): the library and the Python front both refuse it
+    state = one
+    assert lib.stemgnn_sampler_full_hop_sizes(one, one, state, 0, 33, 8, one, one, one, None) == -1
+    assert lib.stemgnn_sampler_full_hop_sizes(one, one, state, 0, 0, 8, one, one, one, None) == -1
+    assert lib.stemgnn_sampler_full_hop_expand(one, one, None, one, 100, state, 0, 33, 1, 2, 8, 8, 100, one, one, one,
+                                               one, one, one, one, one, None) == -1
+    from stem_gnn_amd.data.sampler import _check_fanouts
+    assert _check_fanouts([-1, 32, 1]) == [-1, 32, 1]
+    for bad_fan in ([-1, 33], [0, 10], [-2]):
+        with pytest.raises(ValueError):
+            _check_fanouts(bad_fan)
     plan = _SamplerPlan.of(1024, [10, 10])
     assert (plan.cn, plan.ce) == (1024 * 111, 1024 * 110) and plan.ws_bytes == lib.stemgnn_sampler_workspace_bytes(1024, 2, 10)
     want = dict(coo=16 * plan.ce, n_id64=8 * plan.cn, x=8 * plan.cn, type64=8 * plan.ce, n_id=4 * plan.cn,

@@ -84,7 +84,7 @@ def load_prod(path):
 
 
 def test_prod_fixtures_present():
-    assert [os.path.basename(p) for p in PROD] == ["prod_vq_k512_s0.pt", "prod_vq_k512_s1.pt", "prod_vq_ws_s0.pt"]
+    assert [os.path.basename(p) for p in PROD] == ["prod_vq_big_s0.pt", "prod_vq_k512_s0.pt", "prod_vq_k512_s1.pt", "prod_vq_ws_s0.pt"]
     assert all(os.path.getsize(p) < (1 << 20) for p in PROD)
 
 
