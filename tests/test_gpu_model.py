@@ -189,6 +189,8 @@ def test_vq_matches_reference_golden_at_production_shapes(dev, path, gemm_mode, 
         served_by = int(lib.stemgnn_vq_assign_last_path())
         if lean and gemm_mode == 1 and K == 128 and Dc == 128 and N >= 16384:
             assert served_by == 2, "the weight-stationary assignment kernel must serve the production-shape case"
+        elif gemm_mode == 1 and K >= 512 and Dc >= 256 and N >= 8192:
+            assert served_by in (3, 4), "the large-codebook assignment must serve the (9000, 256, 2, 512, 256) case"
         elif lean:
             assert served_by == 1
         flips = assert_indices_match(ind.cpu(), want_ind, gap)
