@@ -351,12 +351,25 @@ int stemgnn_dropout_keep_mask(int64_t n, float p, uint64_t seed, uint64_t offset
  * queries.  Returns the previous mode.  The tile plan (stemgnn_linear_stats_blocks) depends on the mode: set it
  * before sizing buffers.  STEMGNN_GEMM=f32 / bf16 in the environment starts the process in mode 0 / 2. */
 int stemgnn_linear_set_mode(int mode);
-/* Mode 2 only: large products (>= 8 192 rows, >= 2.5e10 flop) take a rounding pass + hipblasLtMatmul (bf16 operands, fp32
- * accumulation and output: the same product the tile kernel forms, 2.2-2.4x faster at the D = 768 shapes) unless
- * switched off here (on = 0; 1 = default; any other value only queries).  Returns the previous setting. */
-int stemgnn_linear_set_library_gemm(int on);
-/* Products the vendor library has served in this process so far (tests prove the path was taken with it). */
-int64_t stemgnn_linear_library_calls(void);
+/* Large products (>= 8 192 rows, both feature extents >= 256 and multiples of 64, >= 2.5e10 flop: the D = 768
+ * configurations) run on the big-tile core (csrc/bigtile.hip: one hand-written 256 x 256 x 64 bf16 MFMA GEMM over
+ * operands cut into bf16 planes by a cut pass) in mode 1 (the six exact piece products as one contraction of 6 K) and
+ * mode 2 (one rounded plane) alike.  Its scratch -- the planes, the weight gradient's split slabs -- comes from the
+ * CALLER: one arena per (device, stream), registered with stemgnn_linear_set_scratch and sized by
+ * stemgnn_linear_scratch_bytes(rows, a, b) (an upper bound for every product y = x w^T, its backward-data and its weight
+ * gradient with at most `rows` rows and feature extents a x b, either way round) and, for the quantiser's code
+ * assignment at large codebooks, stemgnn_vq_assign_scratch_bytes.  The library never allocates, frees or synchronises
+ * for it; the arena must stay valid until the stream has run the products enqueued while it was registered (NULL
+ * unregisters).  A qualifying product that finds no arena, or one too small, runs on the 128-row tile kernels and is
+ * counted in stemgnn_linear_bigtile_fallbacks -- a capacity miss the host can see, never an error swallowed: every other
+ * failure of the core is returned.  stemgnn_linear_set_bigtile(0) switches the core off (1 = default; other values only
+ * query; returns the previous setting); stemgnn_linear_bigtile_calls counts the products it has served. */
+size_t stemgnn_linear_scratch_bytes(int64_t max_rows, int64_t dim_a, int64_t dim_b);
+size_t stemgnn_vq_assign_scratch_bytes(int64_t num_rows, int64_t heads, int64_t code_dim, int64_t codebook_size);
+int stemgnn_linear_set_scratch(void* scratch, size_t bytes, void* stream);
+int stemgnn_linear_set_bigtile(int on);
+int64_t stemgnn_linear_bigtile_calls(void);
+int64_t stemgnn_linear_bigtile_fallbacks(void);
 
 /* y [M, N] = x1 [M, K1] w1[N, K1]^T (+ x2 [M, K2] w2 [N, K2]^T when K2 > 0) + bias [N] (NULL: none).
  * stats_partial (may be NULL): receives per-row-block column sums / sums of squares of y,
@@ -463,11 +476,11 @@ int stemgnn_transpose(const float* in, int64_t rows, int64_t cols, float* out, v
  * ------------------------------------------------------------------------------------ */
 size_t stemgnn_vq_workspace_bytes(int64_t num_rows, int64_t heads, int64_t code_dim, int64_t codebook_size);
 /* Which kernel the calling thread's most recent stemgnn_vq_assign_fwd / _lean call launched: 0 none yet, 1 the tile
- * form (k_vq_assign), 2 the weight-stationary form (k_vq_assign_ws: K = Dc = 128, >= 16 384 rows), 3 the large-codebook
- * form (lean assignment, K >= 512, Dc >= 256, >= 8 192 rows: the six exact piece products as one hipBLASLt GEMM over a
- * contraction of 6 Dc, then arg-max and commitment terms off the similarity matrix; stemgnn_linear_set_library_gemm(0)
- * keeps it on the tile form).  The golden tests use it to make sure a production-shape fixture was served by the
- * production kernel. */
+ * form (k_vq_assign), 2 the weight-stationary form (k_vq_assign_ws: K = Dc = 128, >= 16 384 rows), 4 the large-codebook
+ * form (K >= 512, Dc >= 256, >= 8 192 rows, a scratch arena registered: the six exact piece products of all heads as one
+ * launch of the big-tile core, the arg-max taken from the accumulators per 256-code tile -- no [N, K] similarity matrix
+ * --, one finishing pass; stemgnn_linear_set_bigtile(0) keeps it on the tile form).  The golden tests use it to make
+ * sure a production-shape fixture was served by the production kernel. */
 int stemgnn_vq_assign_last_path(void);
 
 int stemgnn_vq_assign_fwd(const float* xp, int64_t num_rows, int64_t heads, int64_t code_dim,

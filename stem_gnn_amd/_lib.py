@@ -165,8 +165,12 @@ _SIGNATURES = {
     "stemgnn_grad_norm_coef": (c_int, [P, P, I32, c_float, P, P, c_size_t, P]),
     "stemgnn_adamw_step": (c_int, [P, P, P, P, P, I32, c_float, c_float, c_float, c_float, c_float, I64, P, P]),
     "stemgnn_linear_set_mode": (c_int, [c_int]),
-    "stemgnn_linear_set_library_gemm": (c_int, [c_int]),
-    "stemgnn_linear_library_calls": (I64, []),
+    "stemgnn_linear_scratch_bytes": (c_size_t, [I64, I64, I64]),
+    "stemgnn_vq_assign_scratch_bytes": (c_size_t, [I64, I64, I64, I64]),
+    "stemgnn_linear_set_scratch": (c_int, [P, c_size_t, P]),
+    "stemgnn_linear_set_bigtile": (c_int, [c_int]),
+    "stemgnn_linear_bigtile_calls": (I64, []),
+    "stemgnn_linear_bigtile_fallbacks": (I64, []),
     "stemgnn_linear_bwd_data": (c_int, [P, P, I64, I64, I64, P, P]),
     "stemgnn_linear_fwd": (c_int, [P, P, I64, P, P, I64, P, I64, I64, P, P, P, I64, P]),
     "stemgnn_linear_fwd_rows": (c_int, [P, P, I64, P, P, I64, P, I64, I64, P, P, P, I64, I64, P]),

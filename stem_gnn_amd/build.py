@@ -13,7 +13,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libstemgnn_hip.so")
-SOURCES = ["graph_build.hip", "sage_agg.hip", "bn_act.hip", "vq.hip", "edge_ops.hip", "linear.hip", "graph_aug.hip", "sampler.hip", "loss_ops.hip", "optim_ops.hip", "phases.hip", "heads.hip", "wsgemm.hip", "blaslt.hip"]
+SOURCES = ["graph_build.hip", "sage_agg.hip", "bn_act.hip", "vq.hip", "edge_ops.hip", "linear.hip", "graph_aug.hip", "sampler.hip", "loss_ops.hip", "optim_ops.hip", "phases.hip", "heads.hip", "wsgemm.hip", "bigtile.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-fno-gpu-rdc", "-munsafe-fp-atomics"]
@@ -46,8 +46,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         print(f"compiled {len(procs)} of {len(objs)} sources" + (" (clean build)" if force else
               ": " + (", ".join(s for s, _ in procs) or "all objects up to date")), flush=True)
     if procs or not os.path.exists(LIB_PATH):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *objs, "-L/opt/rocm/lib", "-lhipblaslt",
-               "-Wl,-rpath,/opt/rocm/lib"]
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *objs]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

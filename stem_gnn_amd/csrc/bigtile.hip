@@ -1,0 +1,976 @@
+// The big-tile product core (round 4): one hand-written bf16 MFMA GEMM for the LARGE dense products of the path -- the
+// D = 768 configurations (BASELINE configs 3 and 5, the reference's own default width, config/pretrain.yaml:3-16) --
+// used by the projections (nn.Linear forward / backward-data / weight gradient: STEM-GNN/model/encoder.py:83-87,
+// model/vq.py:881,1041, model/pt_model.py:42,80,94) AND by the quantiser's code assignment (model/vq.py:650-657), where
+// the arg-max over the codes is taken from the accumulators: no [N, K] similarity matrix exists.  It replaces the
+// vendor-library wrapper of round 3 (csrc/blaslt.hip, deleted): nothing on the path is a library GEMM any more.
+//
+//   C[i][j] = sum over segments s, k:  A_{pa(s)}[i][k] * B_{pb(s)}[j][k]          ("NT": both operands k-contiguous)
+//
+// Operands are bf16 PLANES written once by a cut pass (k_bt_cut_*): in the exact mode (stemgnn_linear_set_mode(1)) an
+// fp32 operand is its three exact pieces h + m + l (common.h) and the product is the six significant piece products,
+// small terms first -- here six SEGMENTS of one contraction, i.e. ONE bf16 GEMM over 6 K with the operands read from
+// three planes each (nothing is concatenated in memory); in the bf16 GEMM mode (mode 2) one rounded plane, one segment.
+// At D = 768 the products are matrix-bound, so the plane traffic the round-2 plane kernels lost on (D = 128: HBM-bound)
+// is noise here: 0.8 GB of planes against 4.8 PFLOP of executed matrix work for project_in at C3 size.
+//
+// Tile: 256 x 256 x 64 per 512-thread block (8 waves as 2 (a rows) x 4 (b rows); a wave owns 128 x 64 of C as 8 x 4
+// accumulators of v_mfma_f32_16x16x32_bf16), LDS 128 KiB = 2 buffers x 4 half tiles (128 rows x 128 B each), filled by
+// LDS-DMA (global_load_lds_dwordx4: no VGPR round trip), XOR-swizzled on the SOURCE address and on the read (the DMA
+// writes lane-linear), fragments by ds_read_b128 (conflict-free: chunk ^= (row >> 1) & 7).
+// Schedule (after MI355X cdna_hip_programming.md section 5, "256^2 8-phase template", re-derived for this staging
+// order): a K tile is four phases, one C quadrant (64 x 32 per wave, 16 MFMAs) each; every phase is
+//     { ds_read this quadrant's new fragments | stage ONE half tile (2 DMAs per wave) | s_waitcnt vmcnt(8) }
+//     s_barrier  { s_waitcnt lgkmcnt(0); 16 MFMAs }  s_barrier
+// and waves 4-7 run ONE BARRIER BEHIND waves 0-3, so that on every SIMD one wave multiplies while its partner loads.
+// Half tiles are interleaved row sets chosen so that each is read in ONE phase only (A0: phase 0, B0: phase 0 -- its
+// fragments stay in registers for phase 3 --, B1: phase 1, A1: phase 2); a slot is re-staged at least two phases after
+// its last read (the guide's rule for staggered wave groups) and read at the earliest one phase after the wait that
+// retires it: phase 0 stages B1(t+1), 1: A1(t+1), 2: A0(t+2), 3: B0(t+2); with one half tile per phase, "all but the
+// four youngest half tiles have landed" (vmcnt(8)) is exactly what the next phase's reads need.
+#include "common.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <atomic>
+#include <map>
+#include <mutex>
+#include <utility>
+
+namespace stemgnn {
+namespace {
+
+constexpr int kBtThreads = 512;
+constexpr int kTile = 256;                  // C tile edge
+constexpr int kBK = 64;                     // contraction elements per K tile (128-byte rows)
+constexpr int kHalfBytes = 128 * 128;       // one half tile: 128 rows x 128 B
+constexpr int kBufBytes = 4 * kHalfBytes;   // A0 | A1 | B0 | B1
+constexpr int kBtLds = 2 * kBufBytes;       // 128 KiB
+constexpr int kMaxSeg = 12;
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+struct BtOp {
+  const uint16_t* p;  // element (plane, row, k) at p + plane * ps + row * ld + k
+  int64_t ps;         // plane stride, elements
+  int64_t ld;         // row stride, elements (multiple of 8: 16-byte chunks)
+  int64_t rows;       // rows of the operand; tile rows past them are clamped reads the epilogue masks
+  int64_t bs;         // batch stride, elements
+};
+// one stretch of the contraction: planes (pa, pb), K tiles [k0, k0 + kt); (k0z, ktz) is the stretch for b-row tiles
+// at or past BtArgs::b_full_rows (rows of a concatenated operand whose leading part is known to be zero there)
+struct BtSeg { int pa, pb, k0, kt, k0z, ktz; };
+
+enum { kEpiStore = 0, kEpiArgmax = 1 };
+
+struct BtArgs {
+  BtOp a, b;
+  BtSeg seg[kMaxSeg];
+  int nseg, tiles_m, tiles_n, splits, batch;
+  int64_t b_full_rows;
+  // kEpiStore: y[bz * y_bs + split * y_ss + j * ldy + i] = C[i][j] (+ bias[i]) for j < store_rows; stats (optional):
+  // per b-row tile column sums / sums of squares over the rows j < b.rows: stats[tn][2][a.rows]
+  float* y;
+  int64_t ldy, y_bs, y_ss, store_rows;
+  const float* bias;
+  float* stats;
+  // kEpiArgmax: per (batch, b row, a tile) the largest C[i][j] over the tile's valid a rows and the lowest i reaching it
+  float* cand_val;
+  int32_t* cand_idx;
+  int dbg;  // measurement only (STEMGNN_BT_DBG): 1 = no output stores, 2 = no statistics
+};
+
+__device__ __forceinline__ void bt_dma16(const uint16_t* src, unsigned char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int EPI>
+__global__ void __launch_bounds__(kBtThreads) k_bt_gemm(const BtArgs g) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];  // the ONLY LDS object of this kernel
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid >> 2, wc = wid & 3;
+  const int fr = lane & 15, fq = lane >> 4;
+
+  // ---- block -> (batch, split, a tile, b tile): blocks that share an XCD (bid % 8) take consecutive work ids, and
+  // consecutive ids walk patches of 4 b tiles x all a tiles, so co-resident blocks share operand panels in their L2
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int per = g.tiles_m * g.tiles_n;
+  const int outer = wg / per, rem = wg - outer * per;
+  const int bz = outer / g.splits, split = outer - bz * g.splits;
+  constexpr int PW = 4;
+  const int patch = rem / (PW * g.tiles_m);
+  const int pw = min(PW, g.tiles_n - patch * PW);
+  const int idx = rem - patch * PW * g.tiles_m;
+  const int tn = patch * PW + idx % pw, tm = idx / pw;
+  const bool zrange = static_cast<int64_t>(tn) * kTile >= g.b_full_rows;
+
+  // ---- staging: a half tile is 16 one-KB pieces (8 rows x 128 B); wave w moves pieces w and w + 8.  Lane -> row
+  // (lane >> 3) of the piece, LDS chunk (lane & 7); it FETCHES source chunk (lane & 7) ^ ((row >> 1) & 7).
+  // Half-tile row rho of half h is tile row (rho >> 6) * 128 + h * 64 + (rho & 63) of a, (rho >> 5) * 64 + h * 32 + (rho & 31) of b.
+  const uint16_t* const abase = g.a.p + static_cast<int64_t>(bz) * g.a.bs;
+  const uint16_t* const bbase = g.b.p + static_cast<int64_t>(bz) * g.b.bs;
+  uint32_t offA[2][2], offB[2][2];
+  {
+    const int r0 = wid * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((r0 >> 1) & 7);
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int rho = r0 + 64 * j;
+        const int64_t ra = min(static_cast<int64_t>(tm) * kTile + (rho >> 6) * 128 + h * 64 + (rho & 63), g.a.rows - 1);
+        const int64_t rb = min(static_cast<int64_t>(tn) * kTile + (rho >> 5) * 64 + h * 32 + (rho & 31), g.b.rows - 1);
+        offA[h][j] = static_cast<uint32_t>(ra * g.a.ld + chunk * 8);
+        offB[h][j] = static_cast<uint32_t>(rb * g.b.ld + chunk * 8);
+      }
+  }
+  unsigned char* const dma0 = smem + wid * 1024;  // this wave's first piece of half tile 0 of buffer 0
+
+  // ---- the contraction as a list of K tiles: cursor over the segments
+  int T = 0;
+  for (int s = 0; s < g.nseg; ++s) T += (zrange ? g.seg[s].ktz : g.seg[s].kt) / g.splits;
+  int si = 0, kk = 0;
+  int cur_kt = 0;
+  int64_t cur_a = 0, cur_b = 0;  // element offsets of the cursor segment's K tile 0 (this split)
+  auto seg_load = [&]() {
+    const BtSeg sg = g.seg[si < g.nseg ? si : g.nseg - 1];
+    cur_kt = (zrange ? sg.ktz : sg.kt) / g.splits;
+    const int64_t k0 = static_cast<int64_t>(zrange ? sg.k0z : sg.k0) + static_cast<int64_t>(split) * cur_kt;
+    cur_a = sg.pa * g.a.ps + k0 * kBK;
+    cur_b = sg.pb * g.b.ps + k0 * kBK;
+  };
+  auto cursor_next = [&]() {  // to the next K tile with cur_kt > 0 (segments may be empty in the z range)
+    ++kk;
+    while (kk >= cur_kt && si < g.nseg) { ++si; kk = 0; seg_load(); }
+  };
+  seg_load();
+  while (cur_kt == 0 && si < g.nseg) { ++si; seg_load(); }
+
+  floatx4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+  if (T > 0) {
+    // ---- prologue: tile 0 whole (A0 B0 B1 A1) and A0, B0 of tile 1
+    int64_t oa = cur_a + static_cast<int64_t>(kk) * kBK, ob = cur_b + static_cast<int64_t>(kk) * kBK;
+#define BT_STAGE_A(BUF, H, OA)                                                                    \
+  do {                                                                                            \
+    bt_dma16(abase + (OA) + offA[H][0], dma0 + (BUF) * kBufBytes + (H) * kHalfBytes);            \
+    bt_dma16(abase + (OA) + offA[H][1], dma0 + (BUF) * kBufBytes + (H) * kHalfBytes + 8192);     \
+  } while (0)
+#define BT_STAGE_B(BUF, H, OB)                                                                    \
+  do {                                                                                            \
+    bt_dma16(bbase + (OB) + offB[H][0], dma0 + (BUF) * kBufBytes + (2 + (H)) * kHalfBytes);      \
+    bt_dma16(bbase + (OB) + offB[H][1], dma0 + (BUF) * kBufBytes + (2 + (H)) * kHalfBytes + 8192); \
+  } while (0)
+    BT_STAGE_A(0, 0, oa);
+    BT_STAGE_B(0, 0, ob);
+    BT_STAGE_B(0, 1, ob);
+    BT_STAGE_A(0, 1, oa);
+    cursor_next();
+    // offsets of tile t + 1 (o*1) and t + 2 (o*2) while tile t is multiplied; past the end they repeat the last tile
+    // and are never used (the staging that would read them is skipped)
+    int64_t oa1 = cur_a + static_cast<int64_t>(kk) * kBK, ob1 = cur_b + static_cast<int64_t>(kk) * kBK;
+    if (T > 1) {
+      BT_STAGE_A(1, 0, oa1);
+      BT_STAGE_B(1, 0, ob1);
+      cursor_next();
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    int64_t oa2 = cur_a + static_cast<int64_t>(kk) * kBK, ob2 = cur_b + static_cast<int64_t>(kk) * kBK;
+    __builtin_amdgcn_s_barrier();            // every wave's share of tile 0 is in LDS
+    if (wr == 1) __builtin_amdgcn_s_barrier();  // waves 4-7 run one barrier behind: they load while waves 0-3 multiply
+
+    // ---- per-lane fragment addresses: row fr of a 16-row group, 16-byte chunk (s * 4 + fq) ^ (fr >> 1)
+    const int roff = fr * 128 + ((fq ^ (fr >> 1)) << 4);
+    const unsigned char* const ra0 = smem + wr * 64 * 128 + roff;                       // A half h: + h * kHalfBytes
+    const unsigned char* const rb0 = smem + 2 * kHalfBytes + wc * 32 * 128 + roff;      // B half h: + h * kHalfBytes
+    bf16x8 fa[4][2], fb[2][2][2];
+
+#define BT_READ_A(BUF, MH)                                                                                        \
+  _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                              \
+    fa[i_][0] = *reinterpret_cast<const bf16x8*>(ra0 + (BUF) * kBufBytes + (MH) * kHalfBytes + i_ * 2048);       \
+    fa[i_][1] = *reinterpret_cast<const bf16x8*>((ra0 + (BUF) * kBufBytes + (MH) * kHalfBytes + i_ * 2048) + (64 - 2 * ((roff) & 64))); \
+  }
+#define BT_READ_B(BUF, NH)                                                                                        \
+  _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                                              \
+    fb[NH][j_][0] = *reinterpret_cast<const bf16x8*>(rb0 + (BUF) * kBufBytes + (NH) * kHalfBytes + j_ * 2048);   \
+    fb[NH][j_][1] = *reinterpret_cast<const bf16x8*>((rb0 + (BUF) * kBufBytes + (NH) * kHalfBytes + j_ * 2048) + (64 - 2 * ((roff) & 64))); \
+  }
+#define BT_MFMA(MH, NH)                                                                                           \
+  do {                                                                                                            \
+    __builtin_amdgcn_s_barrier();                                                                                 \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                            \
+    __builtin_amdgcn_s_setprio(1);                                                                                \
+    _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)                                                              \
+      _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                            \
+        _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                          \
+          acc[(MH) * 4 + i_][(NH) * 2 + j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                           \
+              fa[i_][s_], fb[NH][j_][s_], acc[(MH) * 4 + i_][(NH) * 2 + j_], 0, 0, 0);                           \
+    __builtin_amdgcn_s_setprio(0);                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                            \
+    __builtin_amdgcn_s_barrier();                                                                                 \
+  } while (0)
+#define BT_WAIT(STAGED)                                                   \
+  do {                                                                    \
+    if (STAGED) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");          \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 \
+  } while (0)
+#define BT_TILE(BUF)                                                      \
+  do {                                                                    \
+    const bool ok1 = t + 1 < T, ok2 = t + 2 < T;                          \
+    /* phase 0: quadrant (0, 0) */                                        \
+    BT_READ_B(BUF, 0);                                                    \
+    BT_READ_A(BUF, 0);                                                    \
+    if (ok1) BT_STAGE_B((BUF) ^ 1, 1, ob1);                               \
+    BT_WAIT(ok1);                                                         \
+    BT_MFMA(0, 0);                                                        \
+    /* phase 1: quadrant (0, 1) */                                        \
+    BT_READ_B(BUF, 1);                                                    \
+    if (ok1) BT_STAGE_A((BUF) ^ 1, 1, oa1);                               \
+    BT_WAIT(ok1);                                                         \
+    BT_MFMA(0, 1);                                                        \
+    /* phase 2: quadrant (1, 1) */                                        \
+    BT_READ_A(BUF, 1);                                                    \
+    if (ok2) BT_STAGE_A(BUF, 0, oa2);                                     \
+    BT_WAIT(ok2);                                                         \
+    BT_MFMA(1, 1);                                                        \
+    /* phase 3: quadrant (1, 0): B0's fragments are still in registers */ \
+    if (ok2) BT_STAGE_B(BUF, 0, ob2);                                     \
+    BT_WAIT(ok2);                                                         \
+    BT_MFMA(1, 0);                                                        \
+    ++t;                                                                  \
+    oa1 = oa2; ob1 = ob2;                                                 \
+    if (ok2) cursor_next();                                               \
+    oa2 = cur_a + static_cast<int64_t>(kk) * kBK;                         \
+    ob2 = cur_b + static_cast<int64_t>(kk) * kBK;                         \
+  } while (0)
+
+    int t = 0;
+    while (t < T) {
+      BT_TILE(0);
+      if (t < T) BT_TILE(1);
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();  // the barrier waves 4-7 took first
+#undef BT_TILE
+#undef BT_WAIT
+#undef BT_MFMA
+#undef BT_READ_A
+#undef BT_READ_B
+#undef BT_STAGE_A
+#undef BT_STAGE_B
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();  // LDS is free: every wave's DMAs have landed, every wave is done reading
+
+  // ---- epilogues.  acc[mi][nj][r] = C[i][j]: i = tm * 256 + wr * 128 + mi * 16 + fq * 4 + r, j = tn * 256 + wc * 64 + nj * 16 + fr
+  const int64_t i_wave = static_cast<int64_t>(tm) * kTile + wr * 128 + fq * 4;
+  const int64_t j_wave = static_cast<int64_t>(tn) * kTile + wc * 64 + fr;
+  if (EPI == kEpiStore) {
+    float* const y = g.y + static_cast<int64_t>(bz) * g.y_bs + static_cast<int64_t>(split) * g.y_ss;
+    float s1[8][4], s2[8][4];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+      const int64_t i = i_wave + mi * 16;
+      const bool iok = i < g.a.rows;  // a.rows is a multiple of 4 (host-checked): the four values share the verdict
+      float4 bv = zero4();
+      if (g.bias && iok) bv = ld4(g.bias + i);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s1[mi][r] = s2[mi][r] = 0.f;
+#pragma unroll
+      for (int nj = 0; nj < 4; ++nj) {
+        const int64_t j = j_wave + nj * 16;
+        const float4 v = make_float4(acc[mi][nj][0] + bv.x, acc[mi][nj][1] + bv.y, acc[mi][nj][2] + bv.z,
+                                     acc[mi][nj][3] + bv.w);
+        if (iok && j < g.store_rows && !(g.dbg & 1)) st4(y + j * g.ldy + i, v);
+        if (g.stats && j < g.b.rows && !(g.dbg & 2)) {
+          s1[mi][0] += v.x; s1[mi][1] += v.y; s1[mi][2] += v.z; s1[mi][3] += v.w;
+          s2[mi][0] += v.x * v.x; s2[mi][1] += v.y * v.y; s2[mi][2] += v.z * v.z; s2[mi][3] += v.w * v.w;
+        }
+      }
+    }
+    if (g.stats && !(g.dbg & 2)) {
+      // over the 16 lanes that share fq (the b rows of a 16-column group), then over the four waves of this a half
+      // through LDS, in fixed order: slab [tn][2][a.rows]
+      float* const red = reinterpret_cast<float*>(smem);  // [2 stats][8 waves][128 i]
+#pragma unroll
+      for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float a = s1[mi][r], b = s2[mi][r];
+#pragma unroll
+          for (int o = 1; o < 16; o <<= 1) {
+            a += __shfl_xor(a, o, 64);
+            b += __shfl_xor(b, o, 64);
+          }
+          if (fr == 0) {
+            red[(0 * 8 + wid) * 128 + mi * 16 + fq * 4 + r] = a;
+            red[(1 * 8 + wid) * 128 + mi * 16 + fq * 4 + r] = b;
+          }
+        }
+      __syncthreads();
+      // 512 threads: (stat, a half, 128 i)
+      const int st = tid >> 8, half = (tid >> 7) & 1, il = tid & 127;
+      const int64_t i = static_cast<int64_t>(tm) * kTile + half * 128 + il;
+      if (i < g.a.rows) {
+        const float* rr = red + (st * 8 + half * 4) * 128 + il;
+        g.stats[(static_cast<int64_t>(tn) * 2 + st) * g.a.rows + i] = (rr[0] + rr[128]) + (rr[256] + rr[384]);
+      }
+    }
+  } else {
+    // running arg-max over this tile's a rows (codes), per b row (data row): a lane's codes ascend with (mi, r), so a
+    // strict '>' keeps the lowest index; then the four fq groups, then the two a halves (lower codes win ties)
+    float* const cv = reinterpret_cast<float*>(smem);                 // [2 a halves][256 j]
+    int32_t* const ci = reinterpret_cast<int32_t*>(smem + 2 * 256 * 4);
+#pragma unroll
+    for (int nj = 0; nj < 4; ++nj) {
+      float best = -INFINITY;
+      int bi = 0x7fffffff;
+#pragma unroll
+      for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = static_cast<int>(i_wave) + mi * 16 + r;
+          const float v = acc[mi][nj][r];
+          if (i < g.a.rows && v > best) { best = v; bi = i; }
+        }
+#pragma unroll
+      for (int o = 16; o < 64; o <<= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+      }
+      if (fq == 0) {
+        cv[wr * 256 + wc * 64 + nj * 16 + fr] = best;
+        ci[wr * 256 + wc * 64 + nj * 16 + fr] = bi;
+      }
+    }
+    __syncthreads();
+    if (tid < 256) {
+      const int64_t j = static_cast<int64_t>(tn) * kTile + tid;
+      if (j < g.b.rows) {
+        float best = cv[tid];
+        int bi = ci[tid];
+        const float ov = cv[256 + tid];
+        const int oi = ci[256 + tid];
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        const int64_t o = (static_cast<int64_t>(bz) * g.b.rows + j) * g.tiles_m + tm;
+        g.cand_val[o] = best;
+        g.cand_idx[o] = bi;
+      }
+    }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Cut passes: fp32 (or bf16-stored) operands -> bf16 planes.  NP = 3: the exact pieces h, m, l (common.h: split3);
+// NP = 1: one plane rounded to nearest even (the bf16 GEMM mode).  A bf16-stored operand IS its own h piece: its m and l
+// planes are never read (the callers' segment lists skip them).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kCutThreads = 256;
+
+// out[plane][m][c0 ...] for two sources side by side: columns [0, K1) from x1 (rows >= x1_rows: zero), [K1, K1 + K2) from
+// x2 (element kind x2_kind); ld = row stride of the planes.  ssq (optional): per row and per `seg_len` columns of the
+// x1 part the sum of squares (the quantiser's row norms): ssq[m][K1 / seg_len].
+template <int NP>
+__global__ void __launch_bounds__(kCutThreads)
+k_bt_cut_rows(const float* __restrict__ x1, int64_t ldx1, int K1, int64_t x1_rows, const void* __restrict__ x2, int x2_kind,
+              int K2, int64_t M, uint16_t* __restrict__ out, int64_t ps, int64_t ld) {
+  const int nv = (K1 + K2) / 4;
+  const int64_t total = M * nv;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kCutThreads + threadIdx.x; i < total;
+       i += static_cast<int64_t>(gridDim.x) * kCutThreads) {
+    const int64_t m = i / nv;
+    const int c = static_cast<int>(i - m * nv) * 4;
+    uint16_t* o = out + m * ld + c;
+    if (c >= K1 && x2_kind == kBF16) {  // stored as bf16: the h plane as it is
+      *reinterpret_cast<uint2*>(o) = *reinterpret_cast<const uint2*>(static_cast<const uint16_t*>(x2) + m * K2 + (c - K1));
+      continue;
+    }
+    float4 v = zero4();
+    if (c < K1) {
+      if (m < x1_rows) v = ld4(x1 + m * ldx1 + c);
+    } else {
+      v = ld4(static_cast<const float*>(x2) + m * K2 + (c - K1));
+    }
+    if (NP == 1) {
+      *reinterpret_cast<uint2*>(o) = pack_rne(v);
+    } else {
+      uint2 h, mm, l;
+      split3(v, h, mm, l);
+      *reinterpret_cast<uint2*>(o) = h;
+      *reinterpret_cast<uint2*>(o + ps) = mm;
+      *reinterpret_cast<uint2*>(o + 2 * ps) = l;
+    }
+  }
+}
+
+// the quantiser's rows: one wave per row of xp [N, H * Dc]: the three planes and ssq[row][h] = |xp_h|^2
+__global__ void __launch_bounds__(kCutThreads)
+k_bt_cut_rows_ssq(const float* __restrict__ x, int64_t N, int H, int Dc, uint16_t* __restrict__ out, int64_t ps,
+                  float* __restrict__ ssq) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = static_cast<int64_t>(blockIdx.x) * (kCutThreads / 64) + (threadIdx.x >> 6);
+  if (row >= N) return;
+  const int64_t HD = static_cast<int64_t>(H) * Dc;
+  for (int h = 0; h < H; ++h) {
+    float acc = 0.f;
+    for (int c = 4 * lane; c < Dc; c += 256) {
+      const float4 v = ld4(x + row * HD + static_cast<int64_t>(h) * Dc + c);
+      acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+      uint2 a, b, l;
+      split3(v, a, b, l);
+      uint16_t* o = out + row * HD + static_cast<int64_t>(h) * Dc + c;
+      *reinterpret_cast<uint2*>(o) = a;
+      *reinterpret_cast<uint2*>(o + ps) = b;
+      *reinterpret_cast<uint2*>(o + 2 * ps) = l;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) ssq[row * H + h] = acc;
+  }
+}
+
+// Transposed planes: x [R, C] (element kind `kind`, row stride C) -> out[plane][c][r], row stride ld >= R rounded up;
+// columns r in [R, ld) are written as zeros (the contraction runs over r in whole K tiles).  A block owns 64 columns c
+// and 256 rows r (four 64 x 64 sub-tiles transposed through LDS).  colsum (optional): partial column sums of x over the
+// block's rows, colsum[blockIdx.x][C] (the bias gradient: finished by k_bt_colsum_finish in fixed order).
+template <int NP>
+__global__ void __launch_bounds__(kCutThreads)
+k_bt_cut_cols(const void* __restrict__ x_, int kind, int64_t R, int C, uint16_t* __restrict__ out, int64_t ps, int64_t ld,
+              float* __restrict__ colsum) {
+  __shared__ __attribute__((aligned(16))) uint16_t tile[NP][64][64 + 8];  // [plane][c][r], 144-byte rows
+  __shared__ float csum[4][64];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int c4 = (tid & 15) * 4;   // this thread's four columns inside the 64-column strip
+  const int rq = tid >> 4;         // 0..15: row inside a group of 16
+  const int c0 = blockIdx.y * 64;
+  float4 cs = zero4();
+  for (int sub = 0; sub < 4; ++sub) {
+    const int64_t r0 = (static_cast<int64_t>(blockIdx.x) * 4 + sub) * 64;
+    if (r0 >= ld) break;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int rl = rq + 16 * it;
+      const int64_t r = r0 + rl;
+      float4 v = zero4();
+      if (r < R && c0 + c4 < C) v = ld4_kind(x_, r * C + c0 + c4, kind);
+      cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
+      const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (NP == 1) {
+          tile[0][c4 + e][rl] = static_cast<uint16_t>(rne_bits(vv[e]));
+        } else {
+          const uint32_t hb = hi16(vv[e]);
+          const float r1 = vv[e] - __uint_as_float(hb);
+          const uint32_t mb = hi16(r1);
+          const uint32_t lb = __float_as_uint(r1 - __uint_as_float(mb));
+          tile[0][c4 + e][rl] = static_cast<uint16_t>(hb >> 16);
+          tile[NP > 1 ? 1 : 0][c4 + e][rl] = static_cast<uint16_t>(mb >> 16);
+          tile[NP > 2 ? 2 : 0][c4 + e][rl] = static_cast<uint16_t>(lb >> 16);
+        }
+      }
+    }
+    __syncthreads();
+    // 64 columns x 8 sixteen-byte chunks per plane
+#pragma unroll
+    for (int q = tid; q < NP * 64 * 8; q += kCutThreads) {
+      const int plane = q / 512, cc = (q >> 3) & 63, ch = q & 7;
+      if (c0 + cc < C && r0 + ch * 8 < ld)
+        *reinterpret_cast<uint4*>(out + plane * ps + static_cast<int64_t>(c0 + cc) * ld + r0 + ch * 8) =
+            *reinterpret_cast<const uint4*>(&tile[plane][cc][ch * 8]);
+    }
+    __syncthreads();
+  }
+  if (colsum) {
+    // the 16 threads that share c4: lanes c4/4 + 16 k of each wave, then the four waves
+#pragma unroll
+    for (int o = 16; o < 64; o <<= 1) {
+      cs.x += __shfl_xor(cs.x, o, 64); cs.y += __shfl_xor(cs.y, o, 64);
+      cs.z += __shfl_xor(cs.z, o, 64); cs.w += __shfl_xor(cs.w, o, 64);
+    }
+    if (lane < 16) {
+      csum[w][lane * 4 + 0] = cs.x; csum[w][lane * 4 + 1] = cs.y;
+      csum[w][lane * 4 + 2] = cs.z; csum[w][lane * 4 + 3] = cs.w;
+    }
+    __syncthreads();
+    if (tid < 64 && c0 + tid < C)
+      colsum[static_cast<int64_t>(blockIdx.x) * C + c0 + tid] = (csum[0][tid] + csum[1][tid]) + (csum[2][tid] + csum[3][tid]);
+  }
+}
+
+// db[c] = sum over slabs of colsum[slab][c], fixed order, fp64 accumulation
+__global__ void __launch_bounds__(kCutThreads)
+k_bt_colsum_finish(const float* __restrict__ partial, int slabs, int C, float* __restrict__ db) {
+  __shared__ double red[kCutThreads];
+  const int cl = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  double s = 0.0;
+  if (c < C)
+    for (int b = slice; b < slabs; b += 4) s += partial[static_cast<int64_t>(b) * C + c];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (slice == 0 && c < C) db[c] = static_cast<float>((red[cl] + red[64 + cl]) + (red[128 + cl] + red[192 + cl]));
+}
+
+// out[i] = sum over s < splits of slab[s][i] (+ nothing): the weight gradient's split slabs, fixed order
+__global__ void __launch_bounds__(kCutThreads)
+k_bt_reduce_slabs(const float* __restrict__ slab, int splits, int64_t n, float* __restrict__ out) {
+  const int64_t i = (static_cast<int64_t>(blockIdx.x) * kCutThreads + threadIdx.x) * 4;
+  if (i >= n) return;
+  float4 a = ld4(slab + i);
+  for (int s = 1; s < splits; ++s) {
+    const float4 v = ld4(slab + static_cast<int64_t>(s) * n + i);
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
+  st4(out + i, a);
+}
+
+// ---- the quantiser's finish: candidates of the code tiles -> index, row norm, commitment term
+// one thread per (row, head); a block's terms -> partial[block] (fp64), finished by k_bt_commit_finish
+__global__ void __launch_bounds__(kCutThreads)
+k_bt_argmax_finish(const float* __restrict__ cand_val, const int32_t* __restrict__ cand_idx, const float* __restrict__ ssq,
+                   const float* __restrict__ esq, int64_t N, int H, int K, int tiles, float* __restrict__ norm_out,
+                   int64_t* __restrict__ ind_out, double* __restrict__ partial) {
+  __shared__ double red[kCutThreads / 64];
+  const int64_t item = static_cast<int64_t>(blockIdx.x) * kCutThreads + threadIdx.x;  // row * H + h
+  double term = 0.0;
+  if (item < N * H) {
+    const int64_t row = item / H;
+    const int h = static_cast<int>(item - row * H);
+    const int64_t o = (static_cast<int64_t>(h) * N + row) * tiles;
+    float best = cand_val[o];
+    int bi = cand_idx[o];
+    for (int t = 1; t < tiles; ++t) {  // tiles ascend in code index: strict '>' keeps the lowest index among equals
+      const float v = cand_val[o + t];
+      if (v > best) { best = v; bi = cand_idx[o + t]; }
+    }
+    const float nrm = sqrtf(ssq[item]);
+    const float inv = 1.0f / fmaxf(nrm, 1e-12f), xn2 = nrm * inv;  // F.normalize eps
+    ind_out[item] = static_cast<int64_t>(bi);
+    norm_out[item] = nrm;
+    if (esq) term = static_cast<double>(esq[static_cast<int64_t>(h) * K + bi] + xn2 * xn2 - 2.0f * best * inv);
+  }
+  for (int o = 32; o > 0; o >>= 1) term += __shfl_xor(term, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = term;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// the form that hands the per-head codes on (csrc/vq.hip: k_vq_assign with `quant`): one wave per (row, head) gathers the
+// winning code, writes x^ + (q - x^) (training, vq.py:937) or q, optionally x^ itself, and sums |q - x^|^2
+__global__ void __launch_bounds__(kCutThreads)
+k_bt_gather_commit(const float* __restrict__ xp, int64_t N, int H, int Dc, int K, const float* __restrict__ embed,
+                   const int64_t* __restrict__ ind, const float* __restrict__ ssq, int training, float* __restrict__ quant,
+                   float* __restrict__ xn_out, double* __restrict__ partial) {
+  __shared__ double red[kCutThreads / 64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t item = static_cast<int64_t>(blockIdx.x) * (kCutThreads / 64) + w;
+  float sq = 0.f;
+  if (item < N * H) {
+    const int64_t row = item / H;
+    const int h = static_cast<int>(item - row * H);
+    const int64_t HD = static_cast<int64_t>(H) * Dc;
+    const float inv = 1.0f / fmaxf(sqrtf(ssq[item]), 1e-12f);
+    const float* xr = xp + row * HD + static_cast<int64_t>(h) * Dc;
+    const float* qr = embed + (static_cast<int64_t>(h) * K + ind[item]) * Dc;
+    for (int c = 4 * lane; c < Dc; c += 256) {
+      const float4 x = ld4(xr + c), q = ld4(qr + c);
+      const float4 n = make_float4(x.x * inv, x.y * inv, x.z * inv, x.w * inv);
+      const float4 d = make_float4(q.x - n.x, q.y - n.y, q.z - n.z, q.w - n.w);
+      sq += d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
+      const float4 o = training ? make_float4(n.x + d.x, n.y + d.y, n.z + d.z, n.w + d.w) : q;
+      st4(quant + row * HD + static_cast<int64_t>(h) * Dc + c, o);
+      if (xn_out) st4(xn_out + row * HD + static_cast<int64_t>(h) * Dc + c, n);
+    }
+  }
+  sq = wave_sum(sq);
+  if (lane == 0) red[w] = static_cast<double>(sq);
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ void __launch_bounds__(kCutThreads)
+k_bt_commit_finish(const double* __restrict__ partial, int64_t n, double scale, float* __restrict__ out) {
+  __shared__ double red[kCutThreads];
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += kCutThreads) s += partial[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = kCutThreads / 2; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = static_cast<float>(red[0] * scale);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Host side.  Scratch (the planes, the split slabs, the arg-max candidates) comes from the CALLER: one arena per
+// (device, stream), registered with stemgnn_linear_set_scratch and sized with stemgnn_linear_scratch_bytes; nothing here
+// allocates, frees or synchronises.  A product that qualifies but finds no arena (or one too small) runs on the tile
+// kernels and is counted (stemgnn_linear_bigtile_fallbacks) -- a capacity miss, never an error swallowed.
+// ---------------------------------------------------------------------------------------------------------------------
+struct Arena { unsigned char* p = nullptr; size_t bytes = 0; };
+std::mutex g_arena_mu;
+std::map<std::pair<int, hipStream_t>, Arena> g_arena;
+
+inline size_t a256(size_t b) { return (b + 255) / 256 * 256; }
+
+bool arena_of(hipStream_t st, size_t need, unsigned char** base) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return false; }
+  std::lock_guard<std::mutex> lock(g_arena_mu);
+  auto it = g_arena.find({dev, st});
+  if (it == g_arena.end() || it->second.bytes < need + 256 || !it->second.p) return false;
+  *base = reinterpret_cast<unsigned char*>(a256(reinterpret_cast<uintptr_t>(it->second.p)));
+  return true;
+}
+
+struct Carve {
+  unsigned char* p;
+  template <typename T> T* take(size_t bytes) { T* r = reinterpret_cast<T*>(p); p += a256(bytes); return r; }
+};
+
+inline unsigned cut_grid(int64_t elems4) {
+  int64_t gsz = (elems4 + kCutThreads - 1) / kCutThreads;
+  if (gsz > 16384) gsz = 16384;
+  return static_cast<unsigned>(gsz < 1 ? 1 : gsz);
+}
+
+int bt_launch(BtArgs& a, int epi, hipStream_t st) {
+  a.tiles_m = static_cast<int>((a.a.rows + kTile - 1) / kTile);
+  a.tiles_n = static_cast<int>((a.b.rows + kTile - 1) / kTile);
+  const int64_t blocks = static_cast<int64_t>(a.tiles_m) * a.tiles_n * a.splits * a.batch;
+  if (blocks <= 0 || blocks >= (1ll << 31) || a.a.rows * a.a.ld >= (1ll << 31) || a.b.rows * a.b.ld >= (1ll << 31))
+    return STEMGNN_ERR_TOO_LARGE;
+  static const hipError_t attr0 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_bt_gemm<kEpiStore>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, kBtLds);
+  static const hipError_t attr1 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_bt_gemm<kEpiArgmax>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, kBtLds);
+  if (attr0 != hipSuccess || attr1 != hipSuccess) return STEMGNN_ERR_HIP;
+  static const int dbg = getenv("STEMGNN_BT_DBG") ? atoi(getenv("STEMGNN_BT_DBG")) : 0;
+  a.dbg = dbg;
+  if (epi == kEpiStore) k_bt_gemm<kEpiStore><<<static_cast<unsigned>(blocks), kBtThreads, kBtLds, st>>>(a);
+  else k_bt_gemm<kEpiArgmax><<<static_cast<unsigned>(blocks), kBtThreads, kBtLds, st>>>(a);
+  STEMGNN_LAUNCH_CHECK();
+  return STEMGNN_OK;
+}
+
+// the segment list of a product: exact mode = the six significant piece products, small terms first (as common.h:
+// mfma_x3); kt_a / kt_b: K tiles of the planes of the a / b side that exist (a bf16-stored part has an h plane only)
+inline void exact_segments(BtArgs& g, int pieces, int kt_all, int kt_b_lo /*K tiles the b side's m / l planes cover*/,
+                           int z_k0, int z_kt_all, int z_kt_lo) {
+  static const int order[6][2] = {{2, 0}, {0, 2}, {1, 1}, {1, 0}, {0, 1}, {0, 0}};  // (a piece, b piece)
+  g.nseg = 0;
+  if (pieces == 1) {
+    g.seg[g.nseg++] = BtSeg{0, 0, 0, kt_all, z_k0, z_kt_all};
+    return;
+  }
+  for (int s = 0; s < 6; ++s) {
+    const int pa = order[s][0], pb = order[s][1];
+    const bool lo = pb != 0;  // the b side's m / l planes
+    g.seg[g.nseg++] = BtSeg{pa, pb, 0, lo ? kt_b_lo : kt_all, z_k0, lo ? z_kt_lo : z_kt_all};
+  }
+}
+
+std::atomic<int> g_bt_on{1};
+std::atomic<int64_t> g_bt_calls{0}, g_bt_fallbacks{0};
+
+}  // namespace
+
+// Products the big-tile core takes: large (>= 8 192 rows, >= 2.5e10 flop), both feature extents at least one 256 tile and
+// multiples of 64.  Below that the 128-row tile / weight-stationary kernels win (HBM-bound shapes, D = 128).
+bool bt_gemm_ok(int64_t M, int64_t N, int64_t K) {
+  // (operand planes are addressed with 32-bit element offsets: rows x row length below 2^31, padding included)
+  return g_bt_on.load(std::memory_order_relaxed) != 0 && M >= 8192 && N >= 256 && K >= 256 && N % 64 == 0 && K % 64 == 0 &&
+         2.0 * static_cast<double>(M) * N * K >= 2.5e10 && (M + 8192) * std::max(N, K) < (1ll << 31);
+}
+void bt_served() { g_bt_calls.fetch_add(1, std::memory_order_relaxed); }
+void bt_missed() { g_bt_fallbacks.fetch_add(1, std::memory_order_relaxed); }
+
+static inline int np_of(int pieces) { return pieces == 1 ? 1 : 3; }
+
+// contraction splits of a weight gradient: about one block per CU over the output tiles
+static inline int bt_dw_splits(int64_t N, int64_t K) {
+  const int64_t tiles = ((N + kTile - 1) / kTile) * ((K + kTile - 1) / kTile);
+  int64_t s = 256 / (tiles < 1 ? 1 : tiles);
+  if (s < 1) s = 1;
+  if (s > 64) s = 64;
+  return static_cast<int>(s);
+}
+static inline int64_t bt_dw_rows_padded(int64_t M, int splits) {
+  const int64_t q = static_cast<int64_t>(kBK) * splits;
+  return (M + q - 1) / q * q;
+}
+// arena bytes of the three products and of the code assignment (what the bt_* carve; the scratch queries take their maximum)
+static inline size_t bt_need_fwd(int np, int64_t M, int64_t N, int64_t K) {
+  return a256(static_cast<size_t>(np) * M * K * 2) + a256(static_cast<size_t>(np) * N * K * 2);
+}
+static inline size_t bt_need_bwd_weight(int np, int64_t M, int64_t N, int64_t K, bool want_db) {
+  const int S = bt_dw_splits(N, K);
+  const int64_t Mp = bt_dw_rows_padded(M, S);
+  return a256(static_cast<size_t>(np) * N * Mp * 2) + a256(static_cast<size_t>(np) * K * Mp * 2) +
+         a256(static_cast<size_t>(S) * N * K * 4) + (want_db ? a256(static_cast<size_t>((Mp + 255) / 256) * N * 4) : 0);
+}
+static inline size_t bt_need_vq(int64_t N, int64_t H, int64_t Dc, int64_t K) {
+  const int64_t tiles = (K + kTile - 1) / kTile;
+  const int64_t fin_blocks = (N * H + kCutThreads - 1) / kCutThreads;
+  const int64_t gat_blocks = (N * H + kCutThreads / 64 - 1) / (kCutThreads / 64);
+  return a256(static_cast<size_t>(3) * H * K * Dc * 2) + a256(static_cast<size_t>(3) * N * H * Dc * 2) +
+         2 * a256(static_cast<size_t>(N) * H * tiles * 4) + a256(static_cast<size_t>(N) * H * 4) +
+         a256(static_cast<size_t>(fin_blocks + gat_blocks) * 8);
+}
+
+// y [M, N] = [x1 | x2] [w1 | w2]^T + bias.  pieces: 3 = exact mode, 1 = bf16 GEMM mode.  Returns STEMGNN_ERR_WORKSPACE
+// when the arena is missing or too small (the caller takes the tile kernels).
+int bt_linear_fwd(int pieces, const float* x1, const float* w1, int64_t K1, const void* x2, int x2_kind, const float* w2,
+                  int64_t K2, const float* bias, int64_t M, int64_t N, float* y, int64_t x1_rows, int64_t store_rows,
+                  float* stats_partial, int64_t stats_slabs, hipStream_t st) {
+  const int np = np_of(pieces);
+  const int64_t K = K1 + K2;
+  if (K1 % kBK != 0 || K2 % kBK != 0) return STEMGNN_ERR_WORKSPACE;
+  const size_t xb = static_cast<size_t>(np) * M * K * 2, wb = static_cast<size_t>(np) * N * K * 2;
+  unsigned char* base = nullptr;
+  if (!arena_of(st, bt_need_fwd(np, M, N, K), &base)) return STEMGNN_ERR_WORKSPACE;
+  Carve c{base};
+  uint16_t* xpl = c.take<uint16_t>(xb);
+  uint16_t* wpl = c.take<uint16_t>(wb);
+  if (np == 3) {
+    k_bt_cut_rows<3><<<cut_grid(M * (K / 4)), kCutThreads, 0, st>>>(x1, K1, static_cast<int>(K1), x1_rows, x2, x2_kind,
+                                                                   static_cast<int>(K2), M, xpl, M * K, K);
+    STEMGNN_LAUNCH_CHECK();
+    k_bt_cut_rows<3><<<cut_grid(N * (K / 4)), kCutThreads, 0, st>>>(w1, K1, static_cast<int>(K1), N, w2, kF32,
+                                                                   static_cast<int>(K2), N, wpl, N * K, K);
+  } else {
+    k_bt_cut_rows<1><<<cut_grid(M * (K / 4)), kCutThreads, 0, st>>>(x1, K1, static_cast<int>(K1), x1_rows, x2, x2_kind,
+                                                                   static_cast<int>(K2), M, xpl, M * K, K);
+    STEMGNN_LAUNCH_CHECK();
+    k_bt_cut_rows<1><<<cut_grid(N * (K / 4)), kCutThreads, 0, st>>>(w1, K1, static_cast<int>(K1), N, w2, kF32,
+                                                                   static_cast<int>(K2), N, wpl, N * K, K);
+  }
+  STEMGNN_LAUNCH_CHECK();
+  BtArgs g{};
+  g.a = BtOp{wpl, N * K, K, N, 0};
+  g.b = BtOp{xpl, M * K, K, M, 0};
+  const int kt1 = static_cast<int>(K1 / kBK), kt2 = static_cast<int>(K2 / kBK);
+  const bool bf = K2 > 0 && x2_kind == kBF16;  // the second part of the b side has an h plane only
+  exact_segments(g, pieces, kt1 + kt2, bf ? kt1 : kt1 + kt2, kt1, kt2, bf ? 0 : kt2);
+  g.splits = 1; g.batch = 1;
+  // row tiles that start at or past the aggregate's rows contract over the second part only
+  g.b_full_rows = (K2 > 0 && x1_rows < M) ? (x1_rows + kTile - 1) / kTile * kTile : (1ll << 62);
+  g.y = y; g.ldy = N; g.y_bs = 0; g.y_ss = 0; g.store_rows = store_rows;
+  g.bias = bias;
+  g.stats = stats_partial;
+  const int rc = bt_launch(g, kEpiStore, st);
+  if (rc != STEMGNN_OK) return rc;
+  if (stats_partial && stats_slabs > g.tiles_n)  // the slabs the consumer reduces over past the ones written here
+    STEMGNN_HIP_TRY(hipMemsetAsync(stats_partial + static_cast<int64_t>(g.tiles_n) * 2 * N, 0,
+                                   sizeof(float) * (stats_slabs - g.tiles_n) * 2 * N, st));
+  return STEMGNN_OK;
+}
+
+// dx [M, K] = dy [M, N] w [N, K]
+int bt_linear_bwd_data(int pieces, const float* dy, const float* w, int64_t M, int64_t N, int64_t K, float* dx,
+                       hipStream_t st) {
+  const int np = np_of(pieces);
+  if (N % kBK != 0) return STEMGNN_ERR_WORKSPACE;
+  const size_t gb = static_cast<size_t>(np) * M * N * 2, wb = static_cast<size_t>(np) * K * N * 2;
+  unsigned char* base = nullptr;
+  if (!arena_of(st, bt_need_fwd(np, M, K, N), &base)) return STEMGNN_ERR_WORKSPACE;
+  Carve c{base};
+  uint16_t* gpl = c.take<uint16_t>(gb);
+  uint16_t* wpl = c.take<uint16_t>(wb);  // w^T planes [K][N]
+  dim3 tg(static_cast<unsigned>((N + 255) / 256), static_cast<unsigned>((K + 63) / 64));
+  if (np == 3) {
+    k_bt_cut_rows<3><<<cut_grid(M * (N / 4)), kCutThreads, 0, st>>>(dy, N, static_cast<int>(N), M, nullptr, kF32, 0, M, gpl,
+                                                                   M * N, N);
+    STEMGNN_LAUNCH_CHECK();
+    k_bt_cut_cols<3><<<tg, kCutThreads, 0, st>>>(w, kF32, N, static_cast<int>(K), wpl, K * N, N, nullptr);
+  } else {
+    k_bt_cut_rows<1><<<cut_grid(M * (N / 4)), kCutThreads, 0, st>>>(dy, N, static_cast<int>(N), M, nullptr, kF32, 0, M, gpl,
+                                                                   M * N, N);
+    STEMGNN_LAUNCH_CHECK();
+    k_bt_cut_cols<1><<<tg, kCutThreads, 0, st>>>(w, kF32, N, static_cast<int>(K), wpl, K * N, N, nullptr);
+  }
+  STEMGNN_LAUNCH_CHECK();
+  BtArgs g{};
+  g.a = BtOp{wpl, K * N, N, K, 0};
+  g.b = BtOp{gpl, M * N, N, M, 0};
+  const int kt = static_cast<int>(N / kBK);
+  exact_segments(g, pieces, kt, kt, 0, kt, kt);
+  g.splits = 1; g.batch = 1;
+  g.b_full_rows = 1ll << 62;
+  g.y = dx; g.ldy = K; g.store_rows = M;
+  return bt_launch(g, kEpiStore, st);
+}
+
+// dw [N, K] = dy [M, N]^T x [M, K]; db [N] = column sums of dy (NULL: skip)
+int bt_linear_bwd_weight(int pieces, const float* dy, const void* x, int x_kind, int64_t M, int64_t N, int64_t K, float* dw,
+                         float* db, hipStream_t st) {
+  const int np = np_of(pieces);
+  const int S = bt_dw_splits(N, K);
+  const int64_t Mp = bt_dw_rows_padded(M, S);
+  const int row_blocks = static_cast<int>((Mp + 255) / 256);
+  const size_t gb = static_cast<size_t>(np) * N * Mp * 2, xb = static_cast<size_t>(np) * K * Mp * 2;
+  const size_t sb = static_cast<size_t>(S) * N * K * 4, pb = db ? static_cast<size_t>(row_blocks) * N * 4 : 0;
+  unsigned char* base = nullptr;
+  if (!arena_of(st, bt_need_bwd_weight(np, M, N, K, db != nullptr), &base)) return STEMGNN_ERR_WORKSPACE;
+  Carve c{base};
+  uint16_t* gpl = c.take<uint16_t>(gb);  // dy^T planes [N][Mp]
+  uint16_t* xpl = c.take<uint16_t>(xb);  // x^T planes [K][Mp]
+  float* slabs = c.take<float>(sb);
+  float* part = db ? c.take<float>(pb) : nullptr;
+  dim3 gg(static_cast<unsigned>(row_blocks), static_cast<unsigned>((N + 63) / 64));
+  dim3 gx(static_cast<unsigned>(row_blocks), static_cast<unsigned>((K + 63) / 64));
+  const bool xbf = x_kind == kBF16;
+  if (np == 3) {
+    k_bt_cut_cols<3><<<gg, kCutThreads, 0, st>>>(dy, kF32, M, static_cast<int>(N), gpl, N * Mp, Mp, part);
+    STEMGNN_LAUNCH_CHECK();
+    k_bt_cut_cols<3><<<gx, kCutThreads, 0, st>>>(x, x_kind, M, static_cast<int>(K), xpl, K * Mp, Mp, nullptr);
+  } else {
+    k_bt_cut_cols<1><<<gg, kCutThreads, 0, st>>>(dy, kF32, M, static_cast<int>(N), gpl, N * Mp, Mp, part);
+    STEMGNN_LAUNCH_CHECK();
+    k_bt_cut_cols<1><<<gx, kCutThreads, 0, st>>>(x, x_kind, M, static_cast<int>(K), xpl, K * Mp, Mp, nullptr);
+  }
+  STEMGNN_LAUNCH_CHECK();
+  BtArgs g{};
+  g.a = BtOp{xpl, K * Mp, Mp, K, 0};
+  g.b = BtOp{gpl, N * Mp, Mp, N, 0};
+  const int kt = static_cast<int>(Mp / kBK);
+  g.nseg = 0;
+  if (pieces == 1) {
+    g.seg[g.nseg++] = BtSeg{0, 0, 0, kt, 0, kt};
+  } else {
+    static const int order[6][2] = {{2, 0}, {0, 2}, {1, 1}, {1, 0}, {0, 1}, {0, 0}};  // (x piece, dy piece)
+    for (int s = 0; s < 6; ++s) {
+      if (xbf && order[s][0] != 0) continue;  // a bf16-stored x is its own h piece: its m and l planes are zero
+      g.seg[g.nseg++] = BtSeg{order[s][0], order[s][1], 0, kt, 0, kt};
+    }
+  }
+  g.splits = S; g.batch = 1;
+  g.b_full_rows = 1ll << 62;
+  g.y = S > 1 ? slabs : dw; g.ldy = K; g.y_ss = N * K; g.store_rows = N;
+  const int rc = bt_launch(g, kEpiStore, st);
+  if (rc != STEMGNN_OK) return rc;
+  if (S > 1) {
+    k_bt_reduce_slabs<<<static_cast<unsigned>((N * K / 4 + kCutThreads - 1) / kCutThreads), kCutThreads, 0, st>>>(
+        slabs, S, N * K, dw);
+    STEMGNN_LAUNCH_CHECK();
+  }
+  if (db) {
+    k_bt_colsum_finish<<<static_cast<unsigned>((N + 63) / 64), kCutThreads, 0, st>>>(part, row_blocks, static_cast<int>(N), db);
+    STEMGNN_LAUNCH_CHECK();
+  }
+  return STEMGNN_OK;
+}
+
+// The quantiser's code assignment at large codebooks (K >= 512 codes of Dc >= 256; BASELINE configs 3 and 5; reference
+// model/vq.py:650-657): the exact six-piece similarity product of ALL heads as one launch of the core, the arg-max
+// taken from the accumulators per 256-code tile (no [N, K] matrix: N x H x K / 256 candidates), then one finishing pass.
+bool bt_vq_assign_ok(int64_t N, int64_t H, int64_t Dc, int64_t K) {
+  return g_bt_on.load(std::memory_order_relaxed) != 0 && N >= 8192 && H >= 1 && K >= 512 && Dc >= 256 && Dc % kBK == 0 &&
+         N * H * Dc < (1ll << 31) && H * K * Dc < (1ll << 31) && H <= 1024;
+}
+int bt_vq_assign(const float* xp, int64_t N, int64_t H, int64_t Dc, const float* embed, const float* esq, int64_t K,
+                 int training, float* xn, float* norm, int64_t* ind, float* quant, float* sqerr, double sq_scale,
+                 hipStream_t st) {
+  if (!quant && !esq) return STEMGNN_ERR_INVALID_ARG;
+  const int64_t HD = H * Dc;
+  const int tiles = static_cast<int>((K + kTile - 1) / kTile);
+  const int64_t fin_blocks = (N * H + kCutThreads - 1) / kCutThreads;
+  const int64_t gat_blocks = (N * H + kCutThreads / 64 - 1) / (kCutThreads / 64);
+  const size_t ab = static_cast<size_t>(3) * H * K * Dc * 2, bb = static_cast<size_t>(3) * N * HD * 2;
+  const size_t cb = static_cast<size_t>(N) * H * tiles * 4, qb = static_cast<size_t>(N) * H * 4;
+  const size_t pb = static_cast<size_t>(fin_blocks + gat_blocks) * 8;
+  unsigned char* base = nullptr;
+  if (!arena_of(st, bt_need_vq(N, H, Dc, K), &base)) return STEMGNN_ERR_WORKSPACE;
+  Carve c{base};
+  uint16_t* epl = c.take<uint16_t>(ab);
+  uint16_t* xpl = c.take<uint16_t>(bb);
+  float* cval = c.take<float>(cb);
+  int32_t* cidx = c.take<int32_t>(cb);
+  float* ssq = c.take<float>(qb);
+  double* partial = c.take<double>(pb);
+  k_bt_cut_rows<3><<<cut_grid(H * K * (Dc / 4)), kCutThreads, 0, st>>>(embed, Dc, static_cast<int>(Dc), H * K, nullptr, kF32,
+                                                                      0, H * K, epl, H * K * Dc, Dc);
+  STEMGNN_LAUNCH_CHECK();
+  k_bt_cut_rows_ssq<<<static_cast<unsigned>((N + 3) / 4), kCutThreads, 0, st>>>(xp, N, static_cast<int>(H),
+                                                                               static_cast<int>(Dc), xpl, N * HD, ssq);
+  STEMGNN_LAUNCH_CHECK();
+  BtArgs g{};
+  g.a = BtOp{epl, H * K * Dc, Dc, K, K * Dc};
+  g.b = BtOp{xpl, N * HD, HD, N, Dc};
+  const int kt = static_cast<int>(Dc / kBK);
+  exact_segments(g, 3, kt, kt, 0, kt, kt);
+  g.splits = 1; g.batch = static_cast<int>(H);
+  g.b_full_rows = 1ll << 62;
+  g.cand_val = cval; g.cand_idx = cidx;
+  int rc = bt_launch(g, kEpiArgmax, st);
+  if (rc != STEMGNN_OK) return rc;
+  k_bt_argmax_finish<<<static_cast<unsigned>(fin_blocks), kCutThreads, 0, st>>>(
+      cval, cidx, ssq, quant ? nullptr : esq, N, static_cast<int>(H), static_cast<int>(K), tiles, norm, ind, partial);
+  STEMGNN_LAUNCH_CHECK();
+  int64_t nparts = fin_blocks;
+  if (quant) {
+    k_bt_gather_commit<<<static_cast<unsigned>(gat_blocks), kCutThreads, 0, st>>>(
+        xp, N, static_cast<int>(H), static_cast<int>(Dc), static_cast<int>(K), embed, ind, ssq, training, quant, xn,
+        partial + fin_blocks);
+    STEMGNN_LAUNCH_CHECK();
+    nparts += gat_blocks;
+  }
+  k_bt_commit_finish<<<1, kCutThreads, 0, st>>>(partial, nparts, sq_scale, sqerr);
+  STEMGNN_LAUNCH_CHECK();
+  return STEMGNN_OK;
+}
+
+}  // namespace stemgnn
+
+using namespace stemgnn;
+
+extern "C" {
+
+size_t stemgnn_linear_scratch_bytes(int64_t max_rows, int64_t dim_a, int64_t dim_b) {
+  if (max_rows <= 0 || dim_a <= 0 || dim_b <= 0) return 0;
+  size_t need = 0;
+  for (int o = 0; o < 2; ++o) {
+    const int64_t N = o ? dim_b : dim_a, K = o ? dim_a : dim_b;
+    need = std::max(need, bt_need_fwd(3, max_rows, N, K));
+    need = std::max(need, bt_need_bwd_weight(3, max_rows, N, K, true));
+  }
+  return need + 1024;
+}
+
+size_t stemgnn_vq_assign_scratch_bytes(int64_t num_rows, int64_t heads, int64_t code_dim, int64_t codebook_size) {
+  if (num_rows <= 0 || heads <= 0 || code_dim <= 0 || codebook_size <= 0) return 0;
+  return bt_need_vq(num_rows, heads, code_dim, codebook_size) + 1024;
+}
+
+int stemgnn_linear_set_scratch(void* scratch, size_t bytes, void* stream_) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return hip_fail(hipGetLastError());
+  std::lock_guard<std::mutex> lock(g_arena_mu);
+  Arena& a = g_arena[{dev, static_cast<hipStream_t>(stream_)}];
+  a.p = static_cast<unsigned char*>(scratch);
+  a.bytes = scratch ? bytes : 0;
+  return STEMGNN_OK;
+}
+
+int stemgnn_linear_set_bigtile(int on) {
+  const int prev = g_bt_on.load(std::memory_order_relaxed);
+  if (on == 0 || on == 1) g_bt_on.store(on, std::memory_order_relaxed);
+  return prev;
+}
+int64_t stemgnn_linear_bigtile_calls(void) { return g_bt_calls.load(std::memory_order_relaxed); }
+int64_t stemgnn_linear_bigtile_fallbacks(void) { return g_bt_fallbacks.load(std::memory_order_relaxed); }
+
+}  // extern "C"

@@ -178,26 +178,30 @@ __device__ __forceinline__ floatx16 mfma_x3_b1(const bf16x8 (&a)[3], const bf16x
   return c;
 }
 
-// csrc/blaslt.hip: the bf16 GEMM mode's large products on the vendor library (a rounding pass + hipblasLtMatmul).
-// lt_gemm_ok: the product is large enough for that to beat the tile kernel; the lt_linear_* return STEMGNN_ERR_INVALID_ARG
-// when the library has no kernel for the shape and STEMGNN_ERR_HIP when it or an allocation failed -- the callers then
-// take the tile kernels.
-bool lt_gemm_ok(int64_t M, int64_t N, int64_t K);
-int lt_linear_fwd(const float* x1, const float* w1, int64_t K1, const void* x2, int x2_kind, const float* w2, int64_t K2,
-                  const float* bias, int64_t M, int64_t N, float* y, int64_t x1_rows, float* stats_partial,
-                  int64_t stats_slabs, hipStream_t st);
-int lt_linear_bwd_data(const float* dy, const float* w, int64_t M, int64_t N, int64_t K, float* dx, hipStream_t st);
-int lt_linear_bwd_weight(const float* dy, const void* x, int x_kind, int64_t M, int64_t N, int64_t K, float* dw, float* db,
-                         hipStream_t st);
-// the quantiser's code assignment at large codebooks: the exact six-piece similarity product as ONE library GEMM over
-// a contraction of 6 Dc, then arg-max + commitment terms off the similarity matrix (same outputs as k_vq_assign; quant ==
-// NULL: its lean form)
-bool lt_vq_assign_ok(int64_t N, int64_t H, int64_t Dc, int64_t K);
-int lt_vq_assign(const float* xp, int64_t N, int64_t H, int64_t Dc, const float* embed, const float* esq, int64_t K,
+// csrc/bigtile.hip: the big-tile bf16 MFMA core (256 x 256 x 64 per block, LDS-DMA staging, eight-phase ping-pong
+// schedule) for the LARGE products -- D = 768 configurations.  `pieces` = 3: the exact mode (operands cut into their three
+// bf16 pieces by a cut pass, the six significant piece products as six segments of one contraction); 1: the bf16 GEMM
+// mode (one rounded plane).  bt_gemm_ok: the product is large enough (and shaped) for the core to beat the 128-row tile
+// kernels.  Scratch comes from the arena the caller registered (stemgnn_linear_set_scratch): the bt_* return
+// STEMGNN_ERR_WORKSPACE when there is none or it is too small -- the ONLY code on which callers take the tile kernels
+// instead (counted by bt_missed); every other failure is propagated.
+bool bt_gemm_ok(int64_t M, int64_t N, int64_t K);
+void bt_served();
+void bt_missed();
+int bt_linear_fwd(int pieces, const float* x1, const float* w1, int64_t K1, const void* x2, int x2_kind, const float* w2,
+                  int64_t K2, const float* bias, int64_t M, int64_t N, float* y, int64_t x1_rows, int64_t store_rows,
+                  float* stats_partial, int64_t stats_slabs, hipStream_t st);
+int bt_linear_bwd_data(int pieces, const float* dy, const float* w, int64_t M, int64_t N, int64_t K, float* dx,
+                       hipStream_t st);
+int bt_linear_bwd_weight(int pieces, const float* dy, const void* x, int x_kind, int64_t M, int64_t N, int64_t K, float* dw,
+                         float* db, hipStream_t st);
+// the quantiser's code assignment at large codebooks: the exact similarity product of all heads as one launch of the core,
+// arg-max per 256-code tile from the accumulators (no [N, K] matrix), one finishing pass (same outputs as k_vq_assign;
+// quant == NULL: its lean form)
+bool bt_vq_assign_ok(int64_t N, int64_t H, int64_t Dc, int64_t K);
+int bt_vq_assign(const float* xp, int64_t N, int64_t H, int64_t Dc, const float* embed, const float* esq, int64_t K,
                  int training, float* xn, float* norm, int64_t* ind, float* quant, float* sqerr, double sq_scale,
                  hipStream_t st);
-bool library_gemm_enabled();  // csrc/linear.hip: stemgnn_linear_set_library_gemm
-void library_gemm_served();   // counts a product the library served (stemgnn_linear_library_calls)
 
 // csrc/wsgemm.hip: the weight-stationary dense product (K == 128): rows row_base.. of  y = x w^T + b  (bt: y = x w with w
 // given as [K][N]); stats_partial[stats_block0 + tile][2][N] takes the column sums / sums of squares per 128-row tile

@@ -1111,13 +1111,19 @@ inline int gemm_mode() {
   }
   return m;
 }
-// Mode 2's large products on the vendor library (csrc/blaslt.hip); stemgnn_linear_set_library_gemm(0) keeps them on the
-// tile kernels (the tests compare the two).
-std::atomic<int> g_library_gemm{1};
-std::atomic<int64_t> g_library_calls{0};  // products the library served (stemgnn_linear_library_calls: tests ask)
-inline bool library_gemm(int64_t M, int64_t N, int64_t K) {
-  return gemm_mode() == 2 && g_library_gemm.load(std::memory_order_relaxed) != 0 && lt_gemm_ok(M, N, K);
-}
+// The large products (D = 768 configurations) run on the big-tile core (csrc/bigtile.hip) in the exact mode and in the
+// bf16 GEMM mode alike; stemgnn_linear_set_bigtile(0) keeps them on the 128-row tile kernels (tests compare the two).
+inline int bigtile_pieces() { const int m = gemm_mode(); return m == 1 ? 3 : (m == 2 ? 1 : 0); }  // 0: fp32-MFMA mode, not served
+inline bool bigtile(int64_t M, int64_t N, int64_t K) { return bigtile_pieces() != 0 && bt_gemm_ok(M, N, K); }
+// runs a bt_* call: STEMGNN_OK = served; STEMGNN_ERR_WORKSPACE = no arena (counted; the caller goes on to the tile
+// kernels); anything else is an error the caller must return
+#define STEMGNN_TRY_BIGTILE(call)                                  \
+  do {                                                             \
+    const int rc_bt__ = (call);                                    \
+    if (rc_bt__ == STEMGNN_OK) { bt_served(); return STEMGNN_OK; } \
+    if (rc_bt__ != STEMGNN_ERR_WORKSPACE) return rc_bt__;          \
+    bt_missed();                                                   \
+  } while (0)
 inline bool gemm_x3() { return gemm_mode() == 1; }        // the exact three-piece form
 inline bool gemm_bf16() { return gemm_mode() == 2; }      // one rounded piece
 inline bool gemm_matrix_bf16() { return gemm_mode() >= 1; }  // either: the bf16 matrix-core tile kernels
@@ -1231,11 +1237,8 @@ int DwBatch::add(const float* dy, const void* x, int x_kind, int64_t M, int64_t 
   }
   if (!dy || !x || !workspace) return STEMGNN_ERR_INVALID_ARG;
   if (workspace_bytes < stemgnn_linear_bwd_weight_workspace_bytes(M, N, K)) return STEMGNN_ERR_WORKSPACE;
-  // bf16 GEMM mode, a large product: on the vendor library at once (nothing to queue)
-  if (library_gemm(M, N, K) && lt_linear_bwd_weight(dy, x, x_kind, M, N, K, dw, db, st) == STEMGNN_OK) {
-    g_library_calls.fetch_add(1, std::memory_order_relaxed);
-    return STEMGNN_OK;
-  }
+  // a large product: on the big-tile core at once (nothing to queue)
+  if (bigtile(M, N, K)) STEMGNN_TRY_BIGTILE(bt_linear_bwd_weight(bigtile_pieces(), dy, x, x_kind, M, N, K, dw, db, st));
   if (count == kMax) {
     const int rc = flush(st);
     if (rc != STEMGNN_OK) return rc;
@@ -1330,21 +1333,6 @@ int stemgnn_linear_set_ws(int min_tiles) {
   return prev;
 }
 
-}  // extern "C"
-namespace stemgnn {
-bool library_gemm_enabled() { return g_library_gemm.load(std::memory_order_relaxed) != 0; }
-void library_gemm_served() { g_library_calls.fetch_add(1, std::memory_order_relaxed); }
-}  // namespace stemgnn
-extern "C" {
-
-int64_t stemgnn_linear_library_calls(void) { return g_library_calls.load(std::memory_order_relaxed); }
-
-int stemgnn_linear_set_library_gemm(int on) {
-  const int prev = g_library_gemm.load(std::memory_order_relaxed);
-  if (on == 0 || on == 1) g_library_gemm.store(on, std::memory_order_relaxed);
-  return prev;
-}
-
 int stemgnn_linear_set_mode(int mode) {
   const int prev = gemm_mode();
   if (mode == 0 || mode == 1 || mode == 2) g_gemm_mode.store(mode, std::memory_order_relaxed);
@@ -1416,14 +1404,9 @@ int stemgnn_linear_fwd_rows_k(const float* x1, const float* w1, int64_t K1, cons
     }
   }
   const int mode = gemm_mode();
-  if (sr == M && library_gemm(M, N, K1 + K2)) {  // bf16 GEMM mode, a large product: rounding pass + vendor library
-    const int rc = lt_linear_fwd(x1, w1, K1, x2, x2_kind, w2, K2, bias, M, N, y, x1r, stats_partial,
-                                 2 * plan.main_tiles + plan.tail_tiles, st);
-    if (rc == STEMGNN_OK) {
-      g_library_calls.fetch_add(1, std::memory_order_relaxed);
-      return rc;
-    }  // otherwise: the tile kernels below
-  }
+  if (bigtile(M, N, K1 + K2))  // a large product: cut pass + the big-tile core
+    STEMGNN_TRY_BIGTILE(bt_linear_fwd(bigtile_pieces(), x1, w1, K1, x2_, x2_kind, w2, K2, bias, M, N, y, x1r, sr,
+                                      stats_partial, 2 * plan.main_tiles + plan.tail_tiles, st));
   if (plan.main_tiles > 0) {
     dim3 grid(static_cast<unsigned>(plan.main_tiles), static_cast<unsigned>(gy));
     launch_fwd_tile<128>(mode, bf, grid, st, x1, w1, k1, x2, w2, k2, bias, M, n, y, stats_partial, 0, 0, x1r, sr);
@@ -1456,10 +1439,7 @@ int stemgnn_linear_bwd_data(const float* dy, const float* w, int64_t M, int64_t 
   if (x3 && ws_enabled() && N == 128 && K % kBN == 0 && (M + kBM - 1) / kBM >= kWsMinTiles)
     return linear_ws_launch(dy, w, nullptr, M, K, 128, dx, nullptr, 0, 0, M, true, st);
   const int mode = gemm_mode();
-  if (library_gemm(M, K, N) && lt_linear_bwd_data(dy, w, M, N, K, dx, st) == STEMGNN_OK) {
-    g_library_calls.fetch_add(1, std::memory_order_relaxed);
-    return STEMGNN_OK;
-  }
+  if (bigtile(M, K, N)) STEMGNN_TRY_BIGTILE(bt_linear_bwd_data(bigtile_pieces(), dy, w, M, N, K, dx, st));
   if (plan.main_tiles > 0) {
     dim3 grid(static_cast<unsigned>(plan.main_tiles), static_cast<unsigned>(gy));
     if (mode == 2) k_linear_fwd_x3<128, false, true, kF32, 1><<<grid, kBlock, 0, st>>>(dy, w, kc, nullptr, nullptr, 0, nullptr, M, n, dx, nullptr, 0, 0, M, M);

@@ -724,7 +724,7 @@ using namespace stemgnn;
 
 extern "C" {
 
-static thread_local int g_last_assign_path = 0;  // 0 none yet, 1 k_vq_assign (tile form), 2 k_vq_assign_ws
+static thread_local int g_last_assign_path = 0;  // 0 none yet, 1 k_vq_assign (tile form), 2 k_vq_assign_ws, 4 the big-tile core
 int stemgnn_vq_assign_last_path(void) { return g_last_assign_path; }
 
 size_t stemgnn_vq_workspace_bytes(int64_t N, int64_t H, int64_t Dc, int64_t K) {
@@ -813,12 +813,17 @@ static int vq_assign_impl(const float* xp, int64_t N, int64_t H, int64_t Dc, con
     g_last_assign_path = 2;
     return vq_assign_ws_launch(xp, N, H, embed, esq, norm, ind, partial, counter, sq_scale, sqerr, st);
   }
-  // a large codebook: the exact six-piece similarity product as one library GEMM (csrc/blaslt.hip)
-  if (x3 && library_gemm_enabled() && lt_vq_assign_ok(N, H, Dc, K) &&
-      lt_vq_assign(xp, N, H, Dc, embed, esq, K, training, xn, norm, ind, quant, sqerr, sq_scale, st) == STEMGNN_OK) {
-    g_last_assign_path = 3;
-    library_gemm_served();
-    return STEMGNN_OK;
+  // a large codebook: the exact six-piece similarity product on the big-tile core, arg-max from the accumulators
+  // (csrc/bigtile.hip); without a scratch arena (the only miss that is not an error) the tile form below serves
+  if (x3 && bt_vq_assign_ok(N, H, Dc, K)) {
+    const int rc = bt_vq_assign(xp, N, H, Dc, embed, esq, K, training, xn, norm, ind, quant, sqerr, sq_scale, st);
+    if (rc == STEMGNN_OK) {
+      g_last_assign_path = 4;
+      bt_served();
+      return STEMGNN_OK;
+    }
+    if (rc != STEMGNN_ERR_WORKSPACE) return rc;
+    bt_missed();
   }
   g_last_assign_path = 1;
 #define STEMGNN_VQ_LAUNCH(CG)                                                                                         \

@@ -676,6 +676,7 @@ class EncoderFn(torch.autograd.Function):
             raise RuntimeError("encoder phase: out_rows is a forward-only option (no_grad callers)")
         z = torch.empty(rows, arr[len(arr) - 1].out_dim, dtype=torch.float32, device=x.device)
         T = 0 if etab is None else etab.size(0)
+        linear_scratch(N, 2 * max(int(a.in_dim) for a in arr), max(int(a.out_dim) for a in arr))
         check(lib.stemgnn_encoder_fwd(ctypes.byref(gv), _p(x), _p(dense), _p(etab), T, arr, ctypes.byref(cfg), _p(z),
                                       _p(save), save.numel(), _stream()), "encoder_fwd")
         if k1_timer.enabled and A > 0:  # one K1 launch per layer, over the rows that can receive edges
@@ -703,6 +704,7 @@ class EncoderFn(torch.autograd.Function):
         scratch = _workspace(lib.stemgnn_encoder_bwd_scratch_bytes(N, A, arr, ctypes.byref(cfg)), x.device)
         g_work = g_z.contiguous()
         T = 0 if etab is None else etab.size(0)
+        linear_scratch(N, 2 * max(int(a.in_dim) for a in arr), max(int(a.out_dim) for a in arr))
         check(lib.stemgnn_encoder_bwd(ctypes.byref(gv), _p(x), _p(dense), _p(etab), T, arr, ctypes.byref(cfg),
                                       _p(g_work), _p(g_x), _p(save), save.numel(), _p(scratch), scratch.numel(),
                                       _stream()), "encoder_bwd")
@@ -798,10 +800,43 @@ def linear_set_mode(mode: int) -> int:
     return int(lib.stemgnn_linear_set_mode(int(mode)))
 
 
-def linear_set_library_gemm(on: int) -> int:
-    """bf16 GEMM mode only: large products on the vendor library (default) or on the tile kernels (0).  Returns the
-    previous setting (any argument but 0 / 1 only queries)."""
-    return int(lib.stemgnn_linear_set_library_gemm(int(on)))
+def linear_set_bigtile(on: int) -> int:
+    """Large products (the D = 768 configurations) on the big-tile core (default) or on the 128-row tile kernels (0).
+    Returns the previous setting (any argument but 0 / 1 only queries)."""
+    return int(lib.stemgnn_linear_set_bigtile(int(on)))
+
+
+# The big-tile core's scratch (operand planes, split slabs, arg-max candidates) is the CALLER's: one arena per (device,
+# stream), allocated here through torch's caching allocator -- in stream order, before the call that needs it -- and
+# registered with the library, which never allocates.  It is kept between calls and only ever grows.
+_BT_ARENA = {}
+
+
+def linear_scratch(rows: int, dim_a: int, dim_b: int, vq: Optional[Tuple[int, int, int]] = None) -> None:
+    """Make sure the current (device, stream)'s arena covers every product with at most ``rows`` rows and feature extents
+    ``dim_a`` x ``dim_b`` (forward, backward-data, weight gradient) and, with ``vq = (heads, code_dim, codebook_size)``,
+    the quantiser's large-codebook assignment over ``rows`` rows.  Shapes the big-tile core does not take cost nothing."""
+    need = 0
+    if rows >= 8192 and min(dim_a, dim_b) >= 256:
+        need = lib.stemgnn_linear_scratch_bytes(rows, dim_a, dim_b)
+    if vq is not None and rows >= 8192 and vq[2] >= 512 and vq[1] >= 256:
+        need = max(need, lib.stemgnn_vq_assign_scratch_bytes(rows, vq[0], vq[1], vq[2]))
+    if need == 0:
+        return
+    dev, st = _cur_device(), _stream()
+    cur = _BT_ARENA.get((dev, st))
+    if cur is None or cur.numel() < need:
+        t = torch.empty(need + need // 16, dtype=torch.uint8, device=torch.device("cuda", dev))
+        check(lib.stemgnn_linear_set_scratch(_p(t), t.numel(), st), "linear_set_scratch")
+        _BT_ARENA[(dev, st)] = t  # the old block goes back to the allocator in stream order
+
+
+def linear_release_scratch() -> None:
+    """Unregister and free every arena (tests; a process that is done with the large configurations)."""
+    for (dev, st) in list(_BT_ARENA):
+        with torch.cuda.device(dev):
+            check(lib.stemgnn_linear_set_scratch(None, 0, st), "linear_set_scratch")
+        del _BT_ARENA[(dev, st)]
 
 
 def linear_fwd(x1: Tensor, w1: Tensor, x2: Optional[Tensor], w2: Optional[Tensor], bias: Optional[Tensor],
@@ -830,6 +865,7 @@ def linear_fwd(x1: Tensor, w1: Tensor, x2: Optional[Tensor], w2: Optional[Tensor
     blocks = int(lib.stemgnn_linear_stats_blocks(M, N))
     if want_stats:
         partial = torch.empty(max(blocks, 1), 2, N, dtype=torch.float32, device=x1.device)
+    linear_scratch(M, K1 + K2, N)
     check(lib.stemgnn_linear_fwd(_p(x1), _p(w1), K1, _p(x2), _p(w2), K2, _p(bias), M, N, _p(y), _p(partial), None,
                                  int(x1_rows), _stream()), "linear_fwd")
     return y, partial, blocks
@@ -842,6 +878,7 @@ def linear_bwd_weight(dy: Tensor, x: Tensor, want_bias: bool):
     dw = torch.empty(N, K, dtype=torch.float32, device=dy.device)
     db = torch.empty(N, dtype=torch.float32, device=dy.device) if want_bias else None
     ws = _workspace(lib.stemgnn_linear_bwd_weight_workspace_bytes(M, N, K), dy.device)
+    linear_scratch(M, N, K)
     check(lib.stemgnn_linear_bwd_weight(_p(dy), _p(x), M, N, K, _p(dw), _p(db), _p(ws), ws.numel(), _stream()),
           "linear_bwd_weight")
     return dw, db
@@ -855,6 +892,7 @@ def linear_bwd_data(dy: Tensor, w: Tensor) -> Tensor:
     if w.size(0) != N:
         raise RuntimeError(f"linear_bwd_data: dy has {N} columns, w has {w.size(0)} rows")
     dx = torch.empty(M, w.size(1), dtype=torch.float32, device=dy.device)
+    linear_scratch(M, N, w.size(1))
     check(lib.stemgnn_linear_bwd_data(_p(dy), _p(w), M, N, w.size(1), _p(dx), _stream()), "linear_bwd_data")
     return dx
 
@@ -905,6 +943,7 @@ class LinearFn(torch.autograd.Function):
                 gx1 = torch.empty_like(x1)
                 gx1[rows:].zero_()  # rows past x1_rows do not reach the output: their gradient is zero, not garbage
                 if rows > 0:
+                    linear_scratch(rows, gy.size(1), w1.size(1))
                     check(lib.stemgnn_linear_bwd_data(_p(gy1), _p(w1), rows, gy.size(1), w1.size(1), _p(gx1), _stream()),
                           "linear_bwd_data")
             if need[1]:
@@ -989,6 +1028,7 @@ class VqAssignFn(torch.autograd.Function):
         sqerr = torch.empty(1, dtype=torch.float32, device=dev)
         ws = _workspace(lib.stemgnn_vq_workspace_bytes(N, H, Dc, K), dev)
         numel = max(N * H * Dc, 1)
+        linear_scratch(N, Dc, Dc, vq=(H, Dc, K))
         check(lib.stemgnn_vq_assign_fwd(_p(xp), N, H, Dc, _p(embed_c), K, int(bool(training)), None, _p(norm), _p(ind),
                                         _p(quant), _p(sqerr), float(loss_weight) / float(numel), _p(ws), ws.numel(),
                                         _stream()), "vq_assign_fwd")
@@ -1050,6 +1090,7 @@ class VqFn(torch.autograd.Function):
         quantize = torch.empty_like(z)
         ind = torch.empty(N, H, dtype=torch.int64, device=z.device)
         loss = torch.empty(1, dtype=torch.float32, device=z.device)
+        linear_scratch(N, z.size(1), w_in.size(0), vq=(H, embed.size(2), embed.size(1)))
         check(lib.stemgnn_vq_fwd(ctypes.byref(p), _p(z), N, int(bool(cfg["training"])), _p(quantize), _p(ind), _p(loss),
                                  _p(save), save.numel(), _stream()), "vq_fwd")
         ctx.cfg = cfg
@@ -1073,6 +1114,7 @@ class VqFn(torch.autograd.Function):
         scratch = _workspace(lib.stemgnn_vq_bwd_scratch_bytes(ctypes.byref(p), N), z.device)
         gq = None if g_quantize is None else g_quantize.contiguous()
         gl = None if g_loss is None else g_loss.reshape(1).contiguous().float()
+        linear_scratch(N, z.size(1), w_in.size(0))
         check(lib.stemgnn_vq_bwd(ctypes.byref(p), _p(z), N, _p(ind), _p(gq), _p(gl), _p(g_z), _p(save), save.numel(),
                                  _p(scratch), scratch.numel(), _stream()), "vq_bwd")
         g_w_in, g_b_in, g_w_out, g_b_out, g_embed = grads
@@ -1348,6 +1390,7 @@ class HeadsFn(torch.autograd.Function):
         losses = torch.empty(4, dtype=torch.float32, device=dev)
         save = _workspace(lib.stemgnn_heads_save_bytes(ctypes.byref(p), N, E, bs, k), dev)
         seed, (o1, o2, o3) = keys
+        linear_scratch(max(N, k), 2 * q.size(1), q.size(1))
         check(lib.stemgnn_heads_fwd(ctypes.byref(p), ctypes.byref(gv), _p(ei), _p(etype), E, _p(etab), etab.size(0), _p(q),
                                     _p(x_feat), _p(z_teacher), bs, k, seed, o1, o2, o3, _p(topo_perm), _p(topo_edges),
                                     _p(ts_perm), _p(ts_edges), _p(ts_type), _p(losses), _p(save), save.numel(), _stream()),
@@ -1375,6 +1418,7 @@ class HeadsFn(torch.autograd.Function):
         N = q.size(0)
         g_q = torch.empty_like(q)
         scratch = _workspace(lib.stemgnn_heads_bwd_scratch_bytes(ctypes.byref(p), N, bs, k), q.device)
+        linear_scratch(max(N, k), 2 * q.size(1), q.size(1))
         check(lib.stemgnn_heads_bwd(ctypes.byref(p), N, _p(q), _p(x_feat), _p(z_teacher), bs, k, _p(topo_edges),
                                     _p(ts_edges), _p(g_losses), _p(g_q), _p(save), save.numel(), E, _p(scratch),
                                     scratch.numel(), _stream()), "heads_bwd")

@@ -1091,13 +1091,16 @@ def test_vq_assign_weight_stationary_matches_the_tile_form(dev, N, H):
 
 
 @pytest.mark.parametrize("N,H,K,Dc", [(9000, 2, 512, 256), (8192, 3, 2048, 768)])
-def test_vq_assign_large_codebook_on_the_vendor_library(dev, N, H, K, Dc):
-    """The lean code assignment at large codebooks (K >= 512, Dc >= 256, N >= 8 192: BASELINE configs 3 / 5) as ONE
-    library GEMM over the six exact piece products (csrc/blaslt.hip: lt_vq_assign_lean) against the fused tile kernel
-    (library switched off) and against torch: indices (lowest index among equals; a duplicated code and a zero row
-    included), row norms, commitment sum.  The two sum their fp32 products in different orders: an index may differ
-    only where the top-2 similarity gap is at rounding level."""
+def test_vq_assign_large_codebook_on_the_bigtile_core(dev, N, H, K, Dc):
+    """The code assignment at large codebooks (K >= 512, Dc >= 256, N >= 8 192: BASELINE configs 3 / 5) on the big-tile
+    core (csrc/bigtile.hip: bt_vq_assign -- the six exact piece products of all heads as one launch, the arg-max taken
+    from the accumulators per 256-code tile, no [N, K] matrix) against the fused tile kernel (core switched off) and
+    against torch: indices (lowest index among equals; a duplicated code and a zero row included), row norms, commitment
+    sum.  The two sum their fp32 products in different orders: an index may differ only where the top-2 similarity gap
+    is at rounding level."""
+    from stem_gnn_amd import ops
     from stem_gnn_amd._lib import lib, check
+    ops.linear_scratch(N, Dc, Dc, vq=(H, Dc, K))  # the core's scratch is the caller's
     torch.manual_seed(N + K)
     st = torch.cuda.current_stream().cuda_stream
     xp = torch.randn(N, H * Dc, device=dev) * (0.5 + torch.rand(N, 1, device=dev))
@@ -1116,14 +1119,14 @@ def test_vq_assign_large_codebook_on_the_vendor_library(dev, N, H, K, Dc):
                                          ind.data_ptr(), sq.data_ptr(), 0.25, ws.data_ptr(), ws.numel(), st))
         return norm, ind, sq, lib.stemgnn_vq_assign_last_path()
 
-    prev = lib.stemgnn_linear_set_library_gemm(0)
+    prev = lib.stemgnn_linear_set_bigtile(0)
     try:
         n0, i0, s0, p0 = run()
-        lib.stemgnn_linear_set_library_gemm(1)
+        lib.stemgnn_linear_set_bigtile(1)
         n1, i1, s1, p1 = run()
     finally:
-        lib.stemgnn_linear_set_library_gemm(prev)
-    assert (p0, p1) == (1, 3)  # the tile kernel, then the library
+        lib.stemgnn_linear_set_bigtile(prev)
+    assert (p0, p1) == (1, 4)  # the tile kernel, then the big-tile core
     xh = xp.view(N, H, Dc)
     sim = torch.einsum("nhd,hkd->nhk", xh.double(), embed.double())
     top2 = sim.topk(2, dim=-1).values
@@ -1149,14 +1152,14 @@ def test_vq_assign_large_codebook_on_the_vendor_library(dev, N, H, K, Dc):
         return xn, q, ind, sq, lib.stemgnn_vq_assign_last_path()
 
     for training in (1, 0):
-        lib.stemgnn_linear_set_library_gemm(0)
+        lib.stemgnn_linear_set_bigtile(0)
         try:
             xn0, q0, j0, t0, p0 = run_full(training)
-            lib.stemgnn_linear_set_library_gemm(1)
+            lib.stemgnn_linear_set_bigtile(1)
             xn1, q1, j1, t1, p1 = run_full(training)
         finally:
-            lib.stemgnn_linear_set_library_gemm(prev)
-        assert (p0, p1) == (1, 3)
+            lib.stemgnn_linear_set_bigtile(prev)
+        assert (p0, p1) == (1, 4)
         same = (j1 == j0).unsqueeze(-1).expand(N, H, Dc).reshape(N, H * Dc)
         assert float((j1 != j0).float().mean()) < 1e-3
         torch.testing.assert_close(xn1, xn0, rtol=1e-6, atol=1e-7)

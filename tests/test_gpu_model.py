@@ -190,7 +190,7 @@ def test_vq_matches_reference_golden_at_production_shapes(dev, path, gemm_mode, 
         if lean and gemm_mode == 1 and K == 128 and Dc == 128 and N >= 16384:
             assert served_by == 2, "the weight-stationary assignment kernel must serve the production-shape case"
         elif gemm_mode == 1 and K >= 512 and Dc >= 256 and N >= 8192:
-            assert served_by in (3, 4), "the large-codebook assignment must serve the (9000, 256, 2, 512, 256) case"
+            assert served_by == 4, "the big-tile core must serve the (9000, 256, 2, 512, 256) case"
         elif lean:
             assert served_by == 1
         flips = assert_indices_match(ind.cpu(), want_ind, gap)
@@ -1063,15 +1063,20 @@ def test_bf16_gemm_mode_is_the_product_of_the_rounded_operands(dev, m, k1, k2, n
     torch.testing.assert_close(db.double(), dy.double().sum(0), rtol=1e-5, atol=1e-4 * float(dy.abs().sum(0).max()))
 
 
-@pytest.mark.parametrize("m,k1,k2,n,rows", [(32768, 768, 0, 768, -1), (20000, 512, 512, 1024, 4000), (9000, 512, 0, 3072, -1)])
-def test_bf16_gemm_mode_large_products_on_the_vendor_library(dev, m, k1, k2, n, rows):
-    """Mode 2's large products take a rounding pass + hipblasLtMatmul (csrc/blaslt.hip) instead of the tile kernel that
-    rounds while it stages: the same product -- rounded operands, fp32 accumulation --, checked against torch on the
-    rounded operands in fp64 AND against the tile kernels (library switched off), with bias, the two-operand form with
-    zero leading rows, the BatchNorm column sums, backward-data, weight and bias gradients."""
+@pytest.mark.parametrize("mode", [1, 2], ids=["exact", "bf16"])
+@pytest.mark.parametrize("m,k1,k2,n,rows", [(32768, 768, 0, 768, -1), (20000, 512, 512, 1024, 4000), (9000, 512, 0, 3072, -1),
+                                            (200_001, 256, 0, 256, -1)])
+def test_large_products_on_the_bigtile_core(dev, mode, m, k1, k2, n, rows):
+    """The large products (>= 8 192 rows, feature extents >= 256: the D = 768 configurations) run on the big-tile core
+    (csrc/bigtile.hip: cut pass + one 256 x 256 x 64 bf16 MFMA GEMM) in the exact mode (six exact piece products:
+    fp32-accurate, checked against fp64 of the fp32 operands) and in the bf16 GEMM mode (rounded operands, checked against
+    fp64 of the rounded operands) -- AND against the 128-row tile kernels (core switched off): y with bias, the
+    two-operand form with zero leading rows, the BatchNorm column sums, backward-data, weight and bias gradients.  Row
+    counts that are no multiple of the 256-row tile, a 12-tile-wide output, a one-tile output."""
     from stem_gnn_amd import ops
+    from stem_gnn_amd._lib import lib
     torch.manual_seed(m + n)
-    r = lambda t: t.bfloat16().double()  # noqa: E731
+    r = (lambda t: t.bfloat16().double()) if mode == 2 else (lambda t: t.double())  # noqa: E731
     a = torch.randn(m, k1, device=dev) * (1 + 3 * torch.rand(m, 1, device=dev))
     w = torch.randn(n, k1, device=dev) * 0.2
     a2 = torch.randn(m, k2, device=dev) if k2 else None
@@ -1080,47 +1085,82 @@ def test_bf16_gemm_mode_large_products_on_the_vendor_library(dev, m, k1, k2, n, 
     if rows >= 0:
         a[rows:] = 0
     dy = torch.randn(m, n, device=dev)
-    prev = ops.linear_set_mode(2)
+    prev = ops.linear_set_mode(mode)
     out = {}
     try:
-        from stem_gnn_amd._lib import lib
-        for lib_on in (1, 0):
-            was = ops.linear_set_library_gemm(lib_on)
-            served = lib.stemgnn_linear_library_calls()
+        for core_on in (1, 0):
+            was = ops.linear_set_bigtile(core_on)
+            served, missed = lib.stemgnn_linear_bigtile_calls(), lib.stemgnn_linear_bigtile_fallbacks()
             y, part, blocks = ops.linear_fwd(a, w, a2, w2, b, True, rows)
-            out[lib_on] = (y, part[:blocks].double().sum(0), ops.linear_bwd_data(dy, w), *ops.linear_bwd_weight(dy, a, True))
-            took = lib.stemgnn_linear_library_calls() - served  # forward, backward-data, weight gradient
-            assert took == 0 if not lib_on else (took == 3 if k2 == 0 else took >= 1), took
-            ops.linear_set_library_gemm(was)
+            out[core_on] = (y, part[:blocks].double().sum(0), ops.linear_bwd_data(dy, w), *ops.linear_bwd_weight(dy, a, True))
+            took = lib.stemgnn_linear_bigtile_calls() - served  # forward, backward-data, weight gradient
+            # (the two-operand case's backward products, over k1 alone, stay below the core's size gate)
+            assert took == 0 if not core_on else (took == 3 if k2 == 0 else took >= 1), took
+            assert lib.stemgnn_linear_bigtile_fallbacks() == missed  # the arena was there: nothing fell back
+            ops.linear_set_bigtile(was)
     finally:
         ops.linear_set_mode(prev)
     ref = r(a) @ r(w).t() + (r(a2) @ r(w2).t() if k2 else 0) + b.double()
     refs = (ref, torch.stack([ref.sum(0), (ref * ref).sum(0)]), r(dy) @ r(w), r(dy).t() @ r(a), dy.double().sum(0))
-    for name, got_lib, got_tile, want in zip(("y", "column sums", "dx", "dw", "db"), out[1], out[0], refs):
+    for name, got_core, got_tile, want in zip(("y", "column sums", "dx", "dw", "db"), out[1], out[0], refs):
         tol = 2e-5 * float(want.abs().max())
-        torch.testing.assert_close(got_lib.double(), want, rtol=1e-5, atol=tol, msg=lambda s_: f"{name} (library): {s_}")
-        torch.testing.assert_close(got_lib.double(), got_tile.double(), rtol=1e-5, atol=tol,
-                                   msg=lambda s_: f"{name} (library vs tile kernel): {s_}")
-    # an operand stored as bf16 (feature_kind 1: C5's hidden activations) goes to the library as it is
-    from stem_gnn_amd._lib import lib, check
+        torch.testing.assert_close(got_core.double(), want, rtol=1e-5, atol=tol, msg=lambda s_: f"{name} (core): {s_}")
+        torch.testing.assert_close(got_core.double(), got_tile.double(), rtol=1e-5, atol=tol,
+                                   msg=lambda s_: f"{name} (core vs tile kernel): {s_}")
+    # an operand stored as bf16 (feature_kind 1: C5's hidden activations) is its own h piece
+    from stem_gnn_amd._lib import check
     xb = a.bfloat16().contiguous()
     st = torch.cuda.current_stream().cuda_stream
-    prev = ops.linear_set_mode(2)
+    prev = ops.linear_set_mode(mode)
     try:
         dws = []
-        for lib_on in (1, 0):
-            was = ops.linear_set_library_gemm(lib_on)
+        for core_on in (1, 0):
+            was = ops.linear_set_bigtile(core_on)
             dw = torch.empty(n, k1, device=dev)
             ws = torch.empty(int(lib.stemgnn_linear_bwd_weight_workspace_bytes(m, n, k1)), dtype=torch.uint8, device=dev)
             check(lib.stemgnn_linear_bwd_weight_k(dy.data_ptr(), xb.data_ptr(), 1, m, n, k1, dw.data_ptr(), None, ws.data_ptr(),
                                                   ws.numel(), st))
             dws.append(dw)
-            ops.linear_set_library_gemm(was)
+            ops.linear_set_bigtile(was)
     finally:
         ops.linear_set_mode(prev)
     want = r(dy).t() @ xb.double()
     torch.testing.assert_close(dws[0].double(), want, rtol=1e-5, atol=2e-5 * float(want.abs().max()))
     torch.testing.assert_close(dws[0], dws[1], rtol=1e-5, atol=2e-5 * float(want.abs().max()))
+
+
+def test_bigtile_core_without_an_arena_is_a_counted_fallback_and_allocates_nothing(dev):
+    """The boundary's rule (entry points never allocate or synchronise) for the big-tile core: its
+    scratch is the caller's arena.  Without one a qualifying product runs on the tile kernels and the miss is COUNTED
+    (no error is swallowed, none is raised); with one, a whole bf16-mode product sequence is served with the device
+    allocator untouched -- torch's allocator statistics see no new segment, the arena's bytes do not move."""
+    from stem_gnn_amd import ops
+    from stem_gnn_amd._lib import lib, check
+    m, k, n = 40_000, 512, 768
+    x, w, dy = torch.randn(m, k, device=dev), torch.randn(n, k, device=dev) * 0.1, torch.randn(m, n, device=dev)
+    y = torch.empty(m, n, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    prev = ops.linear_set_mode(2)
+    try:
+        ops.linear_release_scratch()
+        missed, served = lib.stemgnn_linear_bigtile_fallbacks(), lib.stemgnn_linear_bigtile_calls()
+        check(lib.stemgnn_linear_fwd(x.data_ptr(), w.data_ptr(), k, None, None, 0, None, m, n, y.data_ptr(), None, None, -1, st))
+        assert lib.stemgnn_linear_bigtile_fallbacks() == missed + 1 and lib.stemgnn_linear_bigtile_calls() == served
+        y_tile = y.clone()
+        ops.linear_scratch(m, k, n)
+        torch.cuda.synchronize()
+        before = torch.cuda.memory_stats(dev)["num_device_alloc"]
+        for _ in range(3):
+            check(lib.stemgnn_linear_fwd(x.data_ptr(), w.data_ptr(), k, None, None, 0, None, m, n, y.data_ptr(), None, None, -1, st))
+            dx = ops.linear_bwd_data(dy, w)
+            dw, db = ops.linear_bwd_weight(dy, x, True)
+        torch.cuda.synchronize()
+        assert lib.stemgnn_linear_bigtile_calls() == served + 9 and lib.stemgnn_linear_bigtile_fallbacks() == missed + 1
+        # outputs are torch allocations from its cached pool; the LIBRARY made none: no new device segment appeared
+        assert torch.cuda.memory_stats(dev)["num_device_alloc"] == before
+        torch.testing.assert_close(y, y_tile, rtol=1e-5, atol=2e-5 * float(y_tile.abs().max()))
+    finally:
+        ops.linear_set_mode(prev)
 
 
 def test_deterministic_mode_makes_steps_bit_reproducible(dev):
