@@ -66,7 +66,7 @@ enum { kEpiStore = 0, kEpiArgmax = 1 };
 struct BtArgs {
   BtOp a, b;
   BtSeg seg[kMaxSeg];
-  int nseg, tiles_m, tiles_n, splits, batch;
+  int nseg, tiles_m, tiles_n, splits, batch, work;
   int64_t b_full_rows;
   // kEpiStore: y[bz * y_bs + split * y_ss + j * ldy + i] = C[i][j] (+ bias[i]) for j < store_rows; stats (optional):
   // per b-row tile column sums / sums of squares over the rows j < b.rows: stats[tn][2][a.rows]
@@ -93,11 +93,18 @@ __global__ void __launch_bounds__(kBtThreads) k_bt_gemm(const BtArgs g) {
   const int wr = wid >> 2, wc = wid & 3;
   const int fr = lane & 15, fq = lane >> 4;
 
-  // ---- block -> (batch, split, a tile, b tile): blocks that share an XCD (bid % 8) take consecutive work ids, and
-  // consecutive ids walk patches of 4 b tiles x all a tiles, so co-resident blocks share operand panels in their L2
-  const int nwg = gridDim.x, bid = blockIdx.x;
-  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
-  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  // ---- persistent blocks (one per CU): a block walks work ids (batch, split, a tile, b tile).  Blocks that share an XCD
+  // (bid % 8) own one contiguous stretch of the ids and take them round-robin, so the blocks resident on an XCD work on
+  // NEIGHBOURING ids at any time; consecutive ids walk patches of 4 b tiles x all a tiles -> they share operand panels
+  // in their L2.  A block's output stores drain while it already stages and multiplies its next tile.
+  const int nb = gridDim.x, bid = blockIdx.x;
+  const int nx = nb < 8 ? nb : 8;
+  const int xcd = bid % nx, local = bid / nx;
+  const int nbx = nb / nx + (xcd < nb % nx ? 1 : 0);
+  const int wq = g.work / nx, wrm = g.work % nx;
+  const int wstart = xcd * wq + (xcd < wrm ? xcd : wrm), wcount = wq + (xcd < wrm ? 1 : 0);
+  for (int wi = local; wi < wcount; wi += nbx) {
+  const int wg = wstart + wi;
   const int per = g.tiles_m * g.tiles_n;
   const int outer = wg / per, rem = wg - outer * per;
   const int bz = outer / g.splits, split = outer - bz * g.splits;
@@ -325,6 +332,7 @@ __global__ void __launch_bounds__(kBtThreads) k_bt_gemm(const BtArgs g) {
         const float* rr = red + (st * 8 + half * 4) * 128 + il;
         g.stats[(static_cast<int64_t>(tn) * 2 + st) * g.a.rows + i] = (rr[0] + rr[128]) + (rr[256] + rr[384]);
       }
+      __syncthreads();  // the partial sums' LDS is read: the next tile may stage
     }
   } else {
     // running arg-max over this tile's a rows (codes), per b row (data row): a lane's codes ascend with (mi, r), so a
@@ -368,7 +376,9 @@ __global__ void __launch_bounds__(kBtThreads) k_bt_gemm(const BtArgs g) {
         g.cand_idx[o] = bi;
       }
     }
+    __syncthreads();  // the candidates' LDS is read: the next tile may stage
   }
+  }  // work ids
 }
 
 
@@ -509,18 +519,23 @@ k_bt_cut_cols(const void* __restrict__ x_, int kind, int64_t R, int C, uint16_t*
   }
 }
 
-// db[c] = sum over slabs of colsum[slab][c], fixed order, fp64 accumulation
+// db[c] = sum over slabs of colsum[slab][c], fixed order, fp64 accumulation: 16 columns x 16 slab slices per block
 __global__ void __launch_bounds__(kCutThreads)
 k_bt_colsum_finish(const float* __restrict__ partial, int slabs, int C, float* __restrict__ db) {
   __shared__ double red[kCutThreads];
-  const int cl = threadIdx.x & 63, slice = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
+  const int cl = threadIdx.x & 15, slice = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
   double s = 0.0;
   if (c < C)
-    for (int b = slice; b < slabs; b += 4) s += partial[static_cast<int64_t>(b) * C + c];
+    for (int b = slice; b < slabs; b += 16) s += partial[static_cast<int64_t>(b) * C + c];
   red[threadIdx.x] = s;
   __syncthreads();
-  if (slice == 0 && c < C) db[c] = static_cast<float>((red[cl] + red[64 + cl]) + (red[128 + cl] + red[192 + cl]));
+  if (slice == 0 && c < C) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k * 16 + cl];
+    db[c] = static_cast<float>(t);
+  }
 }
 
 // out[i] = sum over s < splits of slab[s][i] (+ nothing): the weight gradient's split slabs, fixed order
@@ -650,8 +665,18 @@ inline unsigned cut_grid(int64_t elems4) {
 int bt_launch(BtArgs& a, int epi, hipStream_t st) {
   a.tiles_m = static_cast<int>((a.a.rows + kTile - 1) / kTile);
   a.tiles_n = static_cast<int>((a.b.rows + kTile - 1) / kTile);
-  const int64_t blocks = static_cast<int64_t>(a.tiles_m) * a.tiles_n * a.splits * a.batch;
-  if (blocks <= 0 || blocks >= (1ll << 31) || a.a.rows * a.a.ld >= (1ll << 31) || a.b.rows * a.b.ld >= (1ll << 31))
+  const int64_t work = static_cast<int64_t>(a.tiles_m) * a.tiles_n * a.splits * a.batch;
+  static const int cus = [] {
+    int n = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
+      (void)hipGetLastError();
+      n = 256;
+    }
+    return n;
+  }();
+  const int64_t blocks = std::min<int64_t>(work, cus);  // one persistent block per CU (128 KiB of LDS each)
+  a.work = static_cast<int>(work);
+  if (work <= 0 || work >= (1ll << 31) || a.a.rows * a.a.ld >= (1ll << 31) || a.b.rows * a.b.ld >= (1ll << 31))
     return STEMGNN_ERR_TOO_LARGE;
   static const hipError_t attr0 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_bt_gemm<kEpiStore>),
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, kBtLds);
@@ -868,7 +893,7 @@ int bt_linear_bwd_weight(int pieces, const float* dy, const void* x, int x_kind,
     STEMGNN_LAUNCH_CHECK();
   }
   if (db) {
-    k_bt_colsum_finish<<<static_cast<unsigned>((N + 63) / 64), kCutThreads, 0, st>>>(part, row_blocks, static_cast<int>(N), db);
+    k_bt_colsum_finish<<<static_cast<unsigned>((N + 15) / 16), kCutThreads, 0, st>>>(part, row_blocks, static_cast<int>(N), db);
     STEMGNN_LAUNCH_CHECK();
   }
   return STEMGNN_OK;
