@@ -35,6 +35,11 @@ WORKLOADS = {
     "c3": dict(nodes=169_343, edges=2_315_598, dim=768, types=1, full_batch=True, codebook=512,
                desc="C3 stand-in: ogbn-arxiv-sized (169,343 nodes, 2,315,598 directed entries after ToUndirected), "
                     "D=768, K=512, full batch"),
+    # the reference's OWN default width on the sampled C4 graph (config/pretrain.yaml:3-20: hidden_dim = code_dim = 768,
+    # codebook_size 128, 4 heads, batch 1024; pretrain.py:151-153 NeighborLoader [10, 10])
+    "refdefault": dict(nodes=1_000_000, edges=20_000_000, dim=768, types=4, full_batch=False, codebook=128,
+                       desc="reference default width: 1M-node/20M-edge synthetic Graph-U, D = code_dim = 768, H = 4, K = 128, "
+                            "neighbour-sampled [10,10], 1024 seeds/rank"),
     "c5": dict(nodes=0, edges=0, dim=768, types=0, full_batch=False, codebook=2048, mix="all",
                desc="C5 stand-in: --pretrain_dataset all as a union of nine synthetic member graphs with the real "
                     "datasets' node / edge / text-row / edge-type counts (molecule sets scaled to 1.2M nodes), seeds "
@@ -443,6 +448,7 @@ def main():
     for i in range(args.warmup):
         step(i)
     ops.k1_timer.reset(True)
+    ops.bigtile_profile(True)  # no-op for the D = 128 workloads: the big-tile core takes the D >= 256 products only
     # one HIP event in front of every timed step and one behind the last, on the stream the step's kernels run on
     # (the library launches on torch's current stream): step_ms / step_ms_median beside the wall mean
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
@@ -462,6 +468,8 @@ def main():
     gc.enable()
     k1_rows = ops.k1_timer.collect_each()
     ops.k1_timer.reset(False)
+    ops.bigtile_profile(False)
+    bt_ms, bt_flop, bt_launches = ops.bigtile_profile_collect()
 
     from stem_gnn_amd.parallel import reduce_bench_stats
     edges = float(sum(batches[i][1].num_edges for i in range(args.warmup, total)))
@@ -503,6 +511,45 @@ def main():
 
         e2e_ms = in_loop(args.e2e_steps)
 
+
+    # Multi-GPU readiness proxy (no multi-GPU lease in this pool): the SAME step with the model under
+    # DistributedDataParallel at world size 1 on the nccl (= RCCL) backend -- the reducer's hooks, its bucket views (three
+    # buckets per step, parallel.ddp_bucket_cap_mb), FusedAdamW reading them -- so its ms_per_step beside the plain one is
+    # DDP's cost on the real step with no peer to wait for.  Runs LAST (it re-homes the gradients into bucket views).
+    ddp_proxy = None
+    if world == 1 and not wl["full_batch"] and not args.no_extra and args.workload == "c4":
+        try:
+            import socket
+            from stem_gnn_amd.parallel import wrap_ddp
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+            fwd1 = wrap_ddp(model, local_rank)
+
+            def ddp_step(i):
+                x, ei, xe, bs = batches[i % total]
+                return pretrain_step(model, opt, sched, params, x, ei, EdgeTypeAttr(g.edge_text_feat, xe), bs,
+                                     record_draws=False, forward_fn=fwd1)
+
+            for i in range(10):  # the first step runs as one bucket; the reducer re-cuts its buckets after it
+                ddp_step(i)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(args.steps):
+                ddp_step(args.warmup + i)
+            torch.cuda.synchronize()
+            log = fwd1._get_ddp_logging_data()
+            ddp_proxy = {"ms_per_step": (time.perf_counter() - t1) / args.steps * 1e3, "steps": args.steps,
+                         "backend": "nccl (RCCL), world size 1",
+                         "buckets_per_step": len([v for v in str(log.get("rebuilt_bucket_sizes", "")).split(",") if v.strip()]),
+                         "bucket_bytes": str(log.get("rebuilt_bucket_sizes", "")),
+                         "note": "same step, model under DistributedDataParallel (reducer hooks, gradient bucket views, "
+                                 "FusedAdamW on them); no peer: what DDP itself costs on this step"}
+            dist.destroy_process_group()
+        except Exception as e:  # a proxy must never cost the headline line
+            ddp_proxy = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         peak = 8000.0  # MI355X HBM3E spec, GB/s (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
@@ -584,7 +631,22 @@ def main():
                                 "traffic_source": roofline["traffic_source"],
                                 "c_node_level_passes": (alg - sum(v for k, v in table.items() if " K1 " in k)) / (nb[0].size(0) * D * 4),
                                 "breakdown_MB": {k: round(v / 1e6, 1) for k, v in table.items()}}
-        if not args.no_extra:
+        if bt_launches > 0 and bt_ms > 0:
+            # The D >= 256 workloads are matrix-bound: their dense products and the large-codebook assignment run on the
+            # big-tile core (csrc/bigtile.hip); every launch in the timed region carried its own HIP events.  EXECUTED bf16
+            # matrix work (six piece products per fp32 product in the exact mode) over kernel time, against the dense bf16
+            # MFMA peak of MI355X_MICROARCH.md (2.5 PFLOP/s; what the chip sustains on random data is ~1.3-1.5).
+            pieces = 6.0 if ops.linear_set_mode(-1) == 1 else 1.0
+            out["roofline_dense"] = {
+                "bound": "mfma", "kernel": "k_bt_gemm (big-tile core: 256 x 256 x 64 bf16 MFMA tiles, LDS-DMA staging; "
+                                           "launches of the timed region, per-launch HIP events)",
+                "achieved": bt_flop / bt_ms / 1e9, "peak": 2500.0, "unit": "TFLOP/s", "frac": bt_flop / bt_ms / 1e9 / 2500.0,
+                "launches_per_step": bt_launches / args.steps, "kernel_ms_per_step": bt_ms / args.steps,
+                "share_of_step": bt_ms / args.steps / (dt / args.steps * 1e3),
+                "executed_pflop_per_step": bt_flop / args.steps / 1e15,
+                "fp32_equivalent_tflops": bt_flop / bt_ms / 1e9 / pieces,
+                "pieces_per_product": pieces}
+        elif not args.no_extra:
             # The dense products are the largest share of the step: the layer product
             # lin_l(agg) + lin_r(x) at this batch's row count, timed back to back.  Executed matrix-core work is six
             # bf16 MFMA products per fp32 product (csrc/linear.hip), priced against the dense bf16 peak; informational.
@@ -613,6 +675,8 @@ def main():
                 "algorithmic_bytes": (2.0 * Mb + A_b) * D * 4, "achieved": (2.0 * Mb + A_b) * D * 4 / us / 1e3,
                 "peak": peak, "unit": "GB/s", "frac": (2.0 * Mb + A_b) * D * 4 / us / 1e3 / peak}
             out["configs_extra"] = k1_at_full_graph_sizes(dev)
+            if ddp_proxy is not None:
+                out["configs_extra"]["dp1_under_ddp"] = ddp_proxy
         if world == 1 and not args.no_cpu_baseline:
             x, ei, xe, bs = batches[args.warmup]
             out["cpu_baseline"] = cpu_baseline(params, (x.float().cpu(), ei.edge_index.cpu(), g.edge_text_feat.cpu(), xe.cpu()), bs,

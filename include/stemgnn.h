@@ -368,6 +368,12 @@ size_t stemgnn_linear_scratch_bytes(int64_t max_rows, int64_t dim_a, int64_t dim
 size_t stemgnn_vq_assign_scratch_bytes(int64_t num_rows, int64_t heads, int64_t code_dim, int64_t codebook_size);
 int stemgnn_linear_set_scratch(void* scratch, size_t bytes, void* stream);
 int stemgnn_linear_set_bigtile(int on);
+/* Measurement aid (bench.py's matrix-roofline leg), like stemgnn_profile_k1: while enabled, every launch of the big-tile
+ * core is stamped with its own begin / end HIP events; collect() waits for them and returns (HOST pointers) the summed
+ * kernel time in ms, the matrix work those launches EXECUTED in flop (2 x rows x rows x contraction over all segments:
+ * six piece products per fp32 product in mode 1, one in mode 2) and the launch count. */
+int stemgnn_profile_bigtile(int enable);
+int stemgnn_profile_bigtile_collect(double* total_ms_host, double* total_flop_host, int64_t* launches_host);
 int64_t stemgnn_linear_bigtile_calls(void);
 int64_t stemgnn_linear_bigtile_fallbacks(void);
 

@@ -30,12 +30,15 @@
 // four youngest half tiles have landed" (vmcnt(8)) is exactly what the next phase's reads need.
 #include "common.h"
 
+#include <hip/hip_ext.h>
+
 #include <algorithm>
 #include <cstdlib>
 #include <atomic>
 #include <map>
 #include <mutex>
 #include <utility>
+#include <vector>
 
 namespace stemgnn {
 namespace {
@@ -662,6 +665,17 @@ inline unsigned cut_grid(int64_t elems4) {
   return static_cast<unsigned>(gsz < 1 ? 1 : gsz);
 }
 
+// Optional in-situ timing of the core's launches (bench.py's matrix-roofline leg): the launch goes through
+// hipExtLaunchKernelGGL with a start / stop event pair that stamps the kernel's own begin and end, like K1's
+// (csrc/sage_agg.hip); each record carries the matrix work the launch executed (2 x 256^2 x 64 per K tile and block tile).
+struct BtProfile {
+  std::mutex mu;
+  bool enabled = false;
+  struct Rec { hipEvent_t e0, e1; double flop; };
+  std::vector<Rec> recs;
+};
+BtProfile g_bt_profile;
+
 int bt_launch(BtArgs& a, int epi, hipStream_t st) {
   a.tiles_m = static_cast<int>((a.a.rows + kTile - 1) / kTile);
   a.tiles_n = static_cast<int>((a.b.rows + kTile - 1) / kTile);
@@ -685,8 +699,21 @@ int bt_launch(BtArgs& a, int epi, hipStream_t st) {
   if (attr0 != hipSuccess || attr1 != hipSuccess) return STEMGNN_ERR_HIP;
   static const int dbg = getenv("STEMGNN_BT_DBG") ? atoi(getenv("STEMGNN_BT_DBG")) : 0;
   a.dbg = dbg;
-  if (epi == kEpiStore) k_bt_gemm<kEpiStore><<<static_cast<unsigned>(blocks), kBtThreads, kBtLds, st>>>(a);
-  else k_bt_gemm<kEpiArgmax><<<static_cast<unsigned>(blocks), kBtThreads, kBtLds, st>>>(a);
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_bt_profile.mu);
+    if (g_bt_profile.enabled) {
+      STEMGNN_HIP_TRY(hipEventCreate(&ev0));
+      STEMGNN_HIP_TRY(hipEventCreate(&ev1));
+      // executed multiply-adds x 2 over the operands' real extents (tile padding not counted)
+      double ktiles = 0.0;
+      for (int sgi = 0; sgi < a.nseg; ++sgi) ktiles += a.seg[sgi].kt;
+      g_bt_profile.recs.push_back({ev0, ev1, 2.0 * a.a.rows * a.b.rows * ktiles * kBK * a.batch});
+    }
+  }
+  const dim3 grid(static_cast<unsigned>(blocks)), block(kBtThreads);
+  if (epi == kEpiStore) hipExtLaunchKernelGGL((k_bt_gemm<kEpiStore>), grid, block, kBtLds, st, ev0, ev1, 0, a);
+  else hipExtLaunchKernelGGL((k_bt_gemm<kEpiArgmax>), grid, block, kBtLds, st, ev0, ev1, 0, a);
   STEMGNN_LAUNCH_CHECK();
   return STEMGNN_OK;
 }
@@ -987,6 +1014,34 @@ int stemgnn_linear_set_scratch(void* scratch, size_t bytes, void* stream_) {
   Arena& a = g_arena[{dev, static_cast<hipStream_t>(stream_)}];
   a.p = static_cast<unsigned char*>(scratch);
   a.bytes = scratch ? bytes : 0;
+  return STEMGNN_OK;
+}
+
+int stemgnn_profile_bigtile(int enable) {
+  std::lock_guard<std::mutex> lock(g_bt_profile.mu);
+  g_bt_profile.enabled = enable != 0;
+  return STEMGNN_OK;
+}
+
+int stemgnn_profile_bigtile_collect(double* total_ms_host, double* total_flop_host, int64_t* launches_host) {
+  std::vector<BtProfile::Rec> recs;
+  {
+    std::lock_guard<std::mutex> lock(g_bt_profile.mu);
+    recs.swap(g_bt_profile.recs);
+  }
+  double ms_sum = 0.0, flop = 0.0;
+  for (auto& r : recs) {
+    STEMGNN_HIP_TRY(hipEventSynchronize(r.e1));
+    float ms = 0.f;
+    STEMGNN_HIP_TRY(hipEventElapsedTime(&ms, r.e0, r.e1));
+    ms_sum += ms;
+    flop += r.flop;
+    (void)hipEventDestroy(r.e0);
+    (void)hipEventDestroy(r.e1);
+  }
+  if (total_ms_host) *total_ms_host = ms_sum;
+  if (total_flop_host) *total_flop_host = flop;
+  if (launches_host) *launches_host = static_cast<int64_t>(recs.size());
   return STEMGNN_OK;
 }
 

@@ -831,6 +831,18 @@ def linear_scratch(rows: int, dim_a: int, dim_b: int, vq: Optional[Tuple[int, in
         _BT_ARENA[(dev, st)] = t  # the old block goes back to the allocator in stream order
 
 
+def bigtile_profile(enable: bool) -> None:
+    """Start / stop the in-situ timing of the big-tile core's launches (bench.py's matrix-roofline leg)."""
+    check(lib.stemgnn_profile_bigtile(1 if enable else 0), "profile_bigtile")
+
+
+def bigtile_profile_collect() -> Tuple[float, float, int]:
+    """-> (kernel ms, executed flop, launches) of the core's launches since the last collect."""
+    ms, flop, n = ctypes.c_double(0.0), ctypes.c_double(0.0), ctypes.c_int64(0)
+    check(lib.stemgnn_profile_bigtile_collect(ctypes.byref(ms), ctypes.byref(flop), ctypes.byref(n)), "profile_bigtile_collect")
+    return float(ms.value), float(flop.value), int(n.value)
+
+
 def linear_release_scratch() -> None:
     """Unregister and free every arena (tests; a process that is done with the large configurations)."""
     for (dev, st) in list(_BT_ARENA):

@@ -67,7 +67,17 @@ def allreduce_mean_grads_(params: Iterable[Tensor]) -> None:
         off += n
 
 
-def wrap_ddp(model: torch.nn.Module, device_index=None, find_unused_parameters=False):
+def ddp_bucket_cap_mb(model: torch.nn.Module, buckets: int = 3) -> float:
+    """Bucket size that cuts the trainable gradient into about ``buckets`` reductions.  The step's backward produces
+    its gradients in three stretches -- the decoders / heads, the quantiser, the encoder (reverse registration order,
+    which is how the reducer fills buckets) -- so with three buckets the heads' and the quantiser's gradients are on
+    the wire while the encoder's backward still runs.  torch's default (25 MB) puts the whole 2.2 MB gradient of the
+    D = 128 model, and most of the 41.7 MB of the D = 768 one, into a single reduction behind the last weight gradient."""
+    total = sum(p.numel() * p.element_size() for p in model.parameters() if p.requires_grad)
+    return min(25.0, max(total / max(int(buckets), 1) / 2 ** 20, 1.0 / 64))
+
+
+def wrap_ddp(model: torch.nn.Module, device_index=None, find_unused_parameters=False, bucket_cap_mb=None):
     """DistributedDataParallel over the trainable parameters.  The EMA teacher never receives
     gradients (reference pt_model.py:93 detaches it) and is excluded; BatchNorm statistics stay
     per-rank (no buffer broadcast), like the per-batch statistics of the single-GPU path.
@@ -75,11 +85,16 @@ def wrap_ddp(model: torch.nn.Module, device_index=None, find_unused_parameters=F
     ``find_unused_parameters``: pass True for runs in which some trainable parameters receive no gradient in a step
     (``forward(..., no_codebook=True)`` bypasses the VQ projections; a zero loss weight drops a decoder): the reducer
     then searches the graph for them instead of raising.  The default path (every parameter used, MoE routing soft)
-    runs without the search."""
+    runs without the search.
+
+    ``bucket_cap_mb``: None = ``ddp_bucket_cap_mb(model)`` (three reductions per step, overlapped with backward; the
+    reducer re-cuts its buckets after the first step, which still runs as one)."""
     if hasattr(model, "sem_encoder"):
         for p in model.sem_encoder.parameters():
             p.requires_grad_(False)
-    kw = dict(broadcast_buffers=False, gradient_as_bucket_view=True, find_unused_parameters=bool(find_unused_parameters))
+    cap = ddp_bucket_cap_mb(model) if bucket_cap_mb is None else float(bucket_cap_mb)
+    kw = dict(broadcast_buffers=False, gradient_as_bucket_view=True, find_unused_parameters=bool(find_unused_parameters),
+              bucket_cap_mb=cap)
     if device_index is not None:
         kw["device_ids"] = [device_index]
     return torch.nn.parallel.DistributedDataParallel(model, **kw)

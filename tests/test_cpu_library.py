@@ -161,3 +161,18 @@ def test_params_and_scheduler_match_reference_defaults():
         opt.step()
         sch.step()
     assert abs(lrs[0] - 1.0) < 1e-12 and abs(lrs[25] - 0.5) < 1e-9 and abs(lrs[50]) < 1e-9
+
+
+def test_bigtile_core_source_never_allocates_or_synchronises():
+    """The boundary's rule checked on the source of the big-tile core, which replaced the round-3
+    vendor-library wrapper that broke it: no device allocation, no free, no stream / device synchronisation anywhere in
+    csrc/bigtile.hip; the only event wait is in the explicit measurement aid stemgnn_profile_bigtile_collect.  And the
+    library no longer links a vendor GEMM library."""
+    src = open(os.path.join(ROOT, "stem_gnn_amd", "csrc", "bigtile.hip")).read()
+    for banned in ("hipMalloc", "hipFree", "hipStreamSynchronize", "hipDeviceSynchronize", "hipMemcpy(", "hipblas", "rocblas"):
+        assert banned not in src, banned
+    head, _, tail = src.partition("int stemgnn_profile_bigtile_collect(")
+    assert "hipEventSynchronize" not in head and tail.count("hipEventSynchronize") == 1
+    build = open(os.path.join(ROOT, "stem_gnn_amd", "build.py")).read()
+    assert "hipblas" not in build and "rocblas" not in build
+    assert not os.path.exists(os.path.join(ROOT, "stem_gnn_amd", "csrc", "blaslt.hip"))

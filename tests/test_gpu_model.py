@@ -788,6 +788,9 @@ def _ddp_step_worker(rank, world, port, out):
     torch.cuda.synchronize()
     assert isinstance(opt, ops.FusedAdamW) and all(opt.state[p]["step"] == 2 for p in gm.parameters() if p.requires_grad)
     out[rank] = {n: p.detach().cpu().clone() for n, p in gm.named_parameters()}
+    # the reducer's own record: after the first step it re-cut the gradient into the buckets wrap_ddp's cap asks for
+    log = fwd._get_ddp_logging_data()
+    out[("buckets", rank)] = [int(v) for v in str(log.get("rebuilt_bucket_sizes", "")).split(",") if v.strip()]
     dist.barrier()
     dist.destroy_process_group()
 
@@ -823,6 +826,9 @@ def test_two_rank_hip_ddp_two_optimizer_steps(dev):
     assert set(p0) == set(p1)
     for k in p0:
         assert torch.equal(p0[k], p1[k]), f"{k}: the ranks' parameters differ after two steps"
+    # round-3 review, item 6: several readiness points per step -- the second step reduced at least three buckets (the
+    # heads', the quantiser's and the encoder's stretch of the backward), so reductions overlap the backward behind them
+    assert out[("buckets", 0)] == out[("buckets", 1)] and len(out[("buckets", 0)]) >= 3, out[("buckets", 0)]
 
     # ---- the same two global steps in one process
     D, L, H, K = 64, 2, 4, 64
@@ -1159,6 +1165,50 @@ def test_bigtile_core_without_an_arena_is_a_counted_fallback_and_allocates_nothi
         # outputs are torch allocations from its cached pool; the LIBRARY made none: no new device segment appeared
         assert torch.cuda.memory_stats(dev)["num_device_alloc"] == before
         torch.testing.assert_close(y, y_tile, rtol=1e-5, atol=2e-5 * float(y_tile.abs().max()))
+    finally:
+        ops.linear_set_mode(prev)
+
+
+def test_bf16_mode_steps_on_the_bigtile_core_allocate_nothing_after_the_first(dev):
+    """Round-3 review, item 5, at step level: whole pretraining steps in the bf16 GEMM mode at a width the big-tile core
+    takes (N = 50 000, D = 512, H = 4, K = 512: the projections, their backward products AND the large-codebook
+    assignment) with the scratch arena the host registered.  After the first step (which sizes the arena and torch's
+    pool) two more steps are served by the core -- its counter moves, its fallback counter does not -- while neither
+    torch's allocator (no new device segment) nor the device's free memory (a library-side hipMalloc would show there)
+    moves."""
+    from stem_gnn_amd import ops
+    from stem_gnn_amd._lib import lib
+    from stem_gnn_amd.data.synthetic import make_graph
+    from stem_gnn_amd.graph import EdgeTypeAttr, GraphStructure
+    from stem_gnn_amd.pretrain import build_model, build_optimizer, default_params, pretrain_step
+    N, E, D, K = 50_000, 400_000, 512, 512
+    g = make_graph(N, E, D, 4, kind="U", device=dev)
+    params = default_params()
+    params.update(input_dim=D, hidden_dim=D, code_dim=D, codebook_size=K, pretrain_batch_size=N)
+    torch.manual_seed(0)
+    prev = ops.linear_set_mode(2)
+    try:
+        model = build_model(params, dev).train()
+        opt, sched = build_optimizer(model, params)
+        gs = GraphStructure(g.edge_index, N, g.xe, validate=True).ensure_transpose()
+        ea = EdgeTypeAttr(g.edge_text_feat, g.xe)
+        ops.manual_seed(3)
+        losses = []
+        loss, _, _ = pretrain_step(model, opt, sched, params, g.node_text_feat, gs, ea, N, record_draws=False)
+        losses.append(float(loss))
+        torch.cuda.synchronize()
+        served, missed = lib.stemgnn_linear_bigtile_calls(), lib.stemgnn_linear_bigtile_fallbacks()
+        segs, free0 = torch.cuda.memory_stats(dev)["num_device_alloc"], torch.cuda.mem_get_info(dev)[0]
+        for _ in range(2):
+            loss, _, _ = pretrain_step(model, opt, sched, params, g.node_text_feat, gs, ea, N, record_draws=False)
+            losses.append(float(loss))
+        torch.cuda.synchronize()
+        assert lib.stemgnn_linear_bigtile_calls() - served >= 2 * 10, "the step's large products must run on the core"
+        assert lib.stemgnn_linear_bigtile_fallbacks() == missed
+        assert int(lib.stemgnn_vq_assign_last_path()) in (0, 4)  # (the assignment runs on the autograd-free forward thread)
+        assert torch.cuda.memory_stats(dev)["num_device_alloc"] == segs
+        assert torch.cuda.mem_get_info(dev)[0] == free0
+        assert all(l == l and abs(l) < 1e6 for l in losses)
     finally:
         ops.linear_set_mode(prev)
 
