@@ -789,6 +789,11 @@ def _ddp_step_worker(rank, world, port, out):
     assert isinstance(opt, ops.FusedAdamW) and all(opt.state[p]["step"] == 2 for p in gm.parameters() if p.requires_grad)
     out[rank] = {n: p.detach().cpu().clone() for n, p in gm.named_parameters()}
     # the reducer's own record: after the first step it re-cut the gradient into the buckets wrap_ddp's cap asks for
+    # (its statistics are refreshed every few iterations: one more step, after the parameters have been handed back)
+    x, ei, table, et = batches[(rank, 0)]
+    pretrain_step(gm, opt, sched, params, x.to(dev), ei.to(dev), EdgeTypeAttr(table.to(dev), et.to(dev)), 128,
+                  record_draws=False, forward_fn=fwd)
+    torch.cuda.synchronize()
     log = fwd._get_ddp_logging_data()
     out[("buckets", rank)] = [int(v) for v in str(log.get("rebuilt_bucket_sizes", "")).split(",") if v.strip()]
     dist.barrier()
