@@ -71,6 +71,8 @@ def parse():
     ap.add_argument("--preheat", default="auto", choices=["auto", "off"],
                     help="auto: untimed steps until the step time has settled (>= 0.3 s, <= 1 s), before the counted "
                          "--warmup; off: the counted warm-up only")
+    ap.add_argument("--no-dense-profile", action="store_true",
+                    help="do not stamp the big-tile core's launches with HIP events in the timed region (A/B of the stamps' cost)")
     ap.add_argument("--no-extra", action="store_true", help="skip the K1 legs at C2 / C3 size and the dense-product leg")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
     return ap.parse_args()
@@ -448,7 +450,7 @@ def main():
     for i in range(args.warmup):
         step(i)
     ops.k1_timer.reset(True)
-    ops.bigtile_profile(True)  # no-op for the D = 128 workloads: the big-tile core takes the D >= 256 products only
+    ops.bigtile_profile(not args.no_dense_profile)  # no-op for the D = 128 workloads: the big-tile core takes the D >= 256 products only
     # one HIP event in front of every timed step and one behind the last, on the stream the step's kernels run on
     # (the library launches on torch's current stream): step_ms / step_ms_median beside the wall mean
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
@@ -526,27 +528,31 @@ def main():
                 port = sk.getsockname()[1]
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
-            fwd1 = wrap_ddp(model, local_rank)
-
-            def ddp_step(i):
-                x, ei, xe, bs = batches[i % total]
-                return pretrain_step(model, opt, sched, params, x, ei, EdgeTypeAttr(g.edge_text_feat, xe), bs,
-                                     record_draws=False, forward_fn=fwd1)
-
-            for i in range(10):  # the first step runs as one bucket; the reducer re-cuts its buckets after it
-                ddp_step(i)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for i in range(args.steps):
-                ddp_step(args.warmup + i)
-            torch.cuda.synchronize()
-            log = fwd1._get_ddp_logging_data()
-            ddp_proxy = {"ms_per_step": (time.perf_counter() - t1) / args.steps * 1e3, "steps": args.steps,
-                         "backend": "nccl (RCCL), world size 1",
-                         "buckets_per_step": len([v for v in str(log.get("rebuilt_bucket_sizes", "")).split(",") if v.strip()]),
-                         "bucket_bytes": str(log.get("rebuilt_bucket_sizes", "")),
+            ddp_proxy = {"backend": "nccl (RCCL), world size 1", "steps": args.steps,
                          "note": "same step, model under DistributedDataParallel (reducer hooks, gradient bucket views, "
                                  "FusedAdamW on them); no peer: what DDP itself costs on this step"}
+            for label, cap in (("one_bucket", 25.0), ("three_buckets", None)):  # torch's default cap, then wrap_ddp's own
+                fwd1 = wrap_ddp(model, local_rank, bucket_cap_mb=cap)
+
+                def ddp_step(i):
+                    x, ei, xe, bs = batches[i % total]
+                    return pretrain_step(model, opt, sched, params, x, ei, EdgeTypeAttr(g.edge_text_feat, xe), bs,
+                                         record_draws=False, forward_fn=fwd1)
+
+                for i in range(10):  # the first step runs as one bucket; the reducer re-cuts its buckets after it
+                    ddp_step(i)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for i in range(args.steps):
+                    ddp_step(args.warmup + i)
+                torch.cuda.synchronize()
+                ms = (time.perf_counter() - t1) / args.steps * 1e3
+                log = fwd1._get_ddp_logging_data()
+                sizes = str(log.get("rebuilt_bucket_sizes", "") or log.get("bucket_sizes", ""))
+                ddp_proxy[label] = {"ms_per_step": ms, "buckets_per_step": len([v for v in sizes.split(",") if v.strip()]),
+                                    "bucket_bytes": sizes}
+                del fwd1
+            ddp_proxy["ms_per_step"] = ddp_proxy["three_buckets"]["ms_per_step"]  # wrap_ddp's default
             dist.destroy_process_group()
         except Exception as e:  # a proxy must never cost the headline line
             ddp_proxy = {"error": f"{type(e).__name__}: {e}"}

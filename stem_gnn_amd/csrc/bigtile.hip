@@ -88,7 +88,34 @@ __device__ __forceinline__ void bt_dma16(const uint16_t* src, unsigned char* lds
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int EPI>
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+// two transposing reads (ds_read_b64_tr_b16: a 16-lane group reads a block of 4 rows x 16 columns and every lane gets one
+// column of it) = the eight contraction steps of one lane's MFMA fragment, for an operand whose contraction index is its
+// SLOW dimension; `p4` is the second block, four rows (4 x 256 B) further on
+// (inline asm: behind the builtin form hipcc puts s_waitcnt vmcnt(0) -- it cannot tell these reads from the LDS-DMA
+// writes in flight and drains the staging pipeline in front of every phase, which cost 60 % of the kernel.  The reads
+// are issued before the phase's barrier and waited for by the explicit s_waitcnt lgkmcnt(0) + sched_barrier behind it;
+// their results are first touched by the MFMAs after that wait.)
+typedef int v2i __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bf16x8 bt_tr_frag(uint32_t lds_addr) {
+  union { v2i v[2]; bf16x8 f; } u;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(u.v[0]) : "v"(lds_addr));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(u.v[1]) : "v"(lds_addr));
+  return u.f;
+}
+__device__ __forceinline__ uint32_t bt_lds_addr(const unsigned char* p) {
+  return static_cast<uint32_t>(reinterpret_cast<uintptr_t>((const __attribute__((address_space(3))) unsigned char*)p));
+}
+
+// TN = false: C[i][j] = sum_k A[i][k] B[j][k], both operands k-contiguous (planes [rows][k]).
+// TN = true:  C[i][j] = sum_m A[m][i] B[m][j], the contraction over the operands' ROWS (planes [m][features], as the
+//   straight cut pass writes them -- the weight gradient dW = dY^T X reads the same planes as the backward-data product,
+//   no transposed copy exists): a K tile is 64 rows m; a half tile's LDS image is [64 m][128 features] (256-byte rows,
+//   one DMA piece = 4 rows), its 32-byte units XOR-swizzled by (m & 3) | ((m >> 3) & 1) << 2 so that the transposing
+//   reads of a 32-lane half (8 rows x 32 B) cover all 64 banks; BtOp::rows counts FEATURES, ld is the row stride, the
+//   planes hold whole K tiles of rows (zero rows behind the operand's last).
+template <int EPI, bool TN>
 __global__ void __launch_bounds__(kBtThreads) k_bt_gemm(const BtArgs g) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];  // the ONLY LDS object of this kernel
   const int tid = threadIdx.x, lane = tid & 63;
@@ -124,7 +151,7 @@ __global__ void __launch_bounds__(kBtThreads) k_bt_gemm(const BtArgs g) {
   const uint16_t* const abase = g.a.p + static_cast<int64_t>(bz) * g.a.bs;
   const uint16_t* const bbase = g.b.p + static_cast<int64_t>(bz) * g.b.bs;
   uint32_t offA[2][2], offB[2][2];
-  {
+  if (!TN) {
     const int r0 = wid * 8 + (lane >> 3);
     const int chunk = (lane & 7) ^ ((r0 >> 1) & 7);
 #pragma unroll
@@ -137,21 +164,45 @@ __global__ void __launch_bounds__(kBtThreads) k_bt_gemm(const BtArgs g) {
         offA[h][j] = static_cast<uint32_t>(ra * g.a.ld + chunk * 8);
         offB[h][j] = static_cast<uint32_t>(rb * g.b.ld + chunk * 8);
       }
+  } else {
+    // piece = 4 rows m x 256 B; lane -> row (lane >> 4) of the piece, LDS chunk (lane & 15), source chunk ^ swizzle(m);
+    // source chunk c of half h is features (c >> 3) * 128 + h * 64 + (c & 7) * 8 of a, (c >> 2) * 64 + h * 32 + (c & 3) * 8 of b
+    const int sw = (((lane >> 4) & 3) | (((wid >> 1) & 1) << 2)) << 1;
+    const int c = (lane & 15) ^ sw;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int64_t m = (wid + 8 * j) * 4 + (lane >> 4);
+        const int64_t fa = min(static_cast<int64_t>(tm) * kTile + (c >> 3) * 128 + h * 64 + (c & 7) * 8, g.a.rows - 8);
+        const int64_t fb = min(static_cast<int64_t>(tn) * kTile + (c >> 2) * 64 + h * 32 + (c & 3) * 8, g.b.rows - 8);
+        offA[h][j] = static_cast<uint32_t>(m * g.a.ld + fa);
+        offB[h][j] = static_cast<uint32_t>(m * g.b.ld + fb);
+      }
   }
   unsigned char* const dma0 = smem + wid * 1024;  // this wave's first piece of half tile 0 of buffer 0
 
   // ---- the contraction as a list of K tiles: cursor over the segments
   int T = 0;
-  for (int s = 0; s < g.nseg; ++s) T += (zrange ? g.seg[s].ktz : g.seg[s].kt) / g.splits;
+  // a split walks K tiles [split * c, (split + 1) * c) of every segment, c = ceil(tiles / splits) (the last split is short)
+  auto split_range = [&](int kt, int* k_begin) {
+    const int c = (kt + g.splits - 1) / g.splits;
+    *k_begin = split * c;
+    const int left = kt - split * c;
+    return left < 0 ? 0 : (left < c ? left : c);
+  };
+  for (int s = 0; s < g.nseg; ++s) { int kb_; T += split_range(zrange ? g.seg[s].ktz : g.seg[s].kt, &kb_); }
   int si = 0, kk = 0;
   int cur_kt = 0;
   int64_t cur_a = 0, cur_b = 0;  // element offsets of the cursor segment's K tile 0 (this split)
+  const int64_t ka = TN ? kBK * g.a.ld : kBK, kb = TN ? kBK * g.b.ld : kBK;  // elements from one K tile to the next
   auto seg_load = [&]() {
     const BtSeg sg = g.seg[si < g.nseg ? si : g.nseg - 1];
-    cur_kt = (zrange ? sg.ktz : sg.kt) / g.splits;
-    const int64_t k0 = static_cast<int64_t>(zrange ? sg.k0z : sg.k0) + static_cast<int64_t>(split) * cur_kt;
-    cur_a = sg.pa * g.a.ps + k0 * kBK;
-    cur_b = sg.pb * g.b.ps + k0 * kBK;
+    int kbeg = 0;
+    cur_kt = split_range(zrange ? sg.ktz : sg.kt, &kbeg);
+    const int64_t k0 = static_cast<int64_t>(zrange ? sg.k0z : sg.k0) + kbeg;
+    cur_a = sg.pa * g.a.ps + k0 * ka;
+    cur_b = sg.pb * g.b.ps + k0 * kb;
   };
   auto cursor_next = [&]() {  // to the next K tile with cur_kt > 0 (segments may be empty in the z range)
     ++kk;
@@ -168,7 +219,7 @@ __global__ void __launch_bounds__(kBtThreads) k_bt_gemm(const BtArgs g) {
 
   if (T > 0) {
     // ---- prologue: tile 0 whole (A0 B0 B1 A1) and A0, B0 of tile 1
-    int64_t oa = cur_a + static_cast<int64_t>(kk) * kBK, ob = cur_b + static_cast<int64_t>(kk) * kBK;
+    int64_t oa = cur_a + kk * ka, ob = cur_b + kk * kb;
 #define BT_STAGE_A(BUF, H, OA)                                                                    \
   do {                                                                                            \
     bt_dma16(abase + (OA) + offA[H][0], dma0 + (BUF) * kBufBytes + (H) * kHalfBytes);            \
@@ -186,7 +237,7 @@ __global__ void __launch_bounds__(kBtThreads) k_bt_gemm(const BtArgs g) {
     cursor_next();
     // offsets of tile t + 1 (o*1) and t + 2 (o*2) while tile t is multiplied; past the end they repeat the last tile
     // and are never used (the staging that would read them is skipped)
-    int64_t oa1 = cur_a + static_cast<int64_t>(kk) * kBK, ob1 = cur_b + static_cast<int64_t>(kk) * kBK;
+    int64_t oa1 = cur_a + kk * ka, ob1 = cur_b + kk * kb;
     if (T > 1) {
       BT_STAGE_A(1, 0, oa1);
       BT_STAGE_B(1, 0, ob1);
@@ -195,25 +246,42 @@ __global__ void __launch_bounds__(kBtThreads) k_bt_gemm(const BtArgs g) {
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    int64_t oa2 = cur_a + static_cast<int64_t>(kk) * kBK, ob2 = cur_b + static_cast<int64_t>(kk) * kBK;
+    int64_t oa2 = cur_a + kk * ka, ob2 = cur_b + kk * kb;
     __builtin_amdgcn_s_barrier();            // every wave's share of tile 0 is in LDS
     if (wr == 1) __builtin_amdgcn_s_barrier();  // waves 4-7 run one barrier behind: they load while waves 0-3 multiply
 
-    // ---- per-lane fragment addresses: row fr of a 16-row group, 16-byte chunk (s * 4 + fq) ^ (fr >> 1)
+    // ---- per-lane fragment addresses.  NT: row fr of a 16-row group, 16-byte chunk (s * 4 + fq) ^ (fr >> 1).
+    // TN: rows fq * 8 + (fr >> 2) (+ 4: second read; + 32: k step 1) of the [64 m][128 f] image, 8 bytes at feature
+    // 16 u + 4 (fr & 3) of 32-byte unit u ^ x, x = (fr >> 2) | (fq & 1) << 2
     const int roff = fr * 128 + ((fq ^ (fr >> 1)) << 4);
-    const unsigned char* const ra0 = smem + wr * 64 * 128 + roff;                       // A half h: + h * kHalfBytes
-    const unsigned char* const rb0 = smem + 2 * kHalfBytes + wc * 32 * 128 + roff;      // B half h: + h * kHalfBytes
+    const int tx = (fr >> 2) | ((fq & 1) << 2);
+    const int trow = (fq * 8 + (fr >> 2)) * 256 + (fr & 3) * 8;
+    const unsigned char* const ra0 = TN ? smem + trow + 32 * ((wr * 4) ^ (tx & 4)) : smem + wr * 64 * 128 + roff;
+    const unsigned char* const rb0 = TN ? smem + 2 * kHalfBytes + trow + 32 * ((wc * 2) ^ (tx & 6))
+                                        : smem + 2 * kHalfBytes + wc * 32 * 128 + roff;
     bf16x8 fa[4][2], fb[2][2][2];
 
 #define BT_READ_A(BUF, MH)                                                                                        \
   _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                              \
-    fa[i_][0] = *reinterpret_cast<const bf16x8*>(ra0 + (BUF) * kBufBytes + (MH) * kHalfBytes + i_ * 2048);       \
-    fa[i_][1] = *reinterpret_cast<const bf16x8*>((ra0 + (BUF) * kBufBytes + (MH) * kHalfBytes + i_ * 2048) + (64 - 2 * ((roff) & 64))); \
+    if (TN) {                                                                                                     \
+      const unsigned char* p_ = ra0 + (BUF) * kBufBytes + (MH) * kHalfBytes + 32 * (i_ ^ (tx & 3));              \
+      fa[i_][0] = bt_tr_frag(bt_lds_addr(p_));                                                                    \
+      fa[i_][1] = bt_tr_frag(bt_lds_addr(p_ + 32 * 256));                                                         \
+    } else {                                                                                                      \
+      fa[i_][0] = *reinterpret_cast<const bf16x8*>(ra0 + (BUF) * kBufBytes + (MH) * kHalfBytes + i_ * 2048);     \
+      fa[i_][1] = *reinterpret_cast<const bf16x8*>((ra0 + (BUF) * kBufBytes + (MH) * kHalfBytes + i_ * 2048) + (64 - 2 * ((roff) & 64))); \
+    }                                                                                                             \
   }
 #define BT_READ_B(BUF, NH)                                                                                        \
   _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                                              \
-    fb[NH][j_][0] = *reinterpret_cast<const bf16x8*>(rb0 + (BUF) * kBufBytes + (NH) * kHalfBytes + j_ * 2048);   \
-    fb[NH][j_][1] = *reinterpret_cast<const bf16x8*>((rb0 + (BUF) * kBufBytes + (NH) * kHalfBytes + j_ * 2048) + (64 - 2 * ((roff) & 64))); \
+    if (TN) {                                                                                                     \
+      const unsigned char* p_ = rb0 + (BUF) * kBufBytes + (NH) * kHalfBytes + 32 * (j_ ^ (tx & 1));              \
+      fb[NH][j_][0] = bt_tr_frag(bt_lds_addr(p_));                                                                \
+      fb[NH][j_][1] = bt_tr_frag(bt_lds_addr(p_ + 32 * 256));                                                     \
+    } else {                                                                                                      \
+      fb[NH][j_][0] = *reinterpret_cast<const bf16x8*>(rb0 + (BUF) * kBufBytes + (NH) * kHalfBytes + j_ * 2048); \
+      fb[NH][j_][1] = *reinterpret_cast<const bf16x8*>((rb0 + (BUF) * kBufBytes + (NH) * kHalfBytes + j_ * 2048) + (64 - 2 * ((roff) & 64))); \
+    }                                                                                                             \
   }
 #define BT_MFMA(MH, NH)                                                                                           \
   do {                                                                                                            \
@@ -261,8 +329,8 @@ __global__ void __launch_bounds__(kBtThreads) k_bt_gemm(const BtArgs g) {
     ++t;                                                                  \
     oa1 = oa2; ob1 = ob2;                                                 \
     if (ok2) cursor_next();                                               \
-    oa2 = cur_a + static_cast<int64_t>(kk) * kBK;                         \
-    ob2 = cur_b + static_cast<int64_t>(kk) * kBK;                         \
+    oa2 = cur_a + kk * ka;                         \
+    ob2 = cur_b + kk * kb;                         \
   } while (0)
 
     int t = 0;
@@ -453,6 +521,69 @@ k_bt_cut_rows_ssq(const float* __restrict__ x, int64_t N, int H, int Dc, uint16_
   }
 }
 
+// Straight planes of x [M, C] (element kind `kind`) written for M_out >= M rows -- the rows behind the operand's last are
+// ZERO: the contraction of a weight gradient (k_bt_gemm<.., TN = true>) walks the rows in whole K tiles -- and, in the
+// same pass, partial column sums (the bias gradient): colsum[blockIdx.x][C] over the block's 256 rows (finished by
+// k_bt_colsum_finish in fixed order).  A block owns 256 rows x 256 columns: wave w takes rows w, w + 4, ... (a wave reads
+// one contiguous KB of a row per step, four rows in flight), a lane 4 columns; the four waves' sums meet in LDS.
+template <int NP>
+__global__ void __launch_bounds__(kCutThreads)
+k_bt_cut_rows_colsum(const void* __restrict__ x_, int kind, int64_t M, int64_t M_out, int C, uint16_t* __restrict__ out,
+                     int64_t ps, float* __restrict__ colsum) {
+  __shared__ float4 red[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = (blockIdx.y * 64 + lane) * 4;
+  const bool cok = c < C;
+  const int64_t r0 = static_cast<int64_t>(blockIdx.x) * 256;
+  float4 cs = zero4();
+  if (cok) {
+    for (int it = 0; it < 64; it += 4) {
+      float4 v[4];
+      uint2 raw[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t r = r0 + w + 4 * (it + u);
+        v[u] = zero4();
+        raw[u] = make_uint2(0u, 0u);
+        if (r < M) {
+          if (kind == kBF16) raw[u] = *reinterpret_cast<const uint2*>(static_cast<const uint16_t*>(x_) + r * C + c);
+          else v[u] = ld4(static_cast<const float*>(x_) + r * C + c);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t r = r0 + w + 4 * (it + u);
+        if (r >= M_out) continue;
+        uint16_t* o = out + r * C + c;
+        if (kind == kBF16) {  // stored as bf16: the h plane as it is (its m and l planes are never read)
+          *reinterpret_cast<uint2*>(o) = raw[u];
+          cs.x += __uint_as_float(raw[u].x << 16); cs.y += __uint_as_float(raw[u].x & 0xffff0000u);
+          cs.z += __uint_as_float(raw[u].y << 16); cs.w += __uint_as_float(raw[u].y & 0xffff0000u);
+          continue;
+        }
+        cs.x += v[u].x; cs.y += v[u].y; cs.z += v[u].z; cs.w += v[u].w;
+        if (NP == 1) {
+          *reinterpret_cast<uint2*>(o) = pack_rne(v[u]);
+        } else {
+          uint2 h, mm, l;
+          split3(v[u], h, mm, l);
+          *reinterpret_cast<uint2*>(o) = h;
+          *reinterpret_cast<uint2*>(o + ps) = mm;
+          *reinterpret_cast<uint2*>(o + 2 * ps) = l;
+        }
+      }
+    }
+  }
+  red[w][lane] = cs;
+  __syncthreads();
+  if (w == 0 && cok) {
+    const float4 a0 = red[0][lane], a1 = red[1][lane], a2 = red[2][lane], a3 = red[3][lane];
+    st4(colsum + static_cast<int64_t>(blockIdx.x) * C + c,
+        make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y), (a0.z + a1.z) + (a2.z + a3.z),
+                    (a0.w + a1.w) + (a2.w + a3.w)));
+  }
+}
+
 // Transposed planes: x [R, C] (element kind `kind`, row stride C) -> out[plane][c][r], row stride ld >= R rounded up;
 // columns r in [R, ld) are written as zeros (the contraction runs over r in whole K tiles).  A block owns 64 columns c
 // and 256 rows r (four 64 x 64 sub-tiles transposed through LDS).  colsum (optional): partial column sums of x over the
@@ -638,25 +769,50 @@ k_bt_commit_finish(const double* __restrict__ partial, int64_t n, double scale, 
 // allocates, frees or synchronises.  A product that qualifies but finds no arena (or one too small) runs on the tile
 // kernels and is counted (stemgnn_linear_bigtile_fallbacks) -- a capacity miss, never an error swallowed.
 // ---------------------------------------------------------------------------------------------------------------------
-struct Arena { unsigned char* p = nullptr; size_t bytes = 0; };
+inline size_t a256(size_t b) { return (b + 255) / 256 * 256; }
+
+// a set of straight planes of one operand, cut earlier in the current scope
+struct PlaneSet {
+  const void* src = nullptr;
+  int64_t rows = 0, cols = 0, rows_padded = 0;
+  int kind = 0, np = 0;
+  uint16_t* p = nullptr;     // [np][rows_padded][cols]
+  float* colsum = nullptr;   // [row_blocks][cols] partial column sums (the bias gradient), row_blocks = ceil(rows_padded / 256)
+};
+struct Arena {
+  unsigned char* p = nullptr;
+  size_t bytes = 0;
+  size_t used = 0;   // bump pointer: reset by every product outside a scope, by the scope's end inside one
+  int depth = 0;     // open scopes
+  std::vector<PlaneSet> cache;
+};
 std::mutex g_arena_mu;
 std::map<std::pair<int, hipStream_t>, Arena> g_arena;
 
-inline size_t a256(size_t b) { return (b + 255) / 256 * 256; }
-
-bool arena_of(hipStream_t st, size_t need, unsigned char** base) {
+Arena* arena_find(hipStream_t st) {
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return false; }
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
   std::lock_guard<std::mutex> lock(g_arena_mu);
   auto it = g_arena.find({dev, st});
-  if (it == g_arena.end() || it->second.bytes < need + 256 || !it->second.p) return false;
-  *base = reinterpret_cast<unsigned char*>(a256(reinterpret_cast<uintptr_t>(it->second.p)));
-  return true;
+  return (it == g_arena.end() || !it->second.p) ? nullptr : &it->second;
 }
 
-struct Carve {
-  unsigned char* p;
-  template <typename T> T* take(size_t bytes) { T* r = reinterpret_cast<T*>(p); p += a256(bytes); return r; }
+// One product's (or, inside a scope, one phase's) claim on the stream's arena.  Kernels of a stream run one after the
+// other, so a product may overwrite the previous product's planes -- unless a scope is open: then the planes cut so far
+// stay (they are shared between the products of the phase) and new claims go behind them.
+struct Lease {
+  Arena* a;
+  explicit Lease(hipStream_t st) : a(arena_find(st)) {
+    if (a && a->depth == 0) { a->used = 0; a->cache.clear(); }
+  }
+  bool ok() const { return a != nullptr; }
+  template <typename T> T* take(size_t bytes) {
+    if (!a) return nullptr;
+    const size_t start = a256(reinterpret_cast<uintptr_t>(a->p) + a->used) - reinterpret_cast<uintptr_t>(a->p);
+    if (start + a256(bytes) > a->bytes) return nullptr;
+    a->used = start + a256(bytes);
+    return reinterpret_cast<T*>(a->p + start);
+  }
 };
 
 inline unsigned cut_grid(int64_t elems4) {
@@ -676,7 +832,7 @@ struct BtProfile {
 };
 BtProfile g_bt_profile;
 
-int bt_launch(BtArgs& a, int epi, hipStream_t st) {
+int bt_launch(BtArgs& a, int epi, hipStream_t st, bool tn = false) {
   a.tiles_m = static_cast<int>((a.a.rows + kTile - 1) / kTile);
   a.tiles_n = static_cast<int>((a.b.rows + kTile - 1) / kTile);
   const int64_t work = static_cast<int64_t>(a.tiles_m) * a.tiles_n * a.splits * a.batch;
@@ -690,13 +846,15 @@ int bt_launch(BtArgs& a, int epi, hipStream_t st) {
   }();
   const int64_t blocks = std::min<int64_t>(work, cus);  // one persistent block per CU (128 KiB of LDS each)
   a.work = static_cast<int>(work);
-  if (work <= 0 || work >= (1ll << 31) || a.a.rows * a.a.ld >= (1ll << 31) || a.b.rows * a.b.ld >= (1ll << 31))
+  if (work <= 0 || work >= (1ll << 31) || (!tn && (a.a.rows * a.a.ld >= (1ll << 31) || a.b.rows * a.b.ld >= (1ll << 31))))
     return STEMGNN_ERR_TOO_LARGE;
-  static const hipError_t attr0 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_bt_gemm<kEpiStore>),
+  static const hipError_t attr0 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_bt_gemm<kEpiStore, false>),
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, kBtLds);
-  static const hipError_t attr1 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_bt_gemm<kEpiArgmax>),
+  static const hipError_t attr1 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_bt_gemm<kEpiArgmax, false>),
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, kBtLds);
-  if (attr0 != hipSuccess || attr1 != hipSuccess) return STEMGNN_ERR_HIP;
+  static const hipError_t attr2 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_bt_gemm<kEpiStore, true>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, kBtLds);
+  if (attr0 != hipSuccess || attr1 != hipSuccess || attr2 != hipSuccess) return STEMGNN_ERR_HIP;
   static const int dbg = getenv("STEMGNN_BT_DBG") ? atoi(getenv("STEMGNN_BT_DBG")) : 0;
   a.dbg = dbg;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -712,8 +870,9 @@ int bt_launch(BtArgs& a, int epi, hipStream_t st) {
     }
   }
   const dim3 grid(static_cast<unsigned>(blocks)), block(kBtThreads);
-  if (epi == kEpiStore) hipExtLaunchKernelGGL((k_bt_gemm<kEpiStore>), grid, block, kBtLds, st, ev0, ev1, 0, a);
-  else hipExtLaunchKernelGGL((k_bt_gemm<kEpiArgmax>), grid, block, kBtLds, st, ev0, ev1, 0, a);
+  if (tn) hipExtLaunchKernelGGL((k_bt_gemm<kEpiStore, true>), grid, block, kBtLds, st, ev0, ev1, 0, a);
+  else if (epi == kEpiStore) hipExtLaunchKernelGGL((k_bt_gemm<kEpiStore, false>), grid, block, kBtLds, st, ev0, ev1, 0, a);
+  else hipExtLaunchKernelGGL((k_bt_gemm<kEpiArgmax, false>), grid, block, kBtLds, st, ev0, ev1, 0, a);
   STEMGNN_LAUNCH_CHECK();
   return STEMGNN_OK;
 }
@@ -760,19 +919,17 @@ static inline int bt_dw_splits(int64_t N, int64_t K) {
   if (s > 64) s = 64;
   return static_cast<int>(s);
 }
-static inline int64_t bt_dw_rows_padded(int64_t M, int splits) {
-  const int64_t q = static_cast<int64_t>(kBK) * splits;
-  return (M + q - 1) / q * q;
+static inline int64_t bt_rows_padded(int64_t M) { return (M + kBK - 1) / kBK * kBK; }  // whole K tiles of rows
+// arena bytes of the three products and of the code assignment (what the bt_* claim; the scratch queries take their maximum)
+static inline size_t bt_need_planes(int np, int64_t M, int64_t C) {
+  const int64_t Mp = bt_rows_padded(M);
+  return a256(static_cast<size_t>(np) * Mp * C * 2) + a256(static_cast<size_t>((Mp + 255) / 256) * C * 4);
 }
-// arena bytes of the three products and of the code assignment (what the bt_* carve; the scratch queries take their maximum)
 static inline size_t bt_need_fwd(int np, int64_t M, int64_t N, int64_t K) {
-  return a256(static_cast<size_t>(np) * M * K * 2) + a256(static_cast<size_t>(np) * N * K * 2);
+  return bt_need_planes(np, M, K) + a256(static_cast<size_t>(np) * N * K * 2);
 }
-static inline size_t bt_need_bwd_weight(int np, int64_t M, int64_t N, int64_t K, bool want_db) {
-  const int S = bt_dw_splits(N, K);
-  const int64_t Mp = bt_dw_rows_padded(M, S);
-  return a256(static_cast<size_t>(np) * N * Mp * 2) + a256(static_cast<size_t>(np) * K * Mp * 2) +
-         a256(static_cast<size_t>(S) * N * K * 4) + (want_db ? a256(static_cast<size_t>((Mp + 255) / 256) * N * 4) : 0);
+static inline size_t bt_need_bwd_weight(int np, int64_t M, int64_t N, int64_t K) {
+  return bt_need_planes(np, M, N) + bt_need_planes(np, M, K) + a256(static_cast<size_t>(bt_dw_splits(N, K)) * N * K * 4);
 }
 static inline size_t bt_need_vq(int64_t N, int64_t H, int64_t Dc, int64_t K) {
   const int64_t tiles = (K + kTile - 1) / kTile;
@@ -781,6 +938,33 @@ static inline size_t bt_need_vq(int64_t N, int64_t H, int64_t Dc, int64_t K) {
   return a256(static_cast<size_t>(3) * H * K * Dc * 2) + a256(static_cast<size_t>(3) * N * H * Dc * 2) +
          2 * a256(static_cast<size_t>(N) * H * tiles * 4) + a256(static_cast<size_t>(N) * H * 4) +
          a256(static_cast<size_t>(fin_blocks + gat_blocks) * 8);
+}
+
+// The straight planes of an operand x [M, C] (rows padded with zeros to whole K tiles) and the partial column sums the
+// cut pass takes along: from the scope's cache when this operand has been cut in the scope, else cut now into the lease.
+static int bt_planes(Lease& lease, const void* x, int kind, int64_t M, int64_t C, int np, hipStream_t st, PlaneSet* out) {
+  if (!lease.ok()) return STEMGNN_ERR_WORKSPACE;
+  if (lease.a->depth > 0)
+    for (const PlaneSet& e : lease.a->cache)
+      if (e.src == x && e.rows == M && e.cols == C && e.kind == kind && e.np == np) { *out = e; return STEMGNN_OK; }
+  PlaneSet ps;
+  ps.src = x; ps.rows = M; ps.cols = C; ps.kind = kind; ps.np = np;
+  ps.rows_padded = bt_rows_padded(M);
+  const int row_blocks = static_cast<int>((ps.rows_padded + 255) / 256);
+  ps.p = lease.take<uint16_t>(static_cast<size_t>(np) * ps.rows_padded * C * 2);
+  ps.colsum = lease.take<float>(static_cast<size_t>(row_blocks) * C * 4);
+  if (!ps.p || !ps.colsum) return STEMGNN_ERR_WORKSPACE;
+  dim3 grid(static_cast<unsigned>(row_blocks), static_cast<unsigned>((C / 4 + 63) / 64));
+  if (np == 3)
+    k_bt_cut_rows_colsum<3><<<grid, kCutThreads, 0, st>>>(x, kind, M, ps.rows_padded, static_cast<int>(C), ps.p,
+                                                         ps.rows_padded * C, ps.colsum);
+  else
+    k_bt_cut_rows_colsum<1><<<grid, kCutThreads, 0, st>>>(x, kind, M, ps.rows_padded, static_cast<int>(C), ps.p,
+                                                         ps.rows_padded * C, ps.colsum);
+  STEMGNN_LAUNCH_CHECK();
+  if (lease.a->depth > 0) lease.a->cache.push_back(ps);
+  *out = ps;
+  return STEMGNN_OK;
 }
 
 // y [M, N] = [x1 | x2] [w1 | w2]^T + bias.  pieces: 3 = exact mode, 1 = bf16 GEMM mode.  Returns STEMGNN_ERR_WORKSPACE
@@ -792,11 +976,10 @@ int bt_linear_fwd(int pieces, const float* x1, const float* w1, int64_t K1, cons
   const int64_t K = K1 + K2;
   if (K1 % kBK != 0 || K2 % kBK != 0) return STEMGNN_ERR_WORKSPACE;
   const size_t xb = static_cast<size_t>(np) * M * K * 2, wb = static_cast<size_t>(np) * N * K * 2;
-  unsigned char* base = nullptr;
-  if (!arena_of(st, bt_need_fwd(np, M, N, K), &base)) return STEMGNN_ERR_WORKSPACE;
-  Carve c{base};
-  uint16_t* xpl = c.take<uint16_t>(xb);
-  uint16_t* wpl = c.take<uint16_t>(wb);
+  Lease lease(st);
+  uint16_t* xpl = lease.take<uint16_t>(xb);
+  uint16_t* wpl = lease.take<uint16_t>(wb);
+  if (!xpl || !wpl) return STEMGNN_ERR_WORKSPACE;
   if (np == 3) {
     k_bt_cut_rows<3><<<cut_grid(M * (K / 4)), kCutThreads, 0, st>>>(x1, K1, static_cast<int>(K1), x1_rows, x2, x2_kind,
                                                                    static_cast<int>(K2), M, xpl, M * K, K);
@@ -836,28 +1019,19 @@ int bt_linear_bwd_data(int pieces, const float* dy, const float* w, int64_t M, i
                        hipStream_t st) {
   const int np = np_of(pieces);
   if (N % kBK != 0) return STEMGNN_ERR_WORKSPACE;
-  const size_t gb = static_cast<size_t>(np) * M * N * 2, wb = static_cast<size_t>(np) * K * N * 2;
-  unsigned char* base = nullptr;
-  if (!arena_of(st, bt_need_fwd(np, M, K, N), &base)) return STEMGNN_ERR_WORKSPACE;
-  Carve c{base};
-  uint16_t* gpl = c.take<uint16_t>(gb);
-  uint16_t* wpl = c.take<uint16_t>(wb);  // w^T planes [K][N]
+  Lease lease(st);
+  PlaneSet gp;
+  int rc = bt_planes(lease, dy, kF32, M, N, np, st, &gp);
+  if (rc != STEMGNN_OK) return rc;
+  uint16_t* wpl = lease.take<uint16_t>(static_cast<size_t>(np) * K * N * 2);  // w^T planes [K][N]
+  if (!wpl) return STEMGNN_ERR_WORKSPACE;
   dim3 tg(static_cast<unsigned>((N + 255) / 256), static_cast<unsigned>((K + 63) / 64));
-  if (np == 3) {
-    k_bt_cut_rows<3><<<cut_grid(M * (N / 4)), kCutThreads, 0, st>>>(dy, N, static_cast<int>(N), M, nullptr, kF32, 0, M, gpl,
-                                                                   M * N, N);
-    STEMGNN_LAUNCH_CHECK();
-    k_bt_cut_cols<3><<<tg, kCutThreads, 0, st>>>(w, kF32, N, static_cast<int>(K), wpl, K * N, N, nullptr);
-  } else {
-    k_bt_cut_rows<1><<<cut_grid(M * (N / 4)), kCutThreads, 0, st>>>(dy, N, static_cast<int>(N), M, nullptr, kF32, 0, M, gpl,
-                                                                   M * N, N);
-    STEMGNN_LAUNCH_CHECK();
-    k_bt_cut_cols<1><<<tg, kCutThreads, 0, st>>>(w, kF32, N, static_cast<int>(K), wpl, K * N, N, nullptr);
-  }
+  if (np == 3) k_bt_cut_cols<3><<<tg, kCutThreads, 0, st>>>(w, kF32, N, static_cast<int>(K), wpl, K * N, N, nullptr);
+  else k_bt_cut_cols<1><<<tg, kCutThreads, 0, st>>>(w, kF32, N, static_cast<int>(K), wpl, K * N, N, nullptr);
   STEMGNN_LAUNCH_CHECK();
   BtArgs g{};
   g.a = BtOp{wpl, K * N, N, K, 0};
-  g.b = BtOp{gpl, M * N, N, M, 0};
+  g.b = BtOp{gp.p, gp.rows_padded * N, N, M, 0};
   const int kt = static_cast<int>(N / kBK);
   exact_segments(g, pieces, kt, kt, 0, kt, kt);
   g.splits = 1; g.batch = 1;
@@ -866,38 +1040,27 @@ int bt_linear_bwd_data(int pieces, const float* dy, const float* w, int64_t M, i
   return bt_launch(g, kEpiStore, st);
 }
 
-// dw [N, K] = dy [M, N]^T x [M, K]; db [N] = column sums of dy (NULL: skip)
+// dw [N, K] = dy [M, N]^T x [M, K]; db [N] = column sums of dy (NULL: skip).  The contraction runs over the operands'
+// rows: the TN form of the core on STRAIGHT planes (the same a backward-data product reads), split over the rows into
+// about one block per CU, the split slabs added in fixed order.
 int bt_linear_bwd_weight(int pieces, const float* dy, const void* x, int x_kind, int64_t M, int64_t N, int64_t K, float* dw,
                          float* db, hipStream_t st) {
   const int np = np_of(pieces);
   const int S = bt_dw_splits(N, K);
-  const int64_t Mp = bt_dw_rows_padded(M, S);
-  const int row_blocks = static_cast<int>((Mp + 255) / 256);
-  const size_t gb = static_cast<size_t>(np) * N * Mp * 2, xb = static_cast<size_t>(np) * K * Mp * 2;
-  const size_t sb = static_cast<size_t>(S) * N * K * 4, pb = db ? static_cast<size_t>(row_blocks) * N * 4 : 0;
-  unsigned char* base = nullptr;
-  if (!arena_of(st, bt_need_bwd_weight(np, M, N, K, db != nullptr), &base)) return STEMGNN_ERR_WORKSPACE;
-  Carve c{base};
-  uint16_t* gpl = c.take<uint16_t>(gb);  // dy^T planes [N][Mp]
-  uint16_t* xpl = c.take<uint16_t>(xb);  // x^T planes [K][Mp]
-  float* slabs = c.take<float>(sb);
-  float* part = db ? c.take<float>(pb) : nullptr;
-  dim3 gg(static_cast<unsigned>(row_blocks), static_cast<unsigned>((N + 63) / 64));
-  dim3 gx(static_cast<unsigned>(row_blocks), static_cast<unsigned>((K + 63) / 64));
+  const int64_t Mp = bt_rows_padded(M);
+  if (Mp * std::max(N, K) >= (1ll << 31)) return STEMGNN_ERR_WORKSPACE;  // 32-bit plane offsets: the tile kernels serve
+  Lease lease(st);
+  PlaneSet gp, xp;
+  int rc = bt_planes(lease, dy, kF32, M, N, np, st, &gp);
+  if (rc != STEMGNN_OK) return rc;
+  rc = bt_planes(lease, x, x_kind, M, K, np, st, &xp);
+  if (rc != STEMGNN_OK) return rc;
+  float* slabs = S > 1 ? lease.take<float>(static_cast<size_t>(S) * N * K * 4) : nullptr;
+  if (S > 1 && !slabs) return STEMGNN_ERR_WORKSPACE;
   const bool xbf = x_kind == kBF16;
-  if (np == 3) {
-    k_bt_cut_cols<3><<<gg, kCutThreads, 0, st>>>(dy, kF32, M, static_cast<int>(N), gpl, N * Mp, Mp, part);
-    STEMGNN_LAUNCH_CHECK();
-    k_bt_cut_cols<3><<<gx, kCutThreads, 0, st>>>(x, x_kind, M, static_cast<int>(K), xpl, K * Mp, Mp, nullptr);
-  } else {
-    k_bt_cut_cols<1><<<gg, kCutThreads, 0, st>>>(dy, kF32, M, static_cast<int>(N), gpl, N * Mp, Mp, part);
-    STEMGNN_LAUNCH_CHECK();
-    k_bt_cut_cols<1><<<gx, kCutThreads, 0, st>>>(x, x_kind, M, static_cast<int>(K), xpl, K * Mp, Mp, nullptr);
-  }
-  STEMGNN_LAUNCH_CHECK();
   BtArgs g{};
-  g.a = BtOp{xpl, K * Mp, Mp, K, 0};
-  g.b = BtOp{gpl, N * Mp, Mp, N, 0};
+  g.a = BtOp{xp.p, Mp * K, K, K, 0};   // C rows i = the features of x
+  g.b = BtOp{gp.p, Mp * N, N, N, 0};   // C columns j = the features of dy
   const int kt = static_cast<int>(Mp / kBK);
   g.nseg = 0;
   if (pieces == 1) {
@@ -912,7 +1075,7 @@ int bt_linear_bwd_weight(int pieces, const float* dy, const void* x, int x_kind,
   g.splits = S; g.batch = 1;
   g.b_full_rows = 1ll << 62;
   g.y = S > 1 ? slabs : dw; g.ldy = K; g.y_ss = N * K; g.store_rows = N;
-  const int rc = bt_launch(g, kEpiStore, st);
+  rc = bt_launch(g, kEpiStore, st, true);
   if (rc != STEMGNN_OK) return rc;
   if (S > 1) {
     k_bt_reduce_slabs<<<static_cast<unsigned>((N * K / 4 + kCutThreads - 1) / kCutThreads), kCutThreads, 0, st>>>(
@@ -920,10 +1083,26 @@ int bt_linear_bwd_weight(int pieces, const float* dy, const void* x, int x_kind,
     STEMGNN_LAUNCH_CHECK();
   }
   if (db) {
-    k_bt_colsum_finish<<<static_cast<unsigned>((N + 15) / 16), kCutThreads, 0, st>>>(part, row_blocks, static_cast<int>(N), db);
+    k_bt_colsum_finish<<<static_cast<unsigned>((N + 15) / 16), kCutThreads, 0, st>>>(
+        gp.colsum, static_cast<int>((Mp + 255) / 256), static_cast<int>(N), db);
     STEMGNN_LAUNCH_CHECK();
   }
   return STEMGNN_OK;
+}
+
+// Scopes: between bt_scope_begin and bt_scope_end (a phase entry point: encoder / quantiser / heads backward) the straight
+// planes of an operand are cut ONCE and shared by every product of the phase that reads it (the pre-activation gradient
+// of a layer feeds two backward-data products and two weight gradients).  The caller promises that an operand's contents
+// do not change inside the scope.  Without an arena a scope is a no-op.
+void bt_scope_begin(hipStream_t st) {
+  Arena* a = arena_find(st);
+  if (!a) return;
+  if (a->depth++ == 0) { a->used = 0; a->cache.clear(); }
+}
+void bt_scope_end(hipStream_t st) {
+  Arena* a = arena_find(st);
+  if (!a || a->depth == 0) return;
+  if (--a->depth == 0) { a->used = 0; a->cache.clear(); }
 }
 
 // The quantiser's code assignment at large codebooks (K >= 512 codes of Dc >= 256; BASELINE configs 3 and 5; reference
@@ -944,15 +1123,14 @@ int bt_vq_assign(const float* xp, int64_t N, int64_t H, int64_t Dc, const float*
   const size_t ab = static_cast<size_t>(3) * H * K * Dc * 2, bb = static_cast<size_t>(3) * N * HD * 2;
   const size_t cb = static_cast<size_t>(N) * H * tiles * 4, qb = static_cast<size_t>(N) * H * 4;
   const size_t pb = static_cast<size_t>(fin_blocks + gat_blocks) * 8;
-  unsigned char* base = nullptr;
-  if (!arena_of(st, bt_need_vq(N, H, Dc, K), &base)) return STEMGNN_ERR_WORKSPACE;
-  Carve c{base};
-  uint16_t* epl = c.take<uint16_t>(ab);
-  uint16_t* xpl = c.take<uint16_t>(bb);
-  float* cval = c.take<float>(cb);
-  int32_t* cidx = c.take<int32_t>(cb);
-  float* ssq = c.take<float>(qb);
-  double* partial = c.take<double>(pb);
+  Lease lease(st);
+  uint16_t* epl = lease.take<uint16_t>(ab);
+  uint16_t* xpl = lease.take<uint16_t>(bb);
+  float* cval = lease.take<float>(cb);
+  int32_t* cidx = lease.take<int32_t>(cb);
+  float* ssq = lease.take<float>(qb);
+  double* partial = lease.take<double>(pb);
+  if (!epl || !xpl || !cval || !cidx || !ssq || !partial) return STEMGNN_ERR_WORKSPACE;
   k_bt_cut_rows<3><<<cut_grid(H * K * (Dc / 4)), kCutThreads, 0, st>>>(embed, Dc, static_cast<int>(Dc), H * K, nullptr, kF32,
                                                                       0, H * K, epl, H * K * Dc, Dc);
   STEMGNN_LAUNCH_CHECK();
@@ -997,9 +1175,9 @@ size_t stemgnn_linear_scratch_bytes(int64_t max_rows, int64_t dim_a, int64_t dim
   for (int o = 0; o < 2; ++o) {
     const int64_t N = o ? dim_b : dim_a, K = o ? dim_a : dim_b;
     need = std::max(need, bt_need_fwd(3, max_rows, N, K));
-    need = std::max(need, bt_need_bwd_weight(3, max_rows, N, K, true));
+    need = std::max(need, bt_need_bwd_weight(3, max_rows, N, K));
   }
-  return need + 1024;
+  return need + 4096;
 }
 
 size_t stemgnn_vq_assign_scratch_bytes(int64_t num_rows, int64_t heads, int64_t code_dim, int64_t codebook_size) {
@@ -1014,6 +1192,8 @@ int stemgnn_linear_set_scratch(void* scratch, size_t bytes, void* stream_) {
   Arena& a = g_arena[{dev, static_cast<hipStream_t>(stream_)}];
   a.p = static_cast<unsigned char*>(scratch);
   a.bytes = scratch ? bytes : 0;
+  a.used = 0;
+  a.cache.clear();  // planes cached in an open scope lived in the old block
   return STEMGNN_OK;
 }
 

@@ -195,6 +195,17 @@ int bt_linear_bwd_data(int pieces, const float* dy, const float* w, int64_t M, i
                        hipStream_t st);
 int bt_linear_bwd_weight(int pieces, const float* dy, const void* x, int x_kind, int64_t M, int64_t N, int64_t K, float* dw,
                          float* db, hipStream_t st);
+// a phase entry point brackets its products with a scope: inside it the planes of an operand are cut once and shared
+// (the caller promises the operand does not change); no-ops without an arena
+void bt_scope_begin(hipStream_t st);
+void bt_scope_end(hipStream_t st);
+struct BtScope {
+  hipStream_t st;
+  explicit BtScope(hipStream_t s) : st(s) { bt_scope_begin(st); }
+  ~BtScope() { bt_scope_end(st); }
+  BtScope(const BtScope&) = delete;
+  BtScope& operator=(const BtScope&) = delete;
+};
 // the quantiser's code assignment at large codebooks: the exact similarity product of all heads as one launch of the core,
 // arg-max per 256-code tile from the accumulators (no [N, K] matrix), one finishing pass (same outputs as k_vq_assign;
 // quant == NULL: its lean form)

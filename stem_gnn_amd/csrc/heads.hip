@@ -195,6 +195,7 @@ int stemgnn_heads_bwd(const stemgnn_heads_params* p, int64_t N, const float* q, 
   const int64_t D = p->dim, I = p->in_dim;
   hipStream_t s0 = static_cast<hipStream_t>(stream);
   const HeadsSave s = plan_heads(save, p, N, E, bs, k);
+  BtScope plane_scope(static_cast<hipStream_t>(stream));  // a head's output gradient: one cut for its two backward products
   Carver c(scratch);
   float* g_zl = c.take<float>(static_cast<size_t>(N) * D);
   float* g_hts = c.take<float>(static_cast<size_t>(k) * D);

@@ -239,6 +239,9 @@ int stemgnn_encoder_bwd(const stemgnn_graph_view* g, const void* x, const float*
       scratch_bytes < stemgnn_encoder_bwd_scratch_bytes(N, A, layers, cfg))
     return STEMGNN_ERR_WORKSPACE;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  // large products on the big-tile core share their operands' planes inside this phase: a layer's pre-activation gradient
+  // is cut once for its two backward-data products and its two weight gradients (operands are not rewritten below)
+  BtScope plane_scope(st);
   const int L = cfg->num_layers;
   const EncoderPlan p = plan_encoder(save, N, A, layers, cfg, nullptr);
   int64_t wi = 0, wo = 0;
@@ -378,6 +381,7 @@ int stemgnn_vq_bwd(const stemgnn_vq_params* p, const float* z, int64_t N, const 
   if (save_bytes < stemgnn_vq_save_bytes(p, N) || scratch_bytes < stemgnn_vq_bwd_scratch_bytes(p, N))
     return STEMGNN_ERR_WORKSPACE;
   const VqSave s = plan_vq(save, p, N);
+  BtScope plane_scope(st);  // g_xp is cut once for project_in's backward-data product and its weight gradient
   Carver c(scratch);
   float* g_q = c.take<float>(static_cast<size_t>(N) * HD);
   float* g_xp = c.take<float>(static_cast<size_t>(N) * HD);

@@ -704,7 +704,7 @@ class EncoderFn(torch.autograd.Function):
         scratch = _workspace(lib.stemgnn_encoder_bwd_scratch_bytes(N, A, arr, ctypes.byref(cfg)), x.device)
         g_work = g_z.contiguous()
         T = 0 if etab is None else etab.size(0)
-        linear_scratch(N, 2 * max(int(a.in_dim) for a in arr), max(int(a.out_dim) for a in arr))
+        linear_scratch(N, 2 * max(int(a.in_dim) for a in arr), max(int(a.out_dim) for a in arr), factor=len(arr) + 1)
         check(lib.stemgnn_encoder_bwd(ctypes.byref(gv), _p(x), _p(dense), _p(etab), T, arr, ctypes.byref(cfg),
                                       _p(g_work), _p(g_x), _p(save), save.numel(), _p(scratch), scratch.numel(),
                                       _stream()), "encoder_bwd")
@@ -812,13 +812,15 @@ def linear_set_bigtile(on: int) -> int:
 _BT_ARENA = {}
 
 
-def linear_scratch(rows: int, dim_a: int, dim_b: int, vq: Optional[Tuple[int, int, int]] = None) -> None:
+def linear_scratch(rows: int, dim_a: int, dim_b: int, vq: Optional[Tuple[int, int, int]] = None, factor: int = 1) -> None:
     """Make sure the current (device, stream)'s arena covers every product with at most ``rows`` rows and feature extents
     ``dim_a`` x ``dim_b`` (forward, backward-data, weight gradient) and, with ``vq = (heads, code_dim, codebook_size)``,
-    the quantiser's large-codebook assignment over ``rows`` rows.  Shapes the big-tile core does not take cost nothing."""
+    the quantiser's large-codebook assignment over ``rows`` rows.  ``factor``: a backward phase keeps the planes of every
+    operand it has cut until it ends (they are shared between its products), so it asks for a multiple of the
+    single-product bound.  Shapes the big-tile core does not take cost nothing."""
     need = 0
     if rows >= 8192 and min(dim_a, dim_b) >= 256:
-        need = lib.stemgnn_linear_scratch_bytes(rows, dim_a, dim_b)
+        need = lib.stemgnn_linear_scratch_bytes(rows, dim_a, dim_b) * max(int(factor), 1)
     if vq is not None and rows >= 8192 and vq[2] >= 512 and vq[1] >= 256:
         need = max(need, lib.stemgnn_vq_assign_scratch_bytes(rows, vq[0], vq[1], vq[2]))
     if need == 0:
@@ -1126,7 +1128,7 @@ class VqFn(torch.autograd.Function):
         scratch = _workspace(lib.stemgnn_vq_bwd_scratch_bytes(ctypes.byref(p), N), z.device)
         gq = None if g_quantize is None else g_quantize.contiguous()
         gl = None if g_loss is None else g_loss.reshape(1).contiguous().float()
-        linear_scratch(N, z.size(1), w_in.size(0))
+        linear_scratch(N, z.size(1), w_in.size(0), factor=2)
         check(lib.stemgnn_vq_bwd(ctypes.byref(p), _p(z), N, _p(ind), _p(gq), _p(gl), _p(g_z), _p(save), save.numel(),
                                  _p(scratch), scratch.numel(), _stream()), "vq_bwd")
         g_w_in, g_b_in, g_w_out, g_b_out, g_embed = grads
@@ -1430,7 +1432,7 @@ class HeadsFn(torch.autograd.Function):
         N = q.size(0)
         g_q = torch.empty_like(q)
         scratch = _workspace(lib.stemgnn_heads_bwd_scratch_bytes(ctypes.byref(p), N, bs, k), q.device)
-        linear_scratch(max(N, k), 2 * q.size(1), q.size(1))
+        linear_scratch(max(N, k), 2 * q.size(1), q.size(1), factor=3)
         check(lib.stemgnn_heads_bwd(ctypes.byref(p), N, _p(q), _p(x_feat), _p(z_teacher), bs, k, _p(topo_edges),
                                     _p(ts_edges), _p(g_losses), _p(g_q), _p(save), save.numel(), E, _p(scratch),
                                     scratch.numel(), _stream()), "heads_bwd")
