@@ -239,8 +239,8 @@ __global__ void __launch_bounds__(kBtThreads) k_bt_gemm(const BtArgs g) {
     // and are never used (the staging that would read them is skipped)
     int64_t oa1 = cur_a + kk * ka, ob1 = cur_b + kk * kb;
     if (T > 1) {
+      BT_STAGE_B(1, 0, ob1);  // (B0 before A0: phase 2's wait must already cover B0(1), which phase 3 reads)
       BT_STAGE_A(1, 0, oa1);
-      BT_STAGE_B(1, 0, ob1);
       cursor_next();
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     } else {
@@ -272,18 +272,18 @@ __global__ void __launch_bounds__(kBtThreads) k_bt_gemm(const BtArgs g) {
       fa[i_][1] = *reinterpret_cast<const bf16x8*>((ra0 + (BUF) * kBufBytes + (MH) * kHalfBytes + i_ * 2048) + (64 - 2 * ((roff) & 64))); \
     }                                                                                                             \
   }
-#define BT_READ_B(BUF, NH)                                                                                        \
+#define BT_READ_B(BUF, NH, SET)                                                                                      \
   _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                                              \
     if (TN) {                                                                                                     \
       const unsigned char* p_ = rb0 + (BUF) * kBufBytes + (NH) * kHalfBytes + 32 * (j_ ^ (tx & 1));              \
-      fb[NH][j_][0] = bt_tr_frag(bt_lds_addr(p_));                                                                \
-      fb[NH][j_][1] = bt_tr_frag(bt_lds_addr(p_ + 32 * 256));                                                     \
+      fb[SET][j_][0] = bt_tr_frag(bt_lds_addr(p_));                                                                \
+      fb[SET][j_][1] = bt_tr_frag(bt_lds_addr(p_ + 32 * 256));                                                     \
     } else {                                                                                                      \
-      fb[NH][j_][0] = *reinterpret_cast<const bf16x8*>(rb0 + (BUF) * kBufBytes + (NH) * kHalfBytes + j_ * 2048); \
-      fb[NH][j_][1] = *reinterpret_cast<const bf16x8*>((rb0 + (BUF) * kBufBytes + (NH) * kHalfBytes + j_ * 2048) + (64 - 2 * ((roff) & 64))); \
+      fb[SET][j_][0] = *reinterpret_cast<const bf16x8*>(rb0 + (BUF) * kBufBytes + (NH) * kHalfBytes + j_ * 2048); \
+      fb[SET][j_][1] = *reinterpret_cast<const bf16x8*>((rb0 + (BUF) * kBufBytes + (NH) * kHalfBytes + j_ * 2048) + (64 - 2 * ((roff) & 64))); \
     }                                                                                                             \
   }
-#define BT_MFMA(MH, NH)                                                                                           \
+#define BT_MFMA(MH, NH, SET)                                                                                          \
   do {                                                                                                            \
     __builtin_amdgcn_s_barrier();                                                                                 \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                            \
@@ -293,7 +293,7 @@ __global__ void __launch_bounds__(kBtThreads) k_bt_gemm(const BtArgs g) {
       _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                            \
         _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                          \
           acc[(MH) * 4 + i_][(NH) * 2 + j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                           \
-              fa[i_][s_], fb[NH][j_][s_], acc[(MH) * 4 + i_][(NH) * 2 + j_], 0, 0, 0);                           \
+              fa[i_][s_], fb[SET][j_][s_], acc[(MH) * 4 + i_][(NH) * 2 + j_], 0, 0, 0);                           \
     __builtin_amdgcn_s_setprio(0);                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                            \
     __builtin_amdgcn_s_barrier();                                                                                 \
@@ -303,36 +303,42 @@ __global__ void __launch_bounds__(kBtThreads) k_bt_gemm(const BtArgs g) {
     if (STAGED) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");          \
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 \
   } while (0)
-#define BT_TILE(BUF)                                                      \
-  do {                                                                    \
-    const bool ok1 = t + 1 < T, ok2 = t + 2 < T;                          \
-    /* phase 0: quadrant (0, 0) */                                        \
-    BT_READ_B(BUF, 0);                                                    \
-    BT_READ_A(BUF, 0);                                                    \
-    if (ok1) BT_STAGE_B((BUF) ^ 1, 1, ob1);                               \
-    BT_WAIT(ok1);                                                         \
-    BT_MFMA(0, 0);                                                        \
-    /* phase 1: quadrant (0, 1) */                                        \
-    BT_READ_B(BUF, 1);                                                    \
-    if (ok1) BT_STAGE_A((BUF) ^ 1, 1, oa1);                               \
-    BT_WAIT(ok1);                                                         \
-    BT_MFMA(0, 1);                                                        \
-    /* phase 2: quadrant (1, 1) */                                        \
-    BT_READ_A(BUF, 1);                                                    \
-    if (ok2) BT_STAGE_A(BUF, 0, oa2);                                     \
-    BT_WAIT(ok2);                                                         \
-    BT_MFMA(1, 1);                                                        \
-    /* phase 3: quadrant (1, 0): B0's fragments are still in registers */ \
-    if (ok2) BT_STAGE_B(BUF, 0, ob2);                                     \
-    BT_WAIT(ok2);                                                         \
-    BT_MFMA(1, 0);                                                        \
-    ++t;                                                                  \
-    oa1 = oa2; ob1 = ob2;                                                 \
-    if (ok2) cursor_next();                                               \
-    oa2 = cur_a + kk * ka;                         \
-    ob2 = cur_b + kk * kb;                         \
+// Fragment reads per phase 8 / 4 / 8 / 4: this tile's B0 fragments were read in the previous tile's phase 3, into the
+// register set B1 had just left (the two B sets swap roles every tile); staging order B1(t+1), A1(t+1), B0(t+2), A0(t+2).
+// (Measured against the first form -- 12 / 4 / 8 / 0 reads, B0's fragments kept for phases 0 and 3 -- in one process
+// on one box: within 1 % either way, profiles/round4_bigtile_schedule_ab.txt: the fragment reads are not what the load
+// segments wait for.)
+#define BT_TILE(BUF)                                                                                   \
+  do {                                                                                                 \
+    const bool ok1 = t + 1 < T, ok2 = t + 2 < T;                                                       \
+    /* phase 0: quadrant (0, 0) */                                                                     \
+    BT_READ_A(BUF, 0);                                                                                 \
+    if (ok1) BT_STAGE_B((BUF) ^ 1, 1, ob1);                                                            \
+    BT_WAIT(ok1);                                                                                      \
+    BT_MFMA(0, 0, BUF);                                                                                \
+    /* phase 1: quadrant (0, 1) */                                                                     \
+    BT_READ_B(BUF, 1, (BUF) ^ 1);                                                                      \
+    if (ok1) BT_STAGE_A((BUF) ^ 1, 1, oa1);                                                            \
+    BT_WAIT(ok1);                                                                                      \
+    BT_MFMA(0, 1, (BUF) ^ 1);                                                                          \
+    /* phase 2: quadrant (1, 1) */                                                                     \
+    BT_READ_A(BUF, 1);                                                                                 \
+    if (ok2) BT_STAGE_B(BUF, 0, ob2);                                                                  \
+    BT_WAIT(ok2);                                                                                      \
+    BT_MFMA(1, 1, (BUF) ^ 1);                                                                          \
+    /* phase 3: quadrant (1, 0); the NEXT tile's B0 fragments go into the set B1 has just left */      \
+    if (ok1) BT_READ_B((BUF) ^ 1, 0, (BUF) ^ 1);                                                       \
+    if (ok2) BT_STAGE_A(BUF, 0, oa2);                                                                  \
+    BT_WAIT(ok2);                                                                                      \
+    BT_MFMA(1, 0, BUF);                                                                                \
+    ++t;                                                                                               \
+    oa1 = oa2; ob1 = ob2;                                                                              \
+    if (ok2) cursor_next();                                                                            \
+    oa2 = cur_a + kk * ka;                                                                             \
+    ob2 = cur_b + kk * kb;                                                                             \
   } while (0)
 
+    BT_READ_B(0, 0, 0);  // tile 0's B0 fragments (every wave is past the barrier behind the prologue's wait)
     int t = 0;
     while (t < T) {
       BT_TILE(0);
@@ -369,7 +375,10 @@ __global__ void __launch_bounds__(kBtThreads) k_bt_gemm(const BtArgs g) {
         const int64_t j = j_wave + nj * 16;
         const float4 v = make_float4(acc[mi][nj][0] + bv.x, acc[mi][nj][1] + bv.y, acc[mi][nj][2] + bv.z,
                                      acc[mi][nj][3] + bv.w);
-        if (iok && j < g.store_rows && !(g.dbg & 1)) st4(y + j * g.ldy + i, v);
+        if (iok && j < g.store_rows && !(g.dbg & 1) && !((g.dbg & 4) && (nj & 1))) {
+          if (g.dbg & 16) __builtin_nontemporal_store(floatx4{v.x, v.y, v.z, v.w}, reinterpret_cast<floatx4*>(y + j * g.ldy + i));
+          else st4(y + j * g.ldy + i, v);
+        }
         if (g.stats && j < g.b.rows && !(g.dbg & 2)) {
           s1[mi][0] += v.x; s1[mi][1] += v.y; s1[mi][2] += v.z; s1[mi][3] += v.w;
           s2[mi][0] += v.x * v.x; s2[mi][1] += v.y * v.y; s2[mi][2] += v.z * v.z; s2[mi][3] += v.w * v.w;
@@ -848,13 +857,12 @@ int bt_launch(BtArgs& a, int epi, hipStream_t st, bool tn = false) {
   a.work = static_cast<int>(work);
   if (work <= 0 || work >= (1ll << 31) || (!tn && (a.a.rows * a.a.ld >= (1ll << 31) || a.b.rows * a.b.ld >= (1ll << 31))))
     return STEMGNN_ERR_TOO_LARGE;
-  static const hipError_t attr0 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_bt_gemm<kEpiStore, false>),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, kBtLds);
-  static const hipError_t attr1 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_bt_gemm<kEpiArgmax, false>),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, kBtLds);
-  static const hipError_t attr2 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_bt_gemm<kEpiStore, true>),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, kBtLds);
-  if (attr0 != hipSuccess || attr1 != hipSuccess || attr2 != hipSuccess) return STEMGNN_ERR_HIP;
+#define BT_ATTR(K) hipFuncSetAttribute(reinterpret_cast<const void*>(K), hipFuncAttributeMaxDynamicSharedMemorySize, kBtLds)
+  static const bool attrs_ok = BT_ATTR((k_bt_gemm<kEpiStore, false>)) == hipSuccess &&
+                               BT_ATTR((k_bt_gemm<kEpiArgmax, false>)) == hipSuccess &&
+                               BT_ATTR((k_bt_gemm<kEpiStore, true>)) == hipSuccess;
+#undef BT_ATTR
+  if (!attrs_ok) return STEMGNN_ERR_HIP;
   static const int dbg = getenv("STEMGNN_BT_DBG") ? atoi(getenv("STEMGNN_BT_DBG")) : 0;
   a.dbg = dbg;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
