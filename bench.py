@@ -527,7 +527,9 @@ def main():
                 sk.bind(("127.0.0.1", 0))
                 port = sk.getsockname()[1]
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+            import datetime
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev,
+                                    timeout=datetime.timedelta(seconds=60))
             ddp_proxy = {"backend": "nccl (RCCL), world size 1", "steps": args.steps,
                          "note": "same step, model under DistributedDataParallel (reducer hooks, gradient bucket views, "
                                  "FusedAdamW on them); no peer: what DDP itself costs on this step"}
