@@ -74,6 +74,9 @@ def parse():
     ap.add_argument("--no-dense-profile", action="store_true",
                     help="do not stamp the big-tile core's launches with HIP events in the timed region (A/B of the stamps' cost)")
     ap.add_argument("--no-extra", action="store_true", help="skip the K1 legs at C2 / C3 size and the dense-product leg")
+    ap.add_argument("--grad-sync", default="flat", choices=["flat", "ddp"],
+                    help="--gpus > 1: flat = one fused copy + one all-reduce per step (parallel.FlatGradSync); ddp = "
+                         "DistributedDataParallel's reducer (three buckets overlapped with the backward)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
     return ap.parse_args()
 
@@ -395,17 +398,24 @@ def main():
     for p in model.sem_encoder.parameters():
         p.requires_grad_(False)  # never receives gradients (pt_model.py:93 detach); keeps DDP bucketing exact
     opt, sched = build_optimizer(model, params)
-    fwd = None
+    fwd, sync = None, None
     if world > 1:
-        from stem_gnn_amd.parallel import wrap_ddp
-        fwd = wrap_ddp(model, local_rank)
+        # gradient exchange: one fused copy + ONE RCCL all-reduce (AVG) per step behind the backward
+        # (parallel.FlatGradSync: +0.1 % on the step at world size 1) or DistributedDataParallel's reducer (three
+        # buckets overlapped with the backward, +8 %: configs_extra.dp1_under_ddp measures both on one card)
+        if args.grad_sync == "ddp":
+            from stem_gnn_amd.parallel import wrap_ddp
+            fwd = wrap_ddp(model, local_rank)
+        else:
+            from stem_gnn_amd.parallel import FlatGradSync
+            sync = FlatGradSync(model.parameters())
     set_validation(False)  # batches come from our own sampler: skip the per-build device->host range check
     model.train()
 
     def step(i):
         x, ei, xe, bs = batches[i]
         return pretrain_step(model, opt, sched, params, x, ei, EdgeTypeAttr(g.edge_text_feat, xe), bs,
-                             record_draws=False, forward_fn=fwd)
+                             record_draws=False, forward_fn=fwd, grad_sync=sync)
 
     # Housekeeping BEFORE the warm-up steps, so that the device goes from the last warm-up step straight into the timed
     # ones (a 100 ms host pause between them lets the clocks drop, and a 20-step timed region is then 3 % slower than
@@ -506,7 +516,7 @@ def main():
                 if done == warm + steps:
                     break
                 pretrain_step(model, opt, sched, params, b.feat, b.graph, EdgeTypeAttr(g.edge_text_feat, b.xe), b.batch_size,
-                              record_draws=False, forward_fn=fwd)
+                              record_draws=False, forward_fn=fwd, grad_sync=sync)
                 done += 1
             torch.cuda.synchronize()
             return (time.perf_counter() - t1) / max(done - warm, 1) * 1e3
@@ -555,6 +565,24 @@ def main():
                                     "bucket_bytes": sizes}
                 del fwd1
             ddp_proxy["ms_per_step"] = ddp_proxy["three_buckets"]["ms_per_step"]  # wrap_ddp's default
+            # the explicit exchange bench.py uses for --gpus N (parallel.FlatGradSync: one fused copy + one all-reduce)
+            from stem_gnn_amd.parallel import FlatGradSync
+            sync = FlatGradSync(model.parameters())
+
+            def flat_step(i):
+                x, ei, xe, bs = batches[i % total]
+                return pretrain_step(model, opt, sched, params, x, ei, EdgeTypeAttr(g.edge_text_feat, xe), bs,
+                                     record_draws=False, grad_sync=sync)
+
+            for i in range(10):
+                flat_step(i)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(args.steps):
+                flat_step(args.warmup + i)
+            torch.cuda.synchronize()
+            ddp_proxy["flat_all_reduce"] = {"ms_per_step": (time.perf_counter() - t1) / args.steps * 1e3,
+                                            "collectives_per_step": 1, "bytes": int(sync.flat.numel() * 4)}
             dist.destroy_process_group()
         except Exception as e:  # a proxy must never cost the headline line
             ddp_proxy = {"error": f"{type(e).__name__}: {e}"}
@@ -612,7 +640,7 @@ def main():
                        "layers": params["num_layers"], "vq_heads": params["codebook_head"],
                        "codebook_size": params["codebook_size"], "code_dim": params["code_dim"],
                        "seeds_per_rank": nb[3], "batch_nodes": int(nb[0].size(0)), "batch_edges": int(nb[1].num_edges),
-                       "parallelism": f"dp{world}", "edge_attr": "type-indexed (4E + T*D*4 bytes)",
+                       "parallelism": f"dp{world}", "grad_sync": (args.grad_sync if world > 1 else None), "edge_attr": "type-indexed (4E + T*D*4 bytes)",
                        "preheat_steps": preheat_steps, "preheat_s": round(preheat_s, 3),
                        "loader_ms_per_batch_outside_timed_region": round(sampler_ms, 3),
                        "ms_per_step_with_loader_in_loop": None if e2e_ms is None else round(e2e_ms, 3)},

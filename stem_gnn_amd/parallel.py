@@ -67,6 +67,56 @@ def allreduce_mean_grads_(params: Iterable[Tensor]) -> None:
         off += n
 
 
+class FlatGradSync:
+    """The explicit form of the gradient exchange for ``pretrain_step(..., grad_sync=...)``: after backward the trainable
+    gradients are packed into ONE flat buffer by a fused multi-tensor copy, averaged by ONE all-reduce (RCCL ``AVG``; sum +
+    scale on backends without it), and every ``p.grad`` becomes a VIEW of the flat buffer -- clipping and FusedAdamW read
+    the views, nothing is copied back.  Two launches plus the collective per step, where DistributedDataParallel's
+    reducer spends 23 (one copy into its bucket view per parameter, every step, because the step hands autograd fresh
+    gradient tensors: +0.11 ms on the 1.5 ms C4 step at world size 1, bench.py ``dp1_under_ddp``).  The price: the
+    reduction starts when the backward has ended instead of overlapping its tail; for this model's 2.2 MB (D = 128) that
+    is one short collective.  The EMA teacher's parameters never receive gradients and are not exchanged; parameters
+    that received none in a step (``no_codebook=True``) contribute zeros."""
+
+    def __init__(self, params: Iterable[Tensor]):
+        self.params = [p for p in params if p.requires_grad]
+        self.flat = None
+        self.views = None
+
+    def _buffers(self):
+        if self.flat is None:
+            p0 = self.params[0]
+            total = sum(p.numel() for p in self.params)
+            self.flat = torch.empty(total, dtype=p0.dtype, device=p0.device)
+            self.views, off = [], 0
+            for p in self.params:
+                self.views.append(self.flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+        return self.flat, self.views
+
+    def __call__(self) -> None:
+        if not self.params:
+            return
+        flat, views = self._buffers()
+        src, dst = [], []
+        for p, v in zip(self.params, views):
+            if p.grad is None:
+                v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr():
+                src.append(p.grad)
+                dst.append(v)
+        if src:
+            torch._foreach_copy_(dst, src)
+        if dist.is_initialized():  # (also at world size 1: bench.py's readiness proxy wants the collective's launch cost)
+            if dist.get_backend() == "nccl":
+                dist.all_reduce(flat, op=dist.ReduceOp.AVG)
+            else:
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+                flat.div_(dist.get_world_size())
+        for p, v in zip(self.params, views):
+            p.grad = v
+
+
 def ddp_bucket_cap_mb(model: torch.nn.Module, buckets: int = 3) -> float:
     """Bucket size that cuts the trainable gradient into about ``buckets`` reductions.  The step's backward produces
     its gradients in three stretches -- the decoders / heads, the quantiser, the encoder (reverse registration order,
@@ -97,4 +147,11 @@ def wrap_ddp(model: torch.nn.Module, device_index=None, find_unused_parameters=F
               bucket_cap_mb=cap)
     if device_index is not None:
         kw["device_ids"] = [device_index]
-    return torch.nn.parallel.DistributedDataParallel(model, **kw)
+    ddp = torch.nn.parallel.DistributedDataParallel(model, **kw)
+    # Without a communication hook the reducer divides EVERY gradient by the world size with a launch of its own as it
+    # becomes ready: 23 five-microsecond launches per step on this model (rocprofv3, world size 1: +0.12 ms on a 1.5 ms
+    # step -- 8 % of scaling efficiency before a byte has moved).  The reducer's BUILT-IN all-reduce hook (C++; a Python
+    # hook costs more than it saves: measured +0.2 ms) divides once per BUCKET -- three launches per step -- with the same
+    # arithmetic: pre-divide, then sum.
+    ddp._register_builtin_comm_hook(dist.BuiltinCommHookType.ALLREDUCE)
+    return ddp

@@ -53,6 +53,25 @@ def _worker(rank, world, port, out):
         dist.all_gather(both, g)
         ok = ok and torch.allclose(p.grad, (both[0] + both[1]) / 2)
     res["avg_ok"] = ok
+    # 3b. the step's own exchange (parallel.FlatGradSync): one fused copy, one all-reduce, p.grad become views
+    torch.manual_seed(0)
+    lin2 = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.Linear(3, 2))
+    for p in lin2[1].parameters():
+        pass
+    frozen = torch.nn.Parameter(torch.ones(2), requires_grad=False)
+    sync = parallel.FlatGradSync(list(lin2.parameters()) + [frozen])
+    ok2 = True
+    for it in range(2):  # the second round finds last round's views in p.grad... replaced by fresh gradients
+        for p in lin2.parameters():
+            p.grad = None
+        lin2(torch.full((2, 4), float(rank + 1 + it))).sum().backward()
+        local = [p.grad.clone() for p in lin2.parameters()]
+        sync()
+        for p, g_ in zip(lin2.parameters(), local):
+            both = [torch.empty_like(g_) for _ in range(world)]
+            dist.all_gather(both, g_)
+            ok2 = ok2 and torch.allclose(p.grad, (both[0] + both[1]) / 2) and p.grad.data_ptr() >= sync.flat.data_ptr()
+    res["flat_ok"] = ok2 and len(sync.params) == 4
     # 4. DDP on the oracle pretraining model: averaged grads == grads of the mean of the two losses
     torch.manual_seed(1)
     om = O.build_oracle_model(8, 2, 2, 4, 8, ortho_max=2)
@@ -93,5 +112,5 @@ def test_two_rank_gloo():
         r = out[rank]
         assert r["cover"] and sorted(r["sizes"]) == [500, 501]
         assert r["stats"] == (2.0, 300.0)
-        assert r["avg_ok"] and r["ddp_same_grads"]
+        assert r["avg_ok"] and r["flat_ok"] and r["ddp_same_grads"]
         assert r["ema_allreduce"] == [[3.0] * 3] * 2

@@ -757,7 +757,7 @@ def _ddp_batches(world, steps, D):
     return out
 
 
-def _ddp_step_worker(rank, world, port, out):
+def _ddp_step_worker(rank, world, port, out, mode="ddp"):
     """One rank of the two-step test: wrap_ddp + FusedAdamW (clip factor folded into its gradient read) + the cosine
     schedule + the teacher EMA -- the optimiser reads the reducer's bucket views (gradient_as_bucket_view)."""
     import os
@@ -775,7 +775,13 @@ def _ddp_step_worker(rank, world, port, out):
     D, L, H, K = 64, 2, 4, 64
     _, gm = make_models(D, L, H, K, D, dev)
     params = default_params()
-    fwd = parallel.wrap_ddp(gm, 0)
+    fwd, sync = None, None
+    if mode == "ddp":
+        fwd = parallel.wrap_ddp(gm, 0)
+    else:  # bench.py's default exchange for --gpus N: one fused copy + one all-reduce, p.grad = views of the flat buffer
+        for p in gm.sem_encoder.parameters():
+            p.requires_grad_(False)
+        sync = parallel.FlatGradSync(gm.parameters())
     opt = ops.FusedAdamW(gm.parameters(), lr=1e-3, weight_decay=1e-2)
     sched = get_scheduler(opt, True, 50)
     batches = _ddp_batches(world, 2, D)
@@ -784,23 +790,27 @@ def _ddp_step_worker(rank, world, port, out):
     for s_ in range(2):
         x, ei, table, et = batches[(rank, s_)]
         pretrain_step(gm, opt, sched, params, x.to(dev), ei.to(dev), EdgeTypeAttr(table.to(dev), et.to(dev)), 128,
-                      record_draws=False, forward_fn=fwd)
+                      record_draws=False, forward_fn=fwd, grad_sync=sync)
     torch.cuda.synchronize()
     assert isinstance(opt, ops.FusedAdamW) and all(opt.state[p]["step"] == 2 for p in gm.parameters() if p.requires_grad)
     out[rank] = {n: p.detach().cpu().clone() for n, p in gm.named_parameters()}
     # the reducer's own record: after the first step it re-cut the gradient into the buckets wrap_ddp's cap asks for
     # (its statistics are refreshed every few iterations: one more step, after the parameters have been handed back)
-    x, ei, table, et = batches[(rank, 0)]
-    pretrain_step(gm, opt, sched, params, x.to(dev), ei.to(dev), EdgeTypeAttr(table.to(dev), et.to(dev)), 128,
-                  record_draws=False, forward_fn=fwd)
-    torch.cuda.synchronize()
-    log = fwd._get_ddp_logging_data()
-    out[("buckets", rank)] = [int(v) for v in str(log.get("rebuilt_bucket_sizes", "")).split(",") if v.strip()]
+    if mode == "ddp":
+        x, ei, table, et = batches[(rank, 0)]
+        pretrain_step(gm, opt, sched, params, x.to(dev), ei.to(dev), EdgeTypeAttr(table.to(dev), et.to(dev)), 128,
+                      record_draws=False, forward_fn=fwd)
+        torch.cuda.synchronize()
+        log = fwd._get_ddp_logging_data()
+        out[("buckets", rank)] = [int(v) for v in str(log.get("rebuilt_bucket_sizes", "")).split(",") if v.strip()]
+    else:
+        out[("buckets", rank)] = [int(sync.flat.numel() * 4)]
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_hip_ddp_two_optimizer_steps(dev):
+@pytest.mark.parametrize("mode", ["ddp", "flat"])
+def test_two_rank_hip_ddp_two_optimizer_steps(dev, mode):
     """the round-2 reducer test used a no-op optimiser.  Here two ranks take TWO real steps
     (FusedAdamW reading gradient_as_bucket_view buckets, clip factor folded in, per-batch cosine schedule, teacher
     EMA).  (i) Both ranks end with bit-equal parameters, teacher included.  (ii) They match one process that computes
@@ -821,7 +831,7 @@ def test_two_rank_hip_ddp_two_optimizer_steps(dev):
     ctx = mp.get_context("spawn")
     mgr = ctx.Manager()
     out = mgr.dict()
-    procs = [ctx.Process(target=_ddp_step_worker, args=(r, 2, port, out)) for r in range(2)]
+    procs = [ctx.Process(target=_ddp_step_worker, args=(r, 2, port, out, mode)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
@@ -833,7 +843,8 @@ def test_two_rank_hip_ddp_two_optimizer_steps(dev):
         assert torch.equal(p0[k], p1[k]), f"{k}: the ranks' parameters differ after two steps"
     # round-3 review, item 6: several readiness points per step -- the second step reduced at least three buckets (the
     # heads', the quantiser's and the encoder's stretch of the backward), so reductions overlap the backward behind them
-    assert out[("buckets", 0)] == out[("buckets", 1)] and len(out[("buckets", 0)]) >= 3, out[("buckets", 0)]
+    # ("flat": bench.py's default exchange -- one flat all-reduce of the whole trainable gradient)
+    assert out[("buckets", 0)] == out[("buckets", 1)] and len(out[("buckets", 0)]) >= (3 if mode == "ddp" else 1), out[("buckets", 0)]
 
     # ---- the same two global steps in one process
     D, L, H, K = 64, 2, 4, 64
