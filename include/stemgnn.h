@@ -417,7 +417,9 @@ int stemgnn_edge_dot_bce(const float* z, int64_t num_nodes, int64_t dim, const i
  * its edges in that order.  _dot_: g_z[n] = g_scalar * sum_e coef[e] z[other endpoint of e]  (g_z is overwritten);
  * _concat_: g_z[n] += sum_e g_out[e][:D] (n first endpoint) + g_out[e][D:] (n second).  workspace:
  * stemgnn_edge_det_workspace_bytes(N, E).  stemgnn_set_deterministic(1) (or STEMGNN_DETERMINISTIC=1) makes the heads
- * phase use them (0 = the atomic forms, the default; negative = query); returns the previous setting. */
+ * phase use them always (0, the default = the atomic forms for the usual sampled batch and the sorted forms once the
+ * scatters are large enough for them to be the faster ones, k * D >= 5e7 elements; negative = query); returns the
+ * previous setting. */
 size_t stemgnn_edge_det_workspace_bytes(int64_t num_nodes, int64_t num_edges);
 int stemgnn_edge_dot_bwd_det(const float* coef, const float* g_scalar, const float* z, int64_t num_nodes, int64_t dim,
                              const int64_t* edge_index, int64_t num_edges, float* g_z, void* workspace,

@@ -215,8 +215,12 @@ int stemgnn_heads_bwd(const stemgnn_heads_params* p, int64_t N, const float* q, 
   const size_t det_bytes = stemgnn_edge_det_workspace_bytes(N, 2 * k);
   void* det_ws = c.take<unsigned char>(det_bytes);
   // STEMGNN_DETERMINISTIC=1 / stemgnn_set_deterministic(1): the two scatters over sampled edges add in a fixed order
-  // (edges grouped by node, two sorts each) instead of with fp32 atomics -- bit-reproducible steps, ~0.15 ms slower
-  const bool det = stemgnn_set_deterministic(-1) == 1;
+  // (edges grouped by node, two sorts each) instead of with fp32 atomics -- bit-reproducible steps, ~0.15 ms slower on a
+  // C4 batch (k = 11 k edges, D = 128).  Atomics run at ~1.3 TB/s of added bytes on this part, plain gathers at 5+: once
+  // the scatters move hundreds of MB the sorted form is the FASTER one (C3: k = 231 k, D = 768: 3.9 ms of atomics ->
+  // 1.9 ms, 76.0 -> 74.0 ms per step; at k * D = 8.6e6, the refdefault batch, the atomics still win by 0.2 ms), so it
+  // is taken on its own from k * D >= 5e7 elements.
+  const bool det = stemgnn_set_deterministic(-1) == 1 || static_cast<double>(k) * static_cast<double>(D) >= 5e7;
   bool zeroed = false;  // g_zl already cleared (by the loss-gradient launch)
 
   // the four weight gradients run as one split-product launch and one reduction at the end (DwBatch)
