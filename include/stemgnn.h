@@ -368,6 +368,12 @@ size_t stemgnn_linear_scratch_bytes(int64_t max_rows, int64_t dim_a, int64_t dim
 size_t stemgnn_vq_assign_scratch_bytes(int64_t num_rows, int64_t heads, int64_t code_dim, int64_t codebook_size);
 int stemgnn_linear_set_scratch(void* scratch, size_t bytes, void* stream);
 int stemgnn_linear_set_bigtile(int on);
+/* Exact mode on the big-tile core: the products that contract along their operands' ROWS' columns (forward,
+ * backward-data, the code assignment) read operands cut into TWO fp16 pieces of rows scaled by a power of two (three
+ * matrix passes, fp32-accurate: csrc/bigtile.hip "pair format"; 1 = default) or into the three bf16 pieces (six passes; 0).
+ * The weight gradient, which contracts over the rows themselves, always takes the bf16 pieces.  Other values only query;
+ * returns the previous setting. */
+int stemgnn_linear_set_pair(int on);
 /* Measurement aid (bench.py's matrix-roofline leg), like stemgnn_profile_k1: while enabled, every launch of the big-tile
  * core is stamped with its own begin / end HIP events; collect() waits for them and returns (HOST pointers) the summed
  * kernel time in ms, the matrix work those launches EXECUTED in flop (2 x rows x rows x contraction over all segments:

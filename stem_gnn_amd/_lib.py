@@ -169,6 +169,7 @@ _SIGNATURES = {
     "stemgnn_vq_assign_scratch_bytes": (c_size_t, [I64, I64, I64, I64]),
     "stemgnn_linear_set_scratch": (c_int, [P, c_size_t, P]),
     "stemgnn_linear_set_bigtile": (c_int, [c_int]),
+    "stemgnn_linear_set_pair": (c_int, [c_int]),
     "stemgnn_profile_bigtile": (c_int, [c_int]),
     "stemgnn_profile_bigtile_collect": (c_int, [P, P, P]),
     "stemgnn_linear_bigtile_calls": (I64, []),

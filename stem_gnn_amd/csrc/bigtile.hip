@@ -52,6 +52,7 @@ constexpr int kBtLds = 2 * kBufBytes;       // 128 KiB
 constexpr int kMaxSeg = 12;
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 struct BtOp {
   const uint16_t* p;  // element (plane, row, k) at p + plane * ps + row * ld + k
@@ -80,6 +81,10 @@ struct BtArgs {
   // kEpiArgmax: per (batch, b row, a tile) the largest C[i][j] over the tile's valid a rows and the lowest i reaching it
   float* cand_val;
   int32_t* cand_idx;
+  // pair format (two fp16 pieces of a row scaled by a power of two, k_bt_cut_pair): the factors that undo the scaling,
+  // one per a row / b row (exact powers of two; NULL: none): C[i][j] is multiplied by a_scale[i] * b_scale[j]
+  const float* a_scale;
+  const float* b_scale;
   int dbg;  // measurement only (STEMGNN_BT_DBG): 1 = no output stores, 2 = no statistics
 };
 
@@ -115,7 +120,7 @@ __device__ __forceinline__ uint32_t bt_lds_addr(const unsigned char* p) {
 //   one DMA piece = 4 rows), its 32-byte units XOR-swizzled by (m & 3) | ((m >> 3) & 1) << 2 so that the transposing
 //   reads of a 32-lane half (8 rows x 32 B) cover all 64 banks; BtOp::rows counts FEATURES, ld is the row stride, the
 //   planes hold whole K tiles of rows (zero rows behind the operand's last).
-template <int EPI, bool TN>
+template <int EPI, bool TN, bool F16>
 __global__ void __launch_bounds__(kBtThreads) k_bt_gemm(const BtArgs g) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];  // the ONLY LDS object of this kernel
   const int tid = threadIdx.x, lane = tid & 63;
@@ -292,8 +297,12 @@ __global__ void __launch_bounds__(kBtThreads) k_bt_gemm(const BtArgs g) {
     _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)                                                              \
       _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                            \
         _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                          \
-          acc[(MH) * 4 + i_][(NH) * 2 + j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                           \
-              fa[i_][s_], fb[SET][j_][s_], acc[(MH) * 4 + i_][(NH) * 2 + j_], 0, 0, 0);                           \
+          acc[(MH) * 4 + i_][(NH) * 2 + j_] =                                                                    \
+              F16 ? __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fa[i_][s_]),                  \
+                                                           __builtin_bit_cast(f16x8, fb[SET][j_][s_]),             \
+                                                           acc[(MH) * 4 + i_][(NH) * 2 + j_], 0, 0, 0)             \
+                  : __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i_][s_], fb[SET][j_][s_],                           \
+                                                            acc[(MH) * 4 + i_][(NH) * 2 + j_], 0, 0, 0);           \
     __builtin_amdgcn_s_setprio(0);                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                            \
     __builtin_amdgcn_s_barrier();                                                                                 \
@@ -366,15 +375,17 @@ __global__ void __launch_bounds__(kBtThreads) k_bt_gemm(const BtArgs g) {
     for (int mi = 0; mi < 8; ++mi) {
       const int64_t i = i_wave + mi * 16;
       const bool iok = i < g.a.rows;  // a.rows is a multiple of 4 (host-checked): the four values share the verdict
-      float4 bv = zero4();
+      float4 bv = zero4(), sa = make_float4(1.f, 1.f, 1.f, 1.f);
       if (g.bias && iok) bv = ld4(g.bias + i);
+      if (g.a_scale && iok) sa = ld4(g.a_scale + i);
 #pragma unroll
       for (int r = 0; r < 4; ++r) s1[mi][r] = s2[mi][r] = 0.f;
 #pragma unroll
       for (int nj = 0; nj < 4; ++nj) {
         const int64_t j = j_wave + nj * 16;
-        const float4 v = make_float4(acc[mi][nj][0] + bv.x, acc[mi][nj][1] + bv.y, acc[mi][nj][2] + bv.z,
-                                     acc[mi][nj][3] + bv.w);
+        const float sb = (g.b_scale && j < g.b.rows) ? g.b_scale[j] : 1.f;  // (powers of two: the products are exact)
+        const float4 v = make_float4(acc[mi][nj][0] * (sa.x * sb) + bv.x, acc[mi][nj][1] * (sa.y * sb) + bv.y,
+                                     acc[mi][nj][2] * (sa.z * sb) + bv.z, acc[mi][nj][3] * (sa.w * sb) + bv.w);
         if (iok && j < g.store_rows && !(g.dbg & 1) && !((g.dbg & 4) && (nj & 1))) {
           if (g.dbg & 16) __builtin_nontemporal_store(floatx4{v.x, v.y, v.z, v.w}, reinterpret_cast<floatx4*>(y + j * g.ldy + i));
           else st4(y + j * g.ldy + i, v);
@@ -428,7 +439,8 @@ __global__ void __launch_bounds__(kBtThreads) k_bt_gemm(const BtArgs g) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int i = static_cast<int>(i_wave) + mi * 16 + r;
-          const float v = acc[mi][nj][r];
+          const float v = (g.a_scale && i < g.a.rows) ? acc[mi][nj][r] * g.a_scale[static_cast<int64_t>(bz) * g.a.rows + i]
+                                                      : acc[mi][nj][r];
           if (i < g.a.rows && v > best) { best = v; bi = i; }
         }
 #pragma unroll
@@ -452,6 +464,7 @@ __global__ void __launch_bounds__(kBtThreads) k_bt_gemm(const BtArgs g) {
         const int oi = ci[256 + tid];
         if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
         const int64_t o = (static_cast<int64_t>(bz) * g.b.rows + j) * g.tiles_m + tm;
+        if (g.b_scale) best *= g.b_scale[static_cast<int64_t>(bz) * g.b.rows + j];  // a positive factor per data row
         g.cand_val[o] = best;
         g.cand_idx[o] = bi;
       }
@@ -527,6 +540,72 @@ k_bt_cut_rows_ssq(const float* __restrict__ x, int64_t N, int H, int Dc, uint16_
     }
     acc = wave_sum(acc);
     if (lane == 0) ssq[row * H + h] = acc;
+  }
+}
+
+// ---- the pair format (round 4): fp32 accuracy from TWO fp16 pieces and three matrix passes instead of three bf16 pieces
+// and six.  A row (or, for the quantiser's input, a head's stretch of a row) is scaled by a power of two that puts its
+// largest magnitude into [2^14, 2^15) -- the top of fp16's range --, then cut into hi = fp16(x s) (round to nearest: 11
+// significant bits) and lo = fp16(x s - hi) (the remainder is exact in fp32; lo keeps 11 more bits).  For an element within
+// 2^-17 of the row's largest that is x to 2^-24 relative -- fp32's own resolution; a smaller element is kept to an
+// ABSOLUTE 2^-25 of the scaled row, i.e. 2^-39 of the row's largest magnitude: far below what the fp32 sum of the row's
+// products resolves.  a b = hi_a hi_b + hi_a lo_b + lo_a hi_b (+ lo_a lo_b < 2^-24 |a b|, dropped), accumulated in the
+// fp32 MFMA accumulator, small terms first; the epilogue multiplies by the two inverse scales (powers of two: exact).
+// The scale is per contraction ROW, so the format serves the products that contract along rows' columns (forward,
+// backward-data, the code assignment); the weight gradient contracts over the rows themselves and keeps the bf16 pieces.
+// A zero or non-finite row is not scaled; a bf16-stored stretch has lo = 0 exactly (its lo plane is never read).
+// One wave per row; `seg` = scaling stretch in columns (the whole row, or code_dim); out[plane][m][ld], plane 0 = hi;
+// inv_scale[(c / seg) * M + m]; ssq (optional) likewise: the stretch's sum of squares (the quantiser's row norms).
+__global__ void __launch_bounds__(kCutThreads)
+k_bt_cut_pair(const float* __restrict__ x1, int64_t ldx1, int K1, int64_t x1_rows, const void* __restrict__ x2, int x2_kind,
+              int K2, int64_t M, int seg, uint16_t* __restrict__ out, int64_t ps, int64_t ld, float* __restrict__ inv_scale,
+              float* __restrict__ ssq) {
+  const int lane = threadIdx.x & 63;
+  const int64_t m = static_cast<int64_t>(blockIdx.x) * (kCutThreads / 64) + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const int K = K1 + K2;
+  auto load4 = [&](int c) -> float4 {
+    if (c < K1) return m < x1_rows ? ld4(x1 + m * ldx1 + c) : zero4();
+    return ld4_kind(x2, m * static_cast<int64_t>(K2) + (c - K1), x2_kind);
+  };
+  for (int s0 = 0, si = 0; s0 < K; s0 += seg, ++si) {
+    float mx = 0.f, sq = 0.f;
+    for (int c = s0 + 4 * lane; c < s0 + seg; c += 256) {
+      const float4 v = load4(c);
+      mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+      sq += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    // (fmaxf drops NaNs: a row holding one is scaled by its largest finite magnitude and keeps its NaN)
+    int shift = 0;
+    if (mx > 0.f && mx <= 3.0e38f) {
+      shift = 14 - ilogbf(mx);
+      shift = shift > 110 ? 110 : (shift < -110 ? -110 : shift);
+    }
+    const float sc = ldexpf(1.f, shift);
+    if (lane == 0) {
+      inv_scale[static_cast<int64_t>(si) * M + m] = ldexpf(1.f, -shift);
+    }
+    if (ssq) {
+      sq = wave_sum(sq);
+      if (lane == 0) ssq[static_cast<int64_t>(si) * M + m] = sq;
+    }
+    for (int c = s0 + 4 * lane; c < s0 + seg; c += 256) {
+      const float4 v = load4(c);
+      const float xs[4] = {v.x * sc, v.y * sc, v.z * sc, v.w * sc};
+      uint32_t hb[4], lb[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const _Float16 h = static_cast<_Float16>(xs[e]);
+        const _Float16 l = static_cast<_Float16>(xs[e] - static_cast<float>(h));
+        hb[e] = static_cast<uint32_t>(__builtin_bit_cast(uint16_t, h));
+        lb[e] = static_cast<uint32_t>(__builtin_bit_cast(uint16_t, l));
+      }
+      uint16_t* o = out + m * ld + c;
+      *reinterpret_cast<uint2*>(o) = make_uint2(hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16));
+      *reinterpret_cast<uint2*>(o + ps) = make_uint2(lb[0] | (lb[1] << 16), lb[2] | (lb[3] << 16));
+    }
   }
 }
 
@@ -699,7 +778,7 @@ k_bt_reduce_slabs(const float* __restrict__ slab, int splits, int64_t n, float* 
 __global__ void __launch_bounds__(kCutThreads)
 k_bt_argmax_finish(const float* __restrict__ cand_val, const int32_t* __restrict__ cand_idx, const float* __restrict__ ssq,
                    const float* __restrict__ esq, int64_t N, int H, int K, int tiles, float* __restrict__ norm_out,
-                   int64_t* __restrict__ ind_out, double* __restrict__ partial) {
+                   int64_t* __restrict__ ind_out, double* __restrict__ partial, int ssq_by_head) {
   __shared__ double red[kCutThreads / 64];
   const int64_t item = static_cast<int64_t>(blockIdx.x) * kCutThreads + threadIdx.x;  // row * H + h
   double term = 0.0;
@@ -713,7 +792,7 @@ k_bt_argmax_finish(const float* __restrict__ cand_val, const int32_t* __restrict
       const float v = cand_val[o + t];
       if (v > best) { best = v; bi = cand_idx[o + t]; }
     }
-    const float nrm = sqrtf(ssq[item]);
+    const float nrm = sqrtf(ssq[ssq_by_head ? static_cast<int64_t>(h) * N + row : item]);
     const float inv = 1.0f / fmaxf(nrm, 1e-12f), xn2 = nrm * inv;  // F.normalize eps
     ind_out[item] = static_cast<int64_t>(bi);
     norm_out[item] = nrm;
@@ -730,7 +809,7 @@ k_bt_argmax_finish(const float* __restrict__ cand_val, const int32_t* __restrict
 __global__ void __launch_bounds__(kCutThreads)
 k_bt_gather_commit(const float* __restrict__ xp, int64_t N, int H, int Dc, int K, const float* __restrict__ embed,
                    const int64_t* __restrict__ ind, const float* __restrict__ ssq, int training, float* __restrict__ quant,
-                   float* __restrict__ xn_out, double* __restrict__ partial) {
+                   float* __restrict__ xn_out, double* __restrict__ partial, int ssq_by_head) {
   __shared__ double red[kCutThreads / 64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t item = static_cast<int64_t>(blockIdx.x) * (kCutThreads / 64) + w;
@@ -739,7 +818,7 @@ k_bt_gather_commit(const float* __restrict__ xp, int64_t N, int H, int Dc, int K
     const int64_t row = item / H;
     const int h = static_cast<int>(item - row * H);
     const int64_t HD = static_cast<int64_t>(H) * Dc;
-    const float inv = 1.0f / fmaxf(sqrtf(ssq[item]), 1e-12f);
+    const float inv = 1.0f / fmaxf(sqrtf(ssq[ssq_by_head ? static_cast<int64_t>(h) * N + row : item]), 1e-12f);
     const float* xr = xp + row * HD + static_cast<int64_t>(h) * Dc;
     const float* qr = embed + (static_cast<int64_t>(h) * K + ind[item]) * Dc;
     for (int c = 4 * lane; c < Dc; c += 256) {
@@ -787,6 +866,7 @@ struct PlaneSet {
   int kind = 0, np = 0;
   uint16_t* p = nullptr;     // [np][rows_padded][cols]
   float* colsum = nullptr;   // [row_blocks][cols] partial column sums (the bias gradient), row_blocks = ceil(rows_padded / 256)
+  float* inv_scale = nullptr;  // pair format (np == 2): [rows] factors that undo the row scaling
 };
 struct Arena {
   unsigned char* p = nullptr;
@@ -841,7 +921,7 @@ struct BtProfile {
 };
 BtProfile g_bt_profile;
 
-int bt_launch(BtArgs& a, int epi, hipStream_t st, bool tn = false) {
+int bt_launch(BtArgs& a, int epi, hipStream_t st, bool tn = false, bool f16 = false) {
   a.tiles_m = static_cast<int>((a.a.rows + kTile - 1) / kTile);
   a.tiles_n = static_cast<int>((a.b.rows + kTile - 1) / kTile);
   const int64_t work = static_cast<int64_t>(a.tiles_m) * a.tiles_n * a.splits * a.batch;
@@ -858,9 +938,11 @@ int bt_launch(BtArgs& a, int epi, hipStream_t st, bool tn = false) {
   if (work <= 0 || work >= (1ll << 31) || (!tn && (a.a.rows * a.a.ld >= (1ll << 31) || a.b.rows * a.b.ld >= (1ll << 31))))
     return STEMGNN_ERR_TOO_LARGE;
 #define BT_ATTR(K) hipFuncSetAttribute(reinterpret_cast<const void*>(K), hipFuncAttributeMaxDynamicSharedMemorySize, kBtLds)
-  static const bool attrs_ok = BT_ATTR((k_bt_gemm<kEpiStore, false>)) == hipSuccess &&
-                               BT_ATTR((k_bt_gemm<kEpiArgmax, false>)) == hipSuccess &&
-                               BT_ATTR((k_bt_gemm<kEpiStore, true>)) == hipSuccess;
+  static const bool attrs_ok = BT_ATTR((k_bt_gemm<kEpiStore, false, false>)) == hipSuccess &&
+                               BT_ATTR((k_bt_gemm<kEpiArgmax, false, false>)) == hipSuccess &&
+                               BT_ATTR((k_bt_gemm<kEpiStore, true, false>)) == hipSuccess &&
+                               BT_ATTR((k_bt_gemm<kEpiStore, false, true>)) == hipSuccess &&
+                               BT_ATTR((k_bt_gemm<kEpiArgmax, false, true>)) == hipSuccess;
 #undef BT_ATTR
   if (!attrs_ok) return STEMGNN_ERR_HIP;
   static const int dbg = getenv("STEMGNN_BT_DBG") ? atoi(getenv("STEMGNN_BT_DBG")) : 0;
@@ -878,9 +960,12 @@ int bt_launch(BtArgs& a, int epi, hipStream_t st, bool tn = false) {
     }
   }
   const dim3 grid(static_cast<unsigned>(blocks)), block(kBtThreads);
-  if (tn) hipExtLaunchKernelGGL((k_bt_gemm<kEpiStore, true>), grid, block, kBtLds, st, ev0, ev1, 0, a);
-  else if (epi == kEpiStore) hipExtLaunchKernelGGL((k_bt_gemm<kEpiStore, false>), grid, block, kBtLds, st, ev0, ev1, 0, a);
-  else hipExtLaunchKernelGGL((k_bt_gemm<kEpiArgmax, false>), grid, block, kBtLds, st, ev0, ev1, 0, a);
+  if (tn && f16) return STEMGNN_ERR_INVALID_ARG;  // the pair format is scaled per row: no contraction over rows
+  if (tn) hipExtLaunchKernelGGL((k_bt_gemm<kEpiStore, true, false>), grid, block, kBtLds, st, ev0, ev1, 0, a);
+  else if (epi == kEpiStore && f16) hipExtLaunchKernelGGL((k_bt_gemm<kEpiStore, false, true>), grid, block, kBtLds, st, ev0, ev1, 0, a);
+  else if (epi == kEpiStore) hipExtLaunchKernelGGL((k_bt_gemm<kEpiStore, false, false>), grid, block, kBtLds, st, ev0, ev1, 0, a);
+  else if (f16) hipExtLaunchKernelGGL((k_bt_gemm<kEpiArgmax, false, true>), grid, block, kBtLds, st, ev0, ev1, 0, a);
+  else hipExtLaunchKernelGGL((k_bt_gemm<kEpiArgmax, false, false>), grid, block, kBtLds, st, ev0, ev1, 0, a);
   STEMGNN_LAUNCH_CHECK();
   return STEMGNN_OK;
 }
@@ -903,6 +988,7 @@ inline void exact_segments(BtArgs& g, int pieces, int kt_all, int kt_b_lo /*K ti
 }
 
 std::atomic<int> g_bt_on{1};
+std::atomic<int> g_bt_pair{1};  // exact mode: forward / backward-data / code assignment from two fp16 pieces (0: three bf16 pieces)
 std::atomic<int64_t> g_bt_calls{0}, g_bt_fallbacks{0};
 
 }  // namespace
@@ -918,6 +1004,13 @@ void bt_served() { g_bt_calls.fetch_add(1, std::memory_order_relaxed); }
 void bt_missed() { g_bt_fallbacks.fetch_add(1, std::memory_order_relaxed); }
 
 static inline int np_of(int pieces) { return pieces == 1 ? 1 : 3; }
+static inline bool use_pair(int pieces) { return pieces == 3 && g_bt_pair.load(std::memory_order_relaxed) != 0; }
+// the pair format's three products, small terms first: (lo, hi), (hi, lo), (hi, hi); plane 0 = hi, 1 = lo
+static inline void pair_segments(BtArgs& g, int kt_all, int z_k0, int z_kt) {
+  static const int order[3][2] = {{1, 0}, {0, 1}, {0, 0}};
+  g.nseg = 0;
+  for (int s = 0; s < 3; ++s) g.seg[g.nseg++] = BtSeg{order[s][0], order[s][1], 0, kt_all, z_k0, z_kt};
+}
 
 // contraction splits of a weight gradient: about one block per CU over the output tiles
 static inline int bt_dw_splits(int64_t N, int64_t K) {
@@ -934,7 +1027,9 @@ static inline size_t bt_need_planes(int np, int64_t M, int64_t C) {
   return a256(static_cast<size_t>(np) * Mp * C * 2) + a256(static_cast<size_t>((Mp + 255) / 256) * C * 4);
 }
 static inline size_t bt_need_fwd(int np, int64_t M, int64_t N, int64_t K) {
-  return bt_need_planes(np, M, K) + a256(static_cast<size_t>(np) * N * K * 2);
+  // (+ the pair format's transposed fp32 copy of the weight and the two scale vectors)
+  return bt_need_planes(np, M, K) + a256(static_cast<size_t>(np) * N * K * 2) + a256(static_cast<size_t>(N) * K * 4) +
+         a256(static_cast<size_t>(M) * 4) + a256(static_cast<size_t>(std::max(N, K)) * 4) + 1024;
 }
 static inline size_t bt_need_bwd_weight(int np, int64_t M, int64_t N, int64_t K) {
   return bt_need_planes(np, M, N) + bt_need_planes(np, M, K) + a256(static_cast<size_t>(bt_dw_splits(N, K)) * N * K * 4);
@@ -944,8 +1039,8 @@ static inline size_t bt_need_vq(int64_t N, int64_t H, int64_t Dc, int64_t K) {
   const int64_t fin_blocks = (N * H + kCutThreads - 1) / kCutThreads;
   const int64_t gat_blocks = (N * H + kCutThreads / 64 - 1) / (kCutThreads / 64);
   return a256(static_cast<size_t>(3) * H * K * Dc * 2) + a256(static_cast<size_t>(3) * N * H * Dc * 2) +
-         2 * a256(static_cast<size_t>(N) * H * tiles * 4) + a256(static_cast<size_t>(N) * H * 4) +
-         a256(static_cast<size_t>(fin_blocks + gat_blocks) * 8);
+         2 * a256(static_cast<size_t>(N) * H * tiles * 4) + 2 * a256(static_cast<size_t>(N) * H * 4) +
+         a256(static_cast<size_t>(H) * K * 4) + a256(static_cast<size_t>(fin_blocks + gat_blocks) * 8);
 }
 
 // The straight planes of an operand x [M, C] (rows padded with zeros to whole K tiles) and the partial column sums the
@@ -960,6 +1055,18 @@ static int bt_planes(Lease& lease, const void* x, int kind, int64_t M, int64_t C
   ps.rows_padded = bt_rows_padded(M);
   const int row_blocks = static_cast<int>((ps.rows_padded + 255) / 256);
   ps.p = lease.take<uint16_t>(static_cast<size_t>(np) * ps.rows_padded * C * 2);
+  if (np == 2) {  // pair format: two fp16 planes of the row-scaled operand + the factors that undo the scaling
+    ps.inv_scale = lease.take<float>(static_cast<size_t>(M) * 4);
+    if (!ps.p || !ps.inv_scale) return STEMGNN_ERR_WORKSPACE;
+    k_bt_cut_pair<<<static_cast<unsigned>((M + 3) / 4), kCutThreads, 0, st>>>(
+        kind == kF32 ? static_cast<const float*>(x) : nullptr, C, kind == kF32 ? static_cast<int>(C) : 0, M,
+        kind == kF32 ? nullptr : x, kind, kind == kF32 ? 0 : static_cast<int>(C), M, static_cast<int>(C), ps.p,
+        ps.rows_padded * C, C, ps.inv_scale, nullptr);
+    STEMGNN_LAUNCH_CHECK();
+    if (lease.a->depth > 0) lease.a->cache.push_back(ps);
+    *out = ps;
+    return STEMGNN_OK;
+  }
   ps.colsum = lease.take<float>(static_cast<size_t>(row_blocks) * C * 4);
   if (!ps.p || !ps.colsum) return STEMGNN_ERR_WORKSPACE;
   dim3 grid(static_cast<unsigned>(row_blocks), static_cast<unsigned>((C / 4 + 63) / 64));
@@ -983,6 +1090,39 @@ int bt_linear_fwd(int pieces, const float* x1, const float* w1, int64_t K1, cons
   const int np = np_of(pieces);
   const int64_t K = K1 + K2;
   if (K1 % kBK != 0 || K2 % kBK != 0) return STEMGNN_ERR_WORKSPACE;
+  if (use_pair(pieces)) {
+    // exact mode, pair format: both operands as two fp16 planes of their row-scaled rows, three matrix passes
+    Lease lease(st);
+    uint16_t* xpl = lease.take<uint16_t>(static_cast<size_t>(2) * M * K * 2);
+    uint16_t* wpl = lease.take<uint16_t>(static_cast<size_t>(2) * N * K * 2);
+    float* xsc = lease.take<float>(static_cast<size_t>(M) * 4);
+    float* wsc = lease.take<float>(static_cast<size_t>(N) * 4);
+    if (!xpl || !wpl || !xsc || !wsc) return STEMGNN_ERR_WORKSPACE;
+    k_bt_cut_pair<<<static_cast<unsigned>((M + 3) / 4), kCutThreads, 0, st>>>(
+        x1, K1, static_cast<int>(K1), x1_rows, x2, x2_kind, static_cast<int>(K2), M, static_cast<int>(K), xpl, M * K, K, xsc,
+        nullptr);
+    STEMGNN_LAUNCH_CHECK();
+    k_bt_cut_pair<<<static_cast<unsigned>((N + 3) / 4), kCutThreads, 0, st>>>(
+        w1, K1, static_cast<int>(K1), N, w2, kF32, static_cast<int>(K2), N, static_cast<int>(K), wpl, N * K, K, wsc, nullptr);
+    STEMGNN_LAUNCH_CHECK();
+    BtArgs g{};
+    g.a = BtOp{wpl, N * K, K, N, 0};
+    g.b = BtOp{xpl, M * K, K, M, 0};
+    const int kt1 = static_cast<int>(K1 / kBK), kt2 = static_cast<int>(K2 / kBK);
+    pair_segments(g, kt1 + kt2, kt1, kt2);
+    g.splits = 1; g.batch = 1;
+    g.b_full_rows = (K2 > 0 && x1_rows < M) ? (x1_rows + kTile - 1) / kTile * kTile : (1ll << 62);
+    g.y = y; g.ldy = N; g.store_rows = store_rows;
+    g.bias = bias;
+    g.stats = stats_partial;
+    g.a_scale = wsc; g.b_scale = xsc;
+    const int rc = bt_launch(g, kEpiStore, st, false, true);
+    if (rc != STEMGNN_OK) return rc;
+    if (stats_partial && stats_slabs > g.tiles_n)
+      STEMGNN_HIP_TRY(hipMemsetAsync(stats_partial + static_cast<int64_t>(g.tiles_n) * 2 * N, 0,
+                                     sizeof(float) * (stats_slabs - g.tiles_n) * 2 * N, st));
+    return STEMGNN_OK;
+  }
   const size_t xb = static_cast<size_t>(np) * M * K * 2, wb = static_cast<size_t>(np) * N * K * 2;
   Lease lease(st);
   uint16_t* xpl = lease.take<uint16_t>(xb);
@@ -1029,6 +1169,29 @@ int bt_linear_bwd_data(int pieces, const float* dy, const float* w, int64_t M, i
   if (N % kBK != 0) return STEMGNN_ERR_WORKSPACE;
   Lease lease(st);
   PlaneSet gp;
+  if (use_pair(pieces)) {
+    // pair format: dy's rows scaled per row; the weight's COLUMNS are the contraction rows of w^T: transpose, then cut
+    int rc = bt_planes(lease, dy, kF32, M, N, 2, st, &gp);
+    if (rc != STEMGNN_OK) return rc;
+    float* wt = lease.take<float>(static_cast<size_t>(K) * N * 4);
+    uint16_t* wpl = lease.take<uint16_t>(static_cast<size_t>(2) * K * N * 2);
+    float* wsc = lease.take<float>(static_cast<size_t>(K) * 4);
+    if (!wt || !wpl || !wsc) return STEMGNN_ERR_WORKSPACE;
+    rc = stemgnn_transpose(w, N, K, wt, st);
+    if (rc != STEMGNN_OK) return rc;
+    k_bt_cut_pair<<<static_cast<unsigned>((K + 3) / 4), kCutThreads, 0, st>>>(wt, N, static_cast<int>(N), K, nullptr, kF32, 0,
+                                                                            K, static_cast<int>(N), wpl, K * N, N, wsc, nullptr);
+    STEMGNN_LAUNCH_CHECK();
+    BtArgs g{};
+    g.a = BtOp{wpl, K * N, N, K, 0};
+    g.b = BtOp{gp.p, gp.rows_padded * N, N, M, 0};
+    pair_segments(g, static_cast<int>(N / kBK), 0, static_cast<int>(N / kBK));
+    g.splits = 1; g.batch = 1;
+    g.b_full_rows = 1ll << 62;
+    g.y = dx; g.ldy = K; g.store_rows = M;
+    g.a_scale = wsc; g.b_scale = gp.inv_scale;
+    return bt_launch(g, kEpiStore, st, false, true);
+  }
   int rc = bt_planes(lease, dy, kF32, M, N, np, st, &gp);
   if (rc != STEMGNN_OK) return rc;
   uint16_t* wpl = lease.take<uint16_t>(static_cast<size_t>(np) * K * N * 2);  // w^T planes [K][N]
@@ -1138,7 +1301,44 @@ int bt_vq_assign(const float* xp, int64_t N, int64_t H, int64_t Dc, const float*
   int32_t* cidx = lease.take<int32_t>(cb);
   float* ssq = lease.take<float>(qb);
   double* partial = lease.take<double>(pb);
-  if (!epl || !xpl || !cval || !cidx || !ssq || !partial) return STEMGNN_ERR_WORKSPACE;
+  float* esc = lease.take<float>(static_cast<size_t>(H) * K * 4);
+  float* xsc = lease.take<float>(qb);
+  if (!epl || !xpl || !cval || !cidx || !ssq || !partial || !esc || !xsc) return STEMGNN_ERR_WORKSPACE;
+  if (g_bt_pair.load(std::memory_order_relaxed) != 0) {
+    // pair format (the reference forces fp32 in this product, vq.py:623,634: the pair product IS fp32-accurate): codes
+    // scaled per code, rows per (row, head); the arg-max compares C[i][j] * scale(code i) -- the row's own factor is
+    // positive and common to its candidates --, the candidate that leaves is the true similarity
+    k_bt_cut_pair<<<static_cast<unsigned>((H * K + 3) / 4), kCutThreads, 0, st>>>(
+        embed, Dc, static_cast<int>(Dc), H * K, nullptr, kF32, 0, H * K, static_cast<int>(Dc), epl, H * K * Dc, Dc, esc, nullptr);
+    STEMGNN_LAUNCH_CHECK();
+    k_bt_cut_pair<<<static_cast<unsigned>((N + 3) / 4), kCutThreads, 0, st>>>(
+        xp, HD, static_cast<int>(HD), N, nullptr, kF32, 0, N, static_cast<int>(Dc), xpl, N * HD, HD, xsc, ssq);
+    STEMGNN_LAUNCH_CHECK();
+    BtArgs g{};
+    g.a = BtOp{epl, H * K * Dc, Dc, K, K * Dc};
+    g.b = BtOp{xpl, N * HD, HD, N, Dc};
+    pair_segments(g, static_cast<int>(Dc / kBK), 0, static_cast<int>(Dc / kBK));
+    g.splits = 1; g.batch = static_cast<int>(H);
+    g.b_full_rows = 1ll << 62;
+    g.cand_val = cval; g.cand_idx = cidx;
+    g.a_scale = esc; g.b_scale = xsc;  // [h * K + i], [h * N + j]
+    int rc = bt_launch(g, kEpiArgmax, st, false, true);
+    if (rc != STEMGNN_OK) return rc;
+    k_bt_argmax_finish<<<static_cast<unsigned>(fin_blocks), kCutThreads, 0, st>>>(
+        cval, cidx, ssq, quant ? nullptr : esq, N, static_cast<int>(H), static_cast<int>(K), tiles, norm, ind, partial, 1);
+    STEMGNN_LAUNCH_CHECK();
+    int64_t nparts = fin_blocks;
+    if (quant) {
+      k_bt_gather_commit<<<static_cast<unsigned>(gat_blocks), kCutThreads, 0, st>>>(
+          xp, N, static_cast<int>(H), static_cast<int>(Dc), static_cast<int>(K), embed, ind, ssq, training, quant, xn,
+          partial + fin_blocks, 1);
+      STEMGNN_LAUNCH_CHECK();
+      nparts += gat_blocks;
+    }
+    k_bt_commit_finish<<<1, kCutThreads, 0, st>>>(partial, nparts, sq_scale, sqerr);
+    STEMGNN_LAUNCH_CHECK();
+    return STEMGNN_OK;
+  }
   k_bt_cut_rows<3><<<cut_grid(H * K * (Dc / 4)), kCutThreads, 0, st>>>(embed, Dc, static_cast<int>(Dc), H * K, nullptr, kF32,
                                                                       0, H * K, epl, H * K * Dc, Dc);
   STEMGNN_LAUNCH_CHECK();
@@ -1156,13 +1356,13 @@ int bt_vq_assign(const float* xp, int64_t N, int64_t H, int64_t Dc, const float*
   int rc = bt_launch(g, kEpiArgmax, st);
   if (rc != STEMGNN_OK) return rc;
   k_bt_argmax_finish<<<static_cast<unsigned>(fin_blocks), kCutThreads, 0, st>>>(
-      cval, cidx, ssq, quant ? nullptr : esq, N, static_cast<int>(H), static_cast<int>(K), tiles, norm, ind, partial);
+      cval, cidx, ssq, quant ? nullptr : esq, N, static_cast<int>(H), static_cast<int>(K), tiles, norm, ind, partial, 0);
   STEMGNN_LAUNCH_CHECK();
   int64_t nparts = fin_blocks;
   if (quant) {
     k_bt_gather_commit<<<static_cast<unsigned>(gat_blocks), kCutThreads, 0, st>>>(
         xp, N, static_cast<int>(H), static_cast<int>(Dc), static_cast<int>(K), embed, ind, ssq, training, quant, xn,
-        partial + fin_blocks);
+        partial + fin_blocks, 0);
     STEMGNN_LAUNCH_CHECK();
     nparts += gat_blocks;
   }
@@ -1231,6 +1431,12 @@ int stemgnn_profile_bigtile_collect(double* total_ms_host, double* total_flop_ho
   if (total_flop_host) *total_flop_host = flop;
   if (launches_host) *launches_host = static_cast<int64_t>(recs.size());
   return STEMGNN_OK;
+}
+
+int stemgnn_linear_set_pair(int on) {
+  const int prev = g_bt_pair.load(std::memory_order_relaxed);
+  if (on == 0 || on == 1) g_bt_pair.store(on, std::memory_order_relaxed);
+  return prev;
 }
 
 int stemgnn_linear_set_bigtile(int on) {

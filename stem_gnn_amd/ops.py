@@ -806,6 +806,12 @@ def linear_set_bigtile(on: int) -> int:
     return int(lib.stemgnn_linear_set_bigtile(int(on)))
 
 
+def linear_set_pair(on: int) -> int:
+    """Exact mode on the big-tile core: forward / backward-data / code assignment from two fp16 pieces of power-of-two
+    scaled rows (1, default: three matrix passes) or from the three bf16 pieces (0: six).  Returns the previous setting."""
+    return int(lib.stemgnn_linear_set_pair(int(on)))
+
+
 # The big-tile core's scratch (operand planes, split slabs, arg-max candidates) is the CALLER's: one arena per (device,
 # stream), allocated here through torch's caching allocator -- in stream order, before the call that needs it -- and
 # registered with the library, which never allocates.  It is kept between calls and only ever grows.

@@ -1151,6 +1151,76 @@ def test_large_products_on_the_bigtile_core(dev, mode, m, k1, k2, n, rows):
     torch.testing.assert_close(dws[0], dws[1], rtol=1e-5, atol=2e-5 * float(want.abs().max()))
 
 
+@pytest.mark.parametrize("case", ["normal", "row_scales", "in_row_range", "outlier", "tiny_and_huge_rows", "zero_rows"])
+def test_pair_format_products_are_fp32_accurate(dev, case):
+    """The exact mode's pair format (csrc/bigtile.hip: two fp16 pieces of rows scaled by a power of two, three matrix
+    passes) against fp64, for the forward and the backward-data product, on operands chosen to strain it: rows of very
+    different magnitudes, eight decades of range INSIDE a row, one outlier of 1e4 among 1e-4 values, rows at 1e-30 and
+    1e+30, all-zero rows.  Yardstick: the error of the fp32-MFMA kernels (mode 0: an fp32 fma chain -- what "fp32" means
+    for this product) and of the three-bf16-piece form on the same operands, every error taken relative to
+    sum_k |x_k| |w_k| of its element (the norm-wise measure an fp32 sum is judged by).  The pair format must be no worse
+    than twice the fp32 chain, level with the bf16-piece form, and finite wherever fp64's results are."""
+    from stem_gnn_amd import ops
+    from stem_gnn_amd._lib import lib
+    torch.manual_seed(11)
+    m, k, n = 32768, 768, 512
+    x = torch.randn(m, k, device=dev)
+    w = torch.randn(n, k, device=dev) * 0.05
+    if case == "row_scales":
+        x *= 10.0 ** (torch.rand(m, 1, device=dev) * 12 - 6)
+        w *= 10.0 ** (torch.rand(n, 1, device=dev) * 6 - 3)
+    elif case == "in_row_range":
+        x *= 10.0 ** (-8 * torch.rand(m, k, device=dev))
+        w *= 10.0 ** (-4 * torch.rand(n, k, device=dev))
+    elif case == "outlier":
+        x *= 1e-4
+        x[torch.arange(m, device=dev), torch.randint(0, k, (m,), device=dev)] = 1e4
+    elif case == "tiny_and_huge_rows":
+        x[: m // 2] *= 1e-30
+        x[m // 2:] *= 1e30
+    elif case == "zero_rows":
+        x[::3] = 0
+        w[5] = 0
+    b = torch.randn(n, device=dev)
+    dy = torch.randn(m, n, device=dev)
+    if case == "row_scales":
+        dy *= 10.0 ** (torch.rand(m, 1, device=dev) * 12 - 6)
+    ref_y = x.double() @ w.double().t()
+    den_y = (x.double().abs() @ w.double().abs().t()).clamp_min(1e-300)
+    ref_dx = dy.double() @ w.double()
+    den_dx = (dy.double().abs() @ w.double().abs()).clamp_min(1e-300)
+
+    def errors(mode, pair):
+        prev, was = ops.linear_set_mode(mode), ops.linear_set_pair(pair)
+        try:
+            served = lib.stemgnn_linear_bigtile_calls()
+            y, _, _ = ops.linear_fwd(x, w, None, None, None, False)  # (no bias: its rounding is not the product's error)
+            dx = ops.linear_bwd_data(dy, w)
+            took = lib.stemgnn_linear_bigtile_calls() - served
+        finally:
+            ops.linear_set_mode(prev)
+            ops.linear_set_pair(was)
+        assert bool(torch.isfinite(y).all()) and bool(torch.isfinite(dx).all())
+        e_y = float(((y.double() - ref_y).abs() / den_y).max())
+        e_dx = float(((dx.double() - ref_dx).abs() / den_dx).max())
+        return e_y, e_dx, took, y
+
+    f32_y, f32_dx, t0, _ = errors(0, 1)        # fp32-MFMA tile kernels (the core does not serve mode 0)
+    b3_y, b3_dx, t3, _ = errors(1, 0)          # the core, three bf16 pieces
+    p_y, p_dx, t2, y_pair = errors(1, 1)       # the core, pair format
+    assert (t0, t3, t2) == (0, 2, 2)
+    print(f"{case}: forward fp32-chain {f32_y:.2e} bf16x3 {b3_y:.2e} pair {p_y:.2e}; backward-data {f32_dx:.2e} {b3_dx:.2e} {p_dx:.2e}")
+    # measured (in this order: fp32 chain, bf16 pieces, pair; forward / backward-data): normal 4.7e-7 1.5e-7 1.5e-7 /
+    # 4.3e-7 1.5e-7 1.3e-7; rows of different magnitudes 4.6e-7 1.4e-7 1.4e-7 / 1.0e-6 3.8e-7 3.8e-7; eight decades
+    # inside a row 1.8e-6 7.6e-7 8.2e-7 / 8.0e-7 3.1e-7 3.3e-7
+    assert p_y <= 2 * f32_y and p_dx <= 2 * f32_dx          # no worse than twice the fp32 chain (it is 2-3x better)
+    assert p_y <= 1.5 * b3_y + 2e-8 and p_dx <= 1.5 * b3_dx + 2e-8  # and level with the three exact bf16 pieces
+    if case == "zero_rows":  # a zero row times anything is exactly zero; with a bias: exactly the bias
+        assert float(y_pair[::3].abs().max()) == 0.0 and float(y_pair[:, 5].abs().max()) == 0.0
+        yb, _, _ = ops.linear_fwd(x, w, None, None, b, False)
+        assert torch.equal(yb[::3], b.expand(yb[::3].shape)) and torch.equal(yb[:, 5], b[5].expand(m))
+
+
 def test_bigtile_core_without_an_arena_is_a_counted_fallback_and_allocates_nothing(dev):
     """The boundary's rule (entry points never allocate or synchronise) for the big-tile core: its
     scratch is the caller's arena.  Without one a qualifying product runs on the tile kernels and the miss is COUNTED

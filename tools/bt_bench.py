@@ -42,7 +42,7 @@ def main():
     shapes = [("project_in 768->3072", 768, 0, 3072), ("layer 768+768->768", 768, 768, 768), ("lin 768->768", 768, 0, 768)]
     for mode in [int(v) for v in args.modes.split(",")]:
         prev = ops.linear_set_mode(mode)
-        pieces = 6 if mode == 1 else 1
+        pieces = (3 if ops.linear_set_pair(-1) else 6) if mode == 1 else 1  # matrix passes per fp32 product (weight gradient: always 6)
         for name, k1, k2, n in shapes:
             x1 = torch.randn(M, k1, device=dev)
             x2 = torch.randn(M, k2, device=dev) if k2 else None
@@ -60,8 +60,9 @@ def main():
                     ms = timeit(fn, args.reps)
                     ops.linear_set_bigtile(was)
                     row.append(ms)
+                pc = 6 if (mode == 1 and what == "bwd-weight") else pieces
                 print(f"mode {mode} {name:24s} {what:10s} core {row[0]:8.3f} ms = {fl / row[0] / 1e9:7.1f} TF fp32-eq "
-                      f"({pieces * fl / row[0] / 1e9:7.1f} executed)   tile {row[1]:8.3f} ms = {fl / row[1] / 1e9:7.1f} TF   "
+                      f"({pc * fl / row[0] / 1e9:7.1f} executed)   tile {row[1]:8.3f} ms = {fl / row[1] / 1e9:7.1f} TF   "
                       f"x{row[1] / row[0]:.2f}", flush=True)
             del x1, x2, dy
         ops.linear_set_mode(prev)
@@ -87,7 +88,7 @@ def main():
             row.append(timeit(run, args.reps))
             ops.linear_set_bigtile(was)
         print(f"assign N={N} H={H} K={K} Dc={Dc}: core {row[0]:8.3f} ms = {fl / row[0] / 1e9:7.1f} TF fp32-eq "
-              f"({6 * fl / row[0] / 1e9:7.1f} executed)   tile {row[1]:8.3f} ms = {fl / row[1] / 1e9:7.1f} TF   x{row[1] / row[0]:.2f}",
+              f"({(3 if ops.linear_set_pair(-1) else 6) * fl / row[0] / 1e9:7.1f} executed)   tile {row[1]:8.3f} ms = {fl / row[1] / 1e9:7.1f} TF   x{row[1] / row[0]:.2f}",
               flush=True)
         del xp
 
