@@ -669,10 +669,10 @@ def main():
                                 "breakdown_MB": {k: round(v / 1e6, 1) for k, v in table.items()}}
         if bt_launches > 0 and bt_ms > 0:
             # The D >= 256 workloads are matrix-bound: their dense products and the large-codebook assignment run on the
-            # big-tile core (csrc/bigtile.hip); every launch in the timed region carried its own HIP events.  EXECUTED bf16
-            # matrix work (six piece products per fp32 product in the exact mode) over kernel time, against the dense bf16
-            # MFMA peak of MI355X_MICROARCH.md (2.5 PFLOP/s; what the chip sustains on random data is ~1.3-1.5).
-            pieces = 6.0 if ops.linear_set_mode(-1) == 1 else 1.0
+            # big-tile core (csrc/bigtile.hip); every launch in the timed region carried its own HIP events.  EXECUTED 16-bit
+            # matrix work (exact mode: three fp16 passes per fp32 product -- six bf16 passes in the weight gradients; bf16
+            # mode: one) over kernel time, against the dense bf16 / fp16 MFMA peak of MI355X_MICROARCH.md (2.5 PFLOP/s;
+            # what the chip sustains on random data is ~1.3-1.5).
             out["roofline_dense"] = {
                 "bound": "mfma", "kernel": "k_bt_gemm (big-tile core: 256 x 256 x 64 bf16 MFMA tiles, LDS-DMA staging; "
                                            "launches of the timed region, per-launch HIP events)",
@@ -680,8 +680,8 @@ def main():
                 "launches_per_step": bt_launches / args.steps, "kernel_ms_per_step": bt_ms / args.steps,
                 "share_of_step": bt_ms / args.steps / (dt / args.steps * 1e3),
                 "executed_pflop_per_step": bt_flop / args.steps / 1e15,
-                "fp32_equivalent_tflops": bt_flop / bt_ms / 1e9 / pieces,
-                "pieces_per_product": pieces}
+                "matrix_passes_per_fp32_product": ("1 (bf16 GEMM mode)" if ops.linear_set_mode(-1) == 2 else
+                                                   "3 (pair format: forward, backward-data, code assignment) / 6 (weight gradient)")}
         elif not args.no_extra:
             # The dense products are the largest share of the step: the layer product
             # lin_l(agg) + lin_r(x) at this batch's row count, timed back to back.  Executed matrix-core work is six

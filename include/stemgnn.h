@@ -351,7 +351,7 @@ int stemgnn_dropout_keep_mask(int64_t n, float p, uint64_t seed, uint64_t offset
  * queries.  Returns the previous mode.  The tile plan (stemgnn_linear_stats_blocks) depends on the mode: set it
  * before sizing buffers.  STEMGNN_GEMM=f32 / bf16 in the environment starts the process in mode 0 / 2. */
 int stemgnn_linear_set_mode(int mode);
-/* Large products (>= 8 192 rows, both feature extents >= 256 and multiples of 64, >= 2.5e10 flop: the D = 768
+/* Large products (>= 8 192 rows, both feature extents >= 256 and multiples of 64, >= 1e10 flop: the D = 768
  * configurations) run on the big-tile core (csrc/bigtile.hip: one hand-written 256 x 256 x 64 bf16 MFMA GEMM over
  * operands cut into bf16 planes by a cut pass) in mode 1 (the six exact piece products as one contraction of 6 K) and
  * mode 2 (one rounded plane) alike.  Its scratch -- the planes, the weight gradient's split slabs -- comes from the

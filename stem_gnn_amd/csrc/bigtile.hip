@@ -993,12 +993,12 @@ std::atomic<int64_t> g_bt_calls{0}, g_bt_fallbacks{0};
 
 }  // namespace
 
-// Products the big-tile core takes: large (>= 8 192 rows, >= 2.5e10 flop), both feature extents at least one 256 tile and
+// Products the big-tile core takes: large (>= 8 192 rows, >= 1e10 flop), both feature extents at least one 256 tile and
 // multiples of 64.  Below that the 128-row tile / weight-stationary kernels win (HBM-bound shapes, D = 128).
 bool bt_gemm_ok(int64_t M, int64_t N, int64_t K) {
   // (operand planes are addressed with 32-bit element offsets: rows x row length below 2^31, padding included)
   return g_bt_on.load(std::memory_order_relaxed) != 0 && M >= 8192 && N >= 256 && K >= 256 && N % 64 == 0 && K % 64 == 0 &&
-         2.0 * static_cast<double>(M) * N * K >= 2.5e10 && (M + 8192) * std::max(N, K) < (1ll << 31);
+         2.0 * static_cast<double>(M) * N * K >= 1.0e10 && (M + 8192) * std::max(N, K) < (1ll << 31);
 }
 void bt_served() { g_bt_calls.fetch_add(1, std::memory_order_relaxed); }
 void bt_missed() { g_bt_fallbacks.fetch_add(1, std::memory_order_relaxed); }

@@ -215,6 +215,60 @@ def test_c2_full_batch_step_matches_oracle(dev):
         torch.testing.assert_close(p2.detach().cpu(), p1.detach(), rtol=1e-3, atol=3e-4, msg=lambda m: f"{n1}: {m}")
 
 
+def test_wide_model_step_on_the_bigtile_core_matches_oracle(dev):
+    """A step whose products the big-tile core serves (csrc/bigtile.hip: the exact mode's pair format for forward /
+    backward-data / the large-codebook assignment, bf16 pieces for the weight gradients) against the CPU oracle:
+    N = 20 000 nodes, E = 120 000, D = code_dim = 512, H = 4, K = 512, full batch -- every layer product, project_in, the
+    decoders' Linears, their backward products and the assignment are past the core's size gate.  The HIP run's draws
+    replayed; every loss term of two optimiser steps to 1e-4 (north_star), the code assignment exact outside near-ties
+    (the oracle adopts a proposed index only within 1e-5 of its own maximum), parameters compared after the steps; the
+    core's counters show that it served the products and that nothing fell back."""
+    import torch.nn as nn
+    from oracle import stem_oracle as O  # checker only
+    from stem_gnn_amd import ops
+    from stem_gnn_amd._lib import lib
+    from stem_gnn_amd.data.synthetic import make_graph
+    from stem_gnn_amd.graph import EdgeTypeAttr, GraphStructure
+    from stem_gnn_amd.model.encoder import Encoder, InnerProductDecoder
+    from stem_gnn_amd.model.pt_model import PretrainModel
+    from stem_gnn_amd.model.vq import VectorQuantize
+    from stem_gnn_amd.pretrain import default_params, pretrain_step
+    N, E, D, L, H, K = 20_000, 120_000, 512, 2, 4, 512
+    g = make_graph(N, E, D, 4, kind="U", device=dev, graph_seed=77, feat_seed=3)
+    x = g.node_text_feat if g.node_text_feat.size(0) == N else g.node_text_feat[g.x]
+    gs = GraphStructure(g.edge_index, N, g.xe, validate=True).ensure_transpose()
+    torch.manual_seed(0)
+    om = O.build_oracle_model(D, L, H, K, D, dropout=0.15)
+    enc = Encoder(D, D, nn.ReLU, L, backbone="sage", normalize="batch", dropout=0.15)
+    vq = VectorQuantize(dim=D, codebook_size=K, codebook_dim=D, heads=H, separate_codebook_per_head=True, decay=0.8,
+                        commitment_weight=10, use_cosine_sim=True, orthogonal_reg_weight=1, orthogonal_reg_max_codes=32,
+                        kmeans_init=False, ema_update=False)
+    gm = PretrainModel(enc, vq, nn.Linear(D, D), InnerProductDecoder(D, D), nn.Linear(2 * D, D))
+    gm.load_state_dict(om.state_dict())
+    gm = gm.to(dev)
+    params = default_params()
+    opt_o = torch.optim.AdamW(om.parameters(), lr=1e-4, weight_decay=1e-5)
+    opt_g = torch.optim.AdamW(gm.parameters(), lr=1e-4, weight_decay=1e-5)
+    ops.manual_seed(23)
+    x_cpu, ei_cpu, ea_cpu = x.cpu(), g.edge_index.cpu(), g.edge_text_feat[g.xe].cpu()
+    torch.set_num_threads(max(torch.get_num_threads(), 8))
+    served, missed = lib.stemgnn_linear_bigtile_calls(), lib.stemgnn_linear_bigtile_fallbacks()
+    for step in range(2):
+        loss_g, losses_g, draws = pretrain_step(gm, opt_g, None, params, x, gs, EdgeTypeAttr(g.edge_text_feat, g.xe), N)
+        cpu_draws = {k: ([m.cpu() for m in v] if isinstance(v, list) else v.cpu()) for k, v in draws.items()}
+        loss_o, losses_o, _ = O.pretrain_step(om, opt_o, None, params, x_cpu, ei_cpu, ea_cpu, N, cpu_draws)
+        for k in losses_o:
+            torch.testing.assert_close(losses_g[k].cpu().reshape(-1), losses_o[k].reshape(-1), rtol=1e-4, atol=1e-5,
+                                       msg=lambda m: f"step {step} {k}: {m}")
+        torch.testing.assert_close(loss_g.cpu().reshape(-1), loss_o.reshape(-1), rtol=1e-4, atol=1e-5)
+    assert lib.stemgnn_linear_bigtile_calls() - served >= 2 * 20, "the step's products must have run on the big-tile core"
+    assert lib.stemgnn_linear_bigtile_fallbacks() == missed
+    for (n1, p1), (n2, p2) in zip(om.named_parameters(), gm.named_parameters()):
+        if "lin_l.bias" in n1 or n1.startswith("sem_encoder"):
+            continue  # exactly-zero true gradient in front of BatchNorm (rounding noise through Adam); teacher: EMA
+        torch.testing.assert_close(p2.detach().cpu(), p1.detach(), rtol=1e-3, atol=3e-4, msg=lambda m: f"{n1}: {m}")
+
+
 def test_c3_sized_full_batch_step_runs_and_learns(dev):
     """BASELINE config 3 stand-in (169,343 nodes, 2,315,598 directed entries, D = 768, K = 512, full batch): too big
     for the CPU oracle, so the step is checked through properties: finite decreasing loss, in-range codes, a used
