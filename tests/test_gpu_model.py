@@ -1240,6 +1240,52 @@ def test_pair_format_products_are_fp32_accurate(dev, case):
         assert torch.equal(yb[::3], b.expand(yb[::3].shape)) and torch.equal(yb[:, 5], b[5].expand(m))
 
 
+@pytest.mark.parametrize("mode,pair", [(1, 1), (1, 0), (2, 1)], ids=["exact-pair", "exact-bf16x3", "bf16"])
+def test_bigtile_layer_product_with_bf16_stored_operand_zero_rows_and_row_limit(dev, mode, pair):
+    """The layer product as BASELINE config 5 runs it, on the big-tile core in every format: lin_l(agg) + lin_r(h) with
+    the aggregate holding its leading `x1_rows` rows only (a sampled batch: row tiles behind them contract over lin_r's
+    half alone -- the boundary 4 000 is inside a 256-row tile), `h` STORED as bf16 (feature_kind 1), the BatchNorm column
+    sums over all rows, and a row limit on the output (the EMA teacher's last layer: statistics over every row, the
+    seed rows' values written) -- against the 128-row tile kernels on the same call and against fp64."""
+    from stem_gnn_amd import ops
+    from stem_gnn_amd._lib import lib, check
+    torch.manual_seed(5)
+    m, k1, k2, n, rows, keep = 33_000, 768, 768, 768, 4_000, 1_024
+    agg = torch.randn(rows, k1, device=dev)                    # a [x1_rows, K1] buffer: rows past it do not exist
+    h = (torch.randn(m, k2, device=dev) * 2).bfloat16().contiguous()
+    w1, w2 = torch.randn(n, k1, device=dev) * 0.05, torch.randn(n, k2, device=dev) * 0.05
+    b = torch.randn(n, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    blocks = int(lib.stemgnn_linear_stats_blocks(m, n))
+    prev, was_pair = ops.linear_set_mode(mode), ops.linear_set_pair(pair)
+    out = {}
+    try:
+        ops.linear_scratch(m, k1 + k2, n)
+        for core_on in (1, 0):
+            was = ops.linear_set_bigtile(core_on)
+            served = lib.stemgnn_linear_bigtile_calls()
+            y = torch.full((keep, n), float("nan"), device=dev)
+            part = torch.zeros(blocks, 2, n, device=dev)
+            check(lib.stemgnn_linear_fwd_rows_k(agg.data_ptr(), w1.data_ptr(), k1, h.data_ptr(), 1, w2.data_ptr(), k2,
+                                                b.data_ptr(), m, n, y.data_ptr(), part.data_ptr(), None, rows, keep, st))
+            assert lib.stemgnn_linear_bigtile_calls() - served == (1 if core_on else 0)
+            out[core_on] = (y, part.double().sum(0))
+            ops.linear_set_bigtile(was)
+    finally:
+        ops.linear_set_mode(prev)
+        ops.linear_set_pair(was_pair)
+    r = (lambda t: t.bfloat16().double()) if mode == 2 else (lambda t: t.double())
+    aggf = torch.zeros(m, k1, device=dev, dtype=torch.float64)
+    aggf[:rows] = r(agg)
+    ref = aggf @ r(w1).t() + h.double() @ r(w2).t() + b.double()
+    want = (ref[:keep], torch.stack([ref.sum(0), (ref * ref).sum(0)]))
+    for name, got_core, got_tile, w_ in zip(("y[:keep]", "column sums"), out[1], out[0], want):
+        tol = 2e-5 * float(w_.abs().max())
+        torch.testing.assert_close(got_core.double(), w_, rtol=1e-5, atol=tol, msg=lambda s_: f"{name} (core): {s_}")
+        torch.testing.assert_close(got_core.double(), got_tile.double(), rtol=1e-5, atol=tol,
+                                   msg=lambda s_: f"{name} (core vs tile kernel): {s_}")
+
+
 def test_bigtile_core_without_an_arena_is_a_counted_fallback_and_allocates_nothing(dev):
     """The boundary's rule (entry points never allocate or synchronise) for the big-tile core: its
     scratch is the caller's arena.  Without one a qualifying product runs on the tile kernels and the miss is COUNTED
