@@ -1,32 +1,38 @@
-// The big-tile product core (round 4): one hand-written bf16 MFMA GEMM for the LARGE dense products of the path -- the
+// The big-tile product core (round 4): one hand-written 16-bit MFMA GEMM for the LARGE dense products of the path -- the
 // D = 768 configurations (BASELINE configs 3 and 5, the reference's own default width, config/pretrain.yaml:3-16) --
 // used by the projections (nn.Linear forward / backward-data / weight gradient: STEM-GNN/model/encoder.py:83-87,
 // model/vq.py:881,1041, model/pt_model.py:42,80,94) AND by the quantiser's code assignment (model/vq.py:650-657), where
 // the arg-max over the codes is taken from the accumulators: no [N, K] similarity matrix exists.  It replaces the
 // vendor-library wrapper of round 3 (csrc/blaslt.hip, deleted): nothing on the path is a library GEMM any more.
 //
-//   C[i][j] = sum over segments s, k:  A_{pa(s)}[i][k] * B_{pb(s)}[j][k]          ("NT": both operands k-contiguous)
+//   NT form:  C[i][j] = sum over stretches s, k:  A_{pa(s)}[i][k] * B_{pb(s)}[j][k]     (both operands k-contiguous)
+//   TN form:  C[i][j] = sum over stretches s, m:  A_{pa(s)}[m][i] * B_{pb(s)}[m][j]     (the weight gradient: contraction
+//             over the operands' rows, read with transposing LDS reads from the same straight planes)
 //
-// Operands are bf16 PLANES written once by a cut pass (k_bt_cut_*): in the exact mode (stemgnn_linear_set_mode(1)) an
-// fp32 operand is its three exact pieces h + m + l (common.h) and the product is the six significant piece products,
-// small terms first -- here six SEGMENTS of one contraction, i.e. ONE bf16 GEMM over 6 K with the operands read from
-// three planes each (nothing is concatenated in memory); in the bf16 GEMM mode (mode 2) one rounded plane, one segment.
+// Operands are 16-bit PLANES written once by a cut pass (k_bt_cut_*), a product is a list of STRETCHES of one contraction
+// (which plane of each side, which K tiles) -- nothing is concatenated in memory:
+//   * exact mode (stemgnn_linear_set_mode(1)), forward / backward-data / code assignment: the PAIR format -- two fp16
+//     pieces of a row scaled by a power of two, three stretches (lo hi, hi lo, hi hi), fp32-accurate (k_bt_cut_pair);
+//   * exact mode, weight gradients (and everything with stemgnn_linear_set_pair(0)): the three exact bf16 pieces
+//     h + m + l of common.h, the six significant piece products, small terms first;
+//   * bf16 GEMM mode (mode 2): one rounded bf16 plane, one stretch.
 // At D = 768 the products are matrix-bound, so the plane traffic the round-2 plane kernels lost on (D = 128: HBM-bound)
 // is noise here: 0.8 GB of planes against 4.8 PFLOP of executed matrix work for project_in at C3 size.
 //
 // Tile: 256 x 256 x 64 per 512-thread block (8 waves as 2 (a rows) x 4 (b rows); a wave owns 128 x 64 of C as 8 x 4
-// accumulators of v_mfma_f32_16x16x32_bf16), LDS 128 KiB = 2 buffers x 4 half tiles (128 rows x 128 B each), filled by
-// LDS-DMA (global_load_lds_dwordx4: no VGPR round trip), XOR-swizzled on the SOURCE address and on the read (the DMA
-// writes lane-linear), fragments by ds_read_b128 (conflict-free: chunk ^= (row >> 1) & 7).
+// accumulators of v_mfma_f32_16x16x32_{bf16,f16}), LDS 128 KiB = 2 buffers x 4 half tiles (128 rows x 128 B each), filled
+// by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip), XOR-swizzled on the SOURCE address and on the read (the DMA
+// writes lane-linear), fragments by ds_read_b128 (conflict-free: chunk ^= (row >> 1) & 7).  Blocks are persistent (one
+// per CU) and walk XCD-contiguous work ids.
 // Schedule (after MI355X cdna_hip_programming.md section 5, "256^2 8-phase template", re-derived for this staging
 // order): a K tile is four phases, one C quadrant (64 x 32 per wave, 16 MFMAs) each; every phase is
 //     { ds_read this quadrant's new fragments | stage ONE half tile (2 DMAs per wave) | s_waitcnt vmcnt(8) }
 //     s_barrier  { s_waitcnt lgkmcnt(0); 16 MFMAs }  s_barrier
 // and waves 4-7 run ONE BARRIER BEHIND waves 0-3, so that on every SIMD one wave multiplies while its partner loads.
-// Half tiles are interleaved row sets chosen so that each is read in ONE phase only (A0: phase 0, B0: phase 0 -- its
-// fragments stay in registers for phase 3 --, B1: phase 1, A1: phase 2); a slot is re-staged at least two phases after
-// its last read (the guide's rule for staggered wave groups) and read at the earliest one phase after the wait that
-// retires it: phase 0 stages B1(t+1), 1: A1(t+1), 2: A0(t+2), 3: B0(t+2); with one half tile per phase, "all but the
+// Half tiles are interleaved row sets chosen so that each is read in ONE phase only (A0: phase 0, B1: phase 1, A1: phase
+// 2, the NEXT tile's B0: phase 3, into the fragment registers B1 has just left); a slot is re-staged three phases after
+// its last read (the guide asks for two with staggered wave groups) and read at the earliest one phase after the wait
+// that retires it: phase 0 stages B1(t+1), 1: A1(t+1), 2: B0(t+2), 3: A0(t+2); with one half tile per phase, "all but the
 // four youngest half tiles have landed" (vmcnt(8)) is exactly what the next phase's reads need.
 #include "common.h"
 
