@@ -640,7 +640,14 @@ def main():
                        "layers": params["num_layers"], "vq_heads": params["codebook_head"],
                        "codebook_size": params["codebook_size"], "code_dim": params["code_dim"],
                        "seeds_per_rank": nb[3], "batch_nodes": int(nb[0].size(0)), "batch_edges": int(nb[1].num_edges),
-                       "parallelism": f"dp{world}", "grad_sync": (args.grad_sync if world > 1 else None), "edge_attr": "type-indexed (4E + T*D*4 bytes)",
+                       "parallelism": f"dp{world}", "grad_sync": (args.grad_sync if world > 1 else None),
+                       "dense_products": (
+                           "bf16 GEMM mode: one bf16 MFMA pass on operands rounded to bf16, fp32 accumulation" if gemm_bf16 else
+                           ("fp32 results on the 16-bit matrix cores, fp32 accumulation: big-tile core -- forward / "
+                            "backward-data / code assignment from two fp16 pieces of power-of-two scaled rows (3 passes), "
+                            "weight gradients from three exact bf16 pieces (6 passes)" if D >= 256 else
+                            "fp32 results from three exact bf16 pieces per operand (6 bf16 MFMA passes), fp32 accumulation: "
+                            "128-row tile / weight-stationary kernels")), "edge_attr": "type-indexed (4E + T*D*4 bytes)",
                        "preheat_steps": preheat_steps, "preheat_s": round(preheat_s, 3),
                        "loader_ms_per_batch_outside_timed_region": round(sampler_ms, 3),
                        "ms_per_step_with_loader_in_loop": None if e2e_ms is None else round(e2e_ms, 3)},
