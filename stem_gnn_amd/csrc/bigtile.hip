@@ -562,6 +562,10 @@ k_bt_cut_rows_ssq(const float* __restrict__ x, int64_t N, int H, int Dc, uint16_
 // A zero or non-finite row is not scaled; a bf16-stored stretch has lo = 0 exactly (its lo plane is never read).
 // One wave per row; `seg` = scaling stretch in columns (the whole row, or code_dim); out[plane][m][ld], plane 0 = hi;
 // inv_scale[(c / seg) * M + m]; ssq (optional) likewise: the stretch's sum of squares (the quantiser's row norms).
+// NV = float4 chunks a lane keeps in registers per stretch (stretch <= NV * 256 columns): the row is READ ONCE -- largest
+// magnitude, then the cut, from registers; NV = 0: any stretch length, two reads of the row (the second one misses the
+// L2 at these sizes: one third more traffic for a pass that is HBM-bound).
+template <int NV>
 __global__ void __launch_bounds__(kCutThreads)
 k_bt_cut_pair(const float* __restrict__ x1, int64_t ldx1, int K1, int64_t x1_rows, const void* __restrict__ x2, int x2_kind,
               int K2, int64_t M, int seg, uint16_t* __restrict__ out, int64_t ps, int64_t ld, float* __restrict__ inv_scale,
@@ -574,12 +578,41 @@ k_bt_cut_pair(const float* __restrict__ x1, int64_t ldx1, int K1, int64_t x1_row
     if (c < K1) return m < x1_rows ? ld4(x1 + m * ldx1 + c) : zero4();
     return ld4_kind(x2, m * static_cast<int64_t>(K2) + (c - K1), x2_kind);
   };
+  auto cut4 = [&](int c, float4 v, float sc) {
+    const float xs[4] = {v.x * sc, v.y * sc, v.z * sc, v.w * sc};
+    uint32_t hb[4], lb[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const _Float16 h = static_cast<_Float16>(xs[e]);
+      const _Float16 l = static_cast<_Float16>(xs[e] - static_cast<float>(h));
+      hb[e] = static_cast<uint32_t>(__builtin_bit_cast(uint16_t, h));
+      lb[e] = static_cast<uint32_t>(__builtin_bit_cast(uint16_t, l));
+    }
+    uint16_t* o = out + m * ld + c;
+    *reinterpret_cast<uint2*>(o) = make_uint2(hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16));
+    *reinterpret_cast<uint2*>(o + ps) = make_uint2(lb[0] | (lb[1] << 16), lb[2] | (lb[3] << 16));
+  };
   for (int s0 = 0, si = 0; s0 < K; s0 += seg, ++si) {
+    float4 keep[NV > 0 ? NV : 1];
     float mx = 0.f, sq = 0.f;
-    for (int c = s0 + 4 * lane; c < s0 + seg; c += 256) {
-      const float4 v = load4(c);
-      mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
-      sq += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    if (NV > 0) {
+#pragma unroll
+      for (int t = 0; t < NV; ++t) {
+        const int c = s0 + 4 * lane + 256 * t;
+        keep[t] = c < s0 + seg ? load4(c) : zero4();
+      }
+#pragma unroll
+      for (int t = 0; t < NV; ++t) {
+        const float4 v = keep[t];
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        sq += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+      }
+    } else {
+      for (int c = s0 + 4 * lane; c < s0 + seg; c += 256) {
+        const float4 v = load4(c);
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        sq += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+      }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
@@ -590,29 +623,41 @@ k_bt_cut_pair(const float* __restrict__ x1, int64_t ldx1, int K1, int64_t x1_row
       shift = shift > 110 ? 110 : (shift < -110 ? -110 : shift);
     }
     const float sc = ldexpf(1.f, shift);
-    if (lane == 0) {
-      inv_scale[static_cast<int64_t>(si) * M + m] = ldexpf(1.f, -shift);
-    }
+    if (lane == 0) inv_scale[static_cast<int64_t>(si) * M + m] = ldexpf(1.f, -shift);
     if (ssq) {
       sq = wave_sum(sq);
       if (lane == 0) ssq[static_cast<int64_t>(si) * M + m] = sq;
     }
-    for (int c = s0 + 4 * lane; c < s0 + seg; c += 256) {
-      const float4 v = load4(c);
-      const float xs[4] = {v.x * sc, v.y * sc, v.z * sc, v.w * sc};
-      uint32_t hb[4], lb[4];
+    if (NV > 0) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const _Float16 h = static_cast<_Float16>(xs[e]);
-        const _Float16 l = static_cast<_Float16>(xs[e] - static_cast<float>(h));
-        hb[e] = static_cast<uint32_t>(__builtin_bit_cast(uint16_t, h));
-        lb[e] = static_cast<uint32_t>(__builtin_bit_cast(uint16_t, l));
+      for (int t = 0; t < NV; ++t) {
+        const int c = s0 + 4 * lane + 256 * t;
+        if (c < s0 + seg) cut4(c, keep[t], sc);
       }
-      uint16_t* o = out + m * ld + c;
-      *reinterpret_cast<uint2*>(o) = make_uint2(hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16));
-      *reinterpret_cast<uint2*>(o + ps) = make_uint2(lb[0] | (lb[1] << 16), lb[2] | (lb[3] << 16));
+    } else {
+      for (int c = s0 + 4 * lane; c < s0 + seg; c += 256) cut4(c, load4(c), sc);
     }
   }
+}
+
+// launch with the smallest register-resident form that holds a stretch
+static int bt_cut_pair(hipStream_t st, const float* x1, int64_t ldx1, int K1, int64_t x1_rows, const void* x2, int x2_kind, int K2,
+                       int64_t M, int seg, uint16_t* out, int64_t ps, int64_t ld, float* inv_scale, float* ssq) {
+  const unsigned grid = static_cast<unsigned>((M + kCutThreads / 64 - 1) / (kCutThreads / 64));
+  const int nv = (seg + 255) / 256;
+#define BT_CUT_GO(NV) k_bt_cut_pair<NV><<<grid, kCutThreads, 0, st>>>(x1, ldx1, K1, x1_rows, x2, x2_kind, K2, M, seg, out, ps, ld, inv_scale, ssq)
+  if (nv <= 1) BT_CUT_GO(1);
+  else if (nv <= 2) BT_CUT_GO(2);
+  else if (nv <= 3) BT_CUT_GO(3);
+  else if (nv <= 4) BT_CUT_GO(4);
+  else if (nv <= 6) BT_CUT_GO(6);
+  else if (nv <= 8) BT_CUT_GO(8);
+  else if (nv <= 12) BT_CUT_GO(12);
+  else if (nv <= 16) BT_CUT_GO(16);
+  else BT_CUT_GO(0);
+#undef BT_CUT_GO
+  STEMGNN_LAUNCH_CHECK();
+  return STEMGNN_OK;
 }
 
 // Straight planes of x [M, C] (element kind `kind`) written for M_out >= M rows -- the rows behind the operand's last are
@@ -1064,11 +1109,7 @@ static int bt_planes(Lease& lease, const void* x, int kind, int64_t M, int64_t C
   if (np == 2) {  // pair format: two fp16 planes of the row-scaled operand + the factors that undo the scaling
     ps.inv_scale = lease.take<float>(static_cast<size_t>(M) * 4);
     if (!ps.p || !ps.inv_scale) return STEMGNN_ERR_WORKSPACE;
-    k_bt_cut_pair<<<static_cast<unsigned>((M + 3) / 4), kCutThreads, 0, st>>>(
-        kind == kF32 ? static_cast<const float*>(x) : nullptr, C, kind == kF32 ? static_cast<int>(C) : 0, M,
-        kind == kF32 ? nullptr : x, kind, kind == kF32 ? 0 : static_cast<int>(C), M, static_cast<int>(C), ps.p,
-        ps.rows_padded * C, C, ps.inv_scale, nullptr);
-    STEMGNN_LAUNCH_CHECK();
+    { const int rc_cut = bt_cut_pair(st, kind == kF32 ? static_cast<const float*>(x) : nullptr, C, kind == kF32 ? static_cast<int>(C) : 0, M, kind == kF32 ? nullptr : x, kind, kind == kF32 ? 0 : static_cast<int>(C), M, static_cast<int>(C), ps.p, ps.rows_padded * C, C, ps.inv_scale, nullptr); if (rc_cut != STEMGNN_OK) return rc_cut; }
     if (lease.a->depth > 0) lease.a->cache.push_back(ps);
     *out = ps;
     return STEMGNN_OK;
@@ -1104,13 +1145,8 @@ int bt_linear_fwd(int pieces, const float* x1, const float* w1, int64_t K1, cons
     float* xsc = lease.take<float>(static_cast<size_t>(M) * 4);
     float* wsc = lease.take<float>(static_cast<size_t>(N) * 4);
     if (!xpl || !wpl || !xsc || !wsc) return STEMGNN_ERR_WORKSPACE;
-    k_bt_cut_pair<<<static_cast<unsigned>((M + 3) / 4), kCutThreads, 0, st>>>(
-        x1, K1, static_cast<int>(K1), x1_rows, x2, x2_kind, static_cast<int>(K2), M, static_cast<int>(K), xpl, M * K, K, xsc,
-        nullptr);
-    STEMGNN_LAUNCH_CHECK();
-    k_bt_cut_pair<<<static_cast<unsigned>((N + 3) / 4), kCutThreads, 0, st>>>(
-        w1, K1, static_cast<int>(K1), N, w2, kF32, static_cast<int>(K2), N, static_cast<int>(K), wpl, N * K, K, wsc, nullptr);
-    STEMGNN_LAUNCH_CHECK();
+    { const int rc_cut = bt_cut_pair(st, x1, K1, static_cast<int>(K1), x1_rows, x2, x2_kind, static_cast<int>(K2), M, static_cast<int>(K), xpl, M * K, K, xsc, nullptr); if (rc_cut != STEMGNN_OK) return rc_cut; }
+    { const int rc_cut = bt_cut_pair(st, w1, K1, static_cast<int>(K1), N, w2, kF32, static_cast<int>(K2), N, static_cast<int>(K), wpl, N * K, K, wsc, nullptr); if (rc_cut != STEMGNN_OK) return rc_cut; }
     BtArgs g{};
     g.a = BtOp{wpl, N * K, K, N, 0};
     g.b = BtOp{xpl, M * K, K, M, 0};
@@ -1185,9 +1221,7 @@ int bt_linear_bwd_data(int pieces, const float* dy, const float* w, int64_t M, i
     if (!wt || !wpl || !wsc) return STEMGNN_ERR_WORKSPACE;
     rc = stemgnn_transpose(w, N, K, wt, st);
     if (rc != STEMGNN_OK) return rc;
-    k_bt_cut_pair<<<static_cast<unsigned>((K + 3) / 4), kCutThreads, 0, st>>>(wt, N, static_cast<int>(N), K, nullptr, kF32, 0,
-                                                                            K, static_cast<int>(N), wpl, K * N, N, wsc, nullptr);
-    STEMGNN_LAUNCH_CHECK();
+    { const int rc_cut = bt_cut_pair(st, wt, N, static_cast<int>(N), K, nullptr, kF32, 0, K, static_cast<int>(N), wpl, K * N, N, wsc, nullptr); if (rc_cut != STEMGNN_OK) return rc_cut; }
     BtArgs g{};
     g.a = BtOp{wpl, K * N, N, K, 0};
     g.b = BtOp{gp.p, gp.rows_padded * N, N, M, 0};
@@ -1314,12 +1348,8 @@ int bt_vq_assign(const float* xp, int64_t N, int64_t H, int64_t Dc, const float*
     // pair format (the reference forces fp32 in this product, vq.py:623,634: the pair product IS fp32-accurate): codes
     // scaled per code, rows per (row, head); the arg-max compares C[i][j] * scale(code i) -- the row's own factor is
     // positive and common to its candidates --, the candidate that leaves is the true similarity
-    k_bt_cut_pair<<<static_cast<unsigned>((H * K + 3) / 4), kCutThreads, 0, st>>>(
-        embed, Dc, static_cast<int>(Dc), H * K, nullptr, kF32, 0, H * K, static_cast<int>(Dc), epl, H * K * Dc, Dc, esc, nullptr);
-    STEMGNN_LAUNCH_CHECK();
-    k_bt_cut_pair<<<static_cast<unsigned>((N + 3) / 4), kCutThreads, 0, st>>>(
-        xp, HD, static_cast<int>(HD), N, nullptr, kF32, 0, N, static_cast<int>(Dc), xpl, N * HD, HD, xsc, ssq);
-    STEMGNN_LAUNCH_CHECK();
+    { const int rc_cut = bt_cut_pair(st, embed, Dc, static_cast<int>(Dc), H * K, nullptr, kF32, 0, H * K, static_cast<int>(Dc), epl, H * K * Dc, Dc, esc, nullptr); if (rc_cut != STEMGNN_OK) return rc_cut; }
+    { const int rc_cut = bt_cut_pair(st, xp, HD, static_cast<int>(HD), N, nullptr, kF32, 0, N, static_cast<int>(Dc), xpl, N * HD, HD, xsc, ssq); if (rc_cut != STEMGNN_OK) return rc_cut; }
     BtArgs g{};
     g.a = BtOp{epl, H * K * Dc, Dc, K, K * Dc};
     g.b = BtOp{xpl, N * HD, HD, N, Dc};
