@@ -464,6 +464,8 @@ def main():
     # one HIP event in front of every timed step and one behind the last, on the stream the step's kernels run on
     # (the library launches on torch's current stream): step_ms / step_ms_median beside the wall mean
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    for ev in marks:
+        ev.record()  # (an event object creates its hipEvent on first use: not inside the timed region)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
