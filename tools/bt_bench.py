@@ -33,10 +33,12 @@ def main():
     ap.add_argument("--rows", type=int, default=169343)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--modes", default="1,2")
+    ap.add_argument("--pair", type=int, default=1, help="exact mode: 1 = pair format (default), 0 = three bf16 pieces")
     args = ap.parse_args()
     from stem_gnn_amd import ops
     from stem_gnn_amd._lib import lib, check
     dev = torch.device("cuda:0")
+    ops.linear_set_pair(args.pair)
     M = args.rows
     torch.manual_seed(0)
     shapes = [("project_in 768->3072", 768, 0, 3072), ("layer 768+768->768", 768, 768, 768), ("lin 768->768", 768, 0, 768)]
