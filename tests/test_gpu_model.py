@@ -1286,6 +1286,64 @@ def test_bigtile_layer_product_with_bf16_stored_operand_zero_rows_and_row_limit(
                                    msg=lambda s_: f"{name} (core vs tile kernel): {s_}")
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
+def test_bigtile_core_random_shapes(dev, seed):
+    """Shapes the fixed cases do not reach, drawn per seed: feature extents that are multiples of 64 but NOT of the
+    256-wide tile (partial feature tiles on both sides: clamped reads, masked stores, masked statistics), odd numbers of
+    K tiles, row counts with ragged last tiles, a zero-leading-rows boundary anywhere, a random row limit on the output;
+    exact mode (pair format for forward / backward-data, bf16 pieces for the weight gradient) and bf16 mode; against fp64
+    and against the tile kernels."""
+    from stem_gnn_amd import ops
+    from stem_gnn_amd._lib import lib, check
+    g = torch.Generator().manual_seed(1000 + seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))  # noqa: E731
+    n, k1 = 64 * ri(4, 14), 64 * ri(4, 10)
+    k2 = 64 * ri(0, 6) if seed % 2 else 0
+    m = max(int(1.05e10 / (2.0 * n * min(n, k1 + k2, k1))) + ri(1, 200), 8192 + ri(0, 300))
+    rows = ri(0, m) if k2 else -1
+    keep = ri(1, m)
+    mode = 1 if seed % 3 else 2
+    torch.manual_seed(seed)
+    a = torch.randn(m, k1, device=dev)
+    w = torch.randn(n, k1, device=dev) * 0.1
+    a2 = torch.randn(m, k2, device=dev) if k2 else None
+    w2 = torch.randn(n, k2, device=dev) * 0.1 if k2 else None
+    b = torch.randn(n, device=dev)
+    if rows >= 0:
+        a[rows:] = 0
+    dy = torch.randn(m, n, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    blocks = int(lib.stemgnn_linear_stats_blocks(m, n))
+    prev = ops.linear_set_mode(mode)
+    out = {}
+    try:
+        ops.linear_scratch(m, k1 + k2, n)
+        for core_on in (1, 0):
+            was = ops.linear_set_bigtile(core_on)
+            served = lib.stemgnn_linear_bigtile_calls()
+            y = torch.full((keep, n), float("nan"), device=dev)
+            part = torch.zeros(blocks, 2, n, device=dev)
+            check(lib.stemgnn_linear_fwd_rows_k(a.data_ptr(), w.data_ptr(), k1, None if a2 is None else a2.data_ptr(), 0,
+                                                None if w2 is None else w2.data_ptr(), k2, b.data_ptr(), m, n, y.data_ptr(),
+                                                part.data_ptr(), None, rows, keep, st))
+            dx = ops.linear_bwd_data(dy, w)
+            dw, db = ops.linear_bwd_weight(dy, a, True)
+            assert (lib.stemgnn_linear_bigtile_calls() - served) == (3 if core_on else 0), (m, n, k1, k2)
+            out[core_on] = (y, part.double().sum(0), dx, dw, db)
+            ops.linear_set_bigtile(was)
+    finally:
+        ops.linear_set_mode(prev)
+    r = (lambda t: t.bfloat16().double()) if mode == 2 else (lambda t: t.double())
+    ref = r(a) @ r(w).t() + (r(a2) @ r(w2).t() if k2 else 0) + b.double()
+    want = (ref[:keep], torch.stack([ref.sum(0), (ref * ref).sum(0)]), r(dy) @ r(w), r(dy).t() @ r(a), dy.double().sum(0))
+    for name, got_core, got_tile, w_ in zip(("y", "column sums", "dx", "dw", "db"), out[1], out[0], want):
+        tol = 2e-5 * float(w_.abs().max())
+        torch.testing.assert_close(got_core.double(), w_, rtol=1e-5, atol=tol,
+                                   msg=lambda s_: f"{name} (core, m={m} n={n} k={k1}+{k2} rows={rows} keep={keep} mode={mode}): {s_}")
+        torch.testing.assert_close(got_core.double(), got_tile.double(), rtol=1e-5, atol=tol,
+                                   msg=lambda s_: f"{name} (core vs tile kernel): {s_}")
+
+
 def test_bigtile_core_without_an_arena_is_a_counted_fallback_and_allocates_nothing(dev):
     """The boundary's rule (entry points never allocate or synchronise) for the big-tile core: its
     scratch is the caller's arena.  Without one a qualifying product runs on the tile kernels and the miss is COUNTED
