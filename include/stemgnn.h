@@ -442,10 +442,15 @@ int stemgnn_set_deterministic(int on);
 int stemgnn_linear_few_rows(const float* x, const float* w, const float* bias, int64_t num_rows, int64_t out_dim,
                             int64_t in_dim, float* y, int32_t weight_is_kn, void* stream);
 
-/* The weight-stationary kernel (csrc/wsgemm.hip) takes the products with one 128-column operand and at least
- * `min_tiles` 128-row tiles (default 128; 0 = never: every product on the tile kernel).  Negative: query only.
- * Returns the previous value.  Both kernels return the same bits; the switch exists for A/B runs and tests. */
+/* The weight-stationary kernels take the products with one 128-column operand and at least `min_tiles` 128-row tiles
+ * (default 128; 0 = never: every product on the tile kernel).  Negative: query only.  Returns the previous value.
+ * With stemgnn_linear_set_pair(1) (the default) that is csrc/wspair.hip: operands in the pair format (two fp16 pieces
+ * of a row scaled by a power of two, three matrix passes, fp32-accurate), which also takes a sampled batch's two-operand
+ * layer product (x1_rows < num_rows: the leading rows' aggregate is multiplied in the blocks' prologues);
+ * stemgnn_linear_wsp_calls counts its launches.  With stemgnn_linear_set_pair(0): csrc/wsgemm.hip, three exact bf16
+ * pieces and six passes -- the same bits as the tile kernel; the switches exist for A/B runs and tests. */
 int stemgnn_linear_set_ws(int min_tiles);
+int64_t stemgnn_linear_wsp_calls(void);
 int64_t stemgnn_linear_stats_blocks(int64_t num_rows, int64_t out_dim);
 int stemgnn_linear_fwd(const float* x1, const float* w1, int64_t k1, const float* x2, const float* w2, int64_t k2,
                        const float* bias, int64_t num_rows, int64_t out_dim, float* y, float* stats_partial,

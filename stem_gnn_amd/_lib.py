@@ -147,6 +147,7 @@ _SIGNATURES = {
     "stemgnn_linear_stats_partial_bytes": (c_size_t, [I64, I64]),
     "stemgnn_linear_stats_blocks": (I64, [I64, I64]),
     "stemgnn_linear_set_ws": (I32, [I32]),
+    "stemgnn_linear_wsp_calls": (I64, []),
     "stemgnn_sample_edges2": (c_int, [P, P, I64, c_uint64, I64, c_uint64, P, P, I64, P, I64, c_uint64, P, P, I64, P, P]),
     "stemgnn_edge_concat_gather": (c_int, [P, I64, I64, P, I64, P, P, I64, P, P, P]),
     "stemgnn_edge_concat_bwd_add": (c_int, [P, I64, I64, P, I64, P, P, P, I64, P]),

@@ -13,7 +13,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libstemgnn_hip.so")
-SOURCES = ["graph_build.hip", "sage_agg.hip", "bn_act.hip", "vq.hip", "edge_ops.hip", "linear.hip", "graph_aug.hip", "sampler.hip", "loss_ops.hip", "optim_ops.hip", "phases.hip", "heads.hip", "wsgemm.hip", "bigtile.hip"]
+SOURCES = ["graph_build.hip", "sage_agg.hip", "bn_act.hip", "vq.hip", "edge_ops.hip", "linear.hip", "graph_aug.hip", "sampler.hip", "loss_ops.hip", "optim_ops.hip", "phases.hip", "heads.hip", "wsgemm.hip", "wspair.hip", "bigtile.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-fno-gpu-rdc", "-munsafe-fp-atomics"]

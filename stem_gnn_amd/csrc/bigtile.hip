@@ -1039,7 +1039,12 @@ inline void exact_segments(BtArgs& g, int pieces, int kt_all, int kt_b_lo /*K ti
 }
 
 std::atomic<int> g_bt_on{1};
-std::atomic<int> g_bt_pair{1};  // exact mode: forward / backward-data / code assignment from two fp16 pieces (0: three bf16 pieces)
+// exact mode: forward / backward-data / code assignment from two fp16 pieces (0: three bf16 pieces); STEMGNN_LINEAR_PAIR=0
+// in the environment starts a process with the bf16 pieces (same-box A/B runs of the bench)
+std::atomic<int> g_bt_pair{[] {
+  const char* e = std::getenv("STEMGNN_LINEAR_PAIR");
+  return (e && e[0] == '0') ? 0 : 1;
+}()};
 std::atomic<int64_t> g_bt_calls{0}, g_bt_fallbacks{0};
 
 }  // namespace
@@ -1054,6 +1059,7 @@ bool bt_gemm_ok(int64_t M, int64_t N, int64_t K) {
 void bt_served() { g_bt_calls.fetch_add(1, std::memory_order_relaxed); }
 void bt_missed() { g_bt_fallbacks.fetch_add(1, std::memory_order_relaxed); }
 
+bool linear_pair_on() { return g_bt_pair.load(std::memory_order_relaxed) != 0; }
 static inline int np_of(int pieces) { return pieces == 1 ? 1 : 3; }
 static inline bool use_pair(int pieces) { return pieces == 3 && g_bt_pair.load(std::memory_order_relaxed) != 0; }
 // the pair format's three products, small terms first: (lo, hi), (hi, lo), (hi, hi); plane 0 = hi, 1 = lo

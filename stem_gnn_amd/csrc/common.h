@@ -105,6 +105,32 @@ __device__ __forceinline__ void split8(float4 a, float4 b, uint4& h, uint4& m, u
   m = make_uint4(m0.x, m0.y, m1.x, m1.y);
   l = make_uint4(l0.x, l0.y, l1.x, l1.y);
 }
+// ---- the pair format (csrc/bigtile.hip, csrc/wspair.hip): the power of two that puts a row's largest magnitude `mx`
+// into [2^14, 2^15) and its inverse; a zero or non-finite row is not scaled
+__device__ __forceinline__ void pair_scale(float mx, float& sc, float& inv) {
+  int shift = 0;
+  if (mx > 0.f && mx <= 3.0e38f) {
+    shift = 14 - ilogbf(mx);
+    shift = shift > 110 ? 110 : (shift < -110 ? -110 : shift);
+  }
+  sc = ldexpf(1.f, shift);
+  inv = ldexpf(1.f, -shift);
+}
+// four values times `sc` -> hi = fp16(x sc) (round to nearest), lo = fp16(x sc - hi) (the remainder is exact in fp32)
+__device__ __forceinline__ void pair_cut4(float4 v, float sc, uint2& h, uint2& l) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  const f2 a = {v.x * sc, v.y * sc}, b = {v.z * sc, v.w * sc};
+  const h2 ha = __builtin_convertvector(a, h2), hb = __builtin_convertvector(b, h2);
+  const h2 la = __builtin_convertvector(a - __builtin_convertvector(ha, f2), h2);
+  const h2 lb = __builtin_convertvector(b - __builtin_convertvector(hb, f2), h2);
+  h = make_uint2(__builtin_bit_cast(uint32_t, ha), __builtin_bit_cast(uint32_t, hb));
+  l = make_uint2(__builtin_bit_cast(uint32_t, la), __builtin_bit_cast(uint32_t, lb));
+}
+__device__ __forceinline__ float max_abs4(float m, float4 v) {
+  return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+}
+
 // q[i] = columns c .. c+3 of contraction row 4 (tid & 7) + i (c = 4 (tid >> 3)): split every element and store column j
 // as the 4 consecutive contraction steps of plane row c + j, i.e. the transposed image [column][32 k] the fragment
 // reads want, for an operand whose contraction index is its SLOW dimension.
@@ -213,6 +239,16 @@ bool bt_vq_assign_ok(int64_t N, int64_t H, int64_t Dc, int64_t K);
 int bt_vq_assign(const float* xp, int64_t N, int64_t H, int64_t Dc, const float* embed, const float* esq, int64_t K,
                  int training, float* xn, float* norm, int64_t* ind, float* quant, float* sqerr, double sq_scale,
                  hipStream_t st);
+
+// csrc/wspair.hip: the weight-stationary product in the PAIR format (two fp16 pieces per operand row scaled by a power of
+// two, three matrix passes instead of six; csrc/bigtile.hip describes the format): rows row_base.. of  y = x w^T + b
+// (K == 128; bt: y = x w with w given as [K][N]), optionally  + x1 w1^T  on the leading x1_rows rows (a sampled batch's
+// layer product: only the leading, expanded nodes carry an aggregate).  stats_partial as linear_ws_launch.
+bool linear_pair_on();  // stemgnn_linear_set_pair
+bool linear_wsp_ok(int64_t M, int64_t N, int64_t K, int64_t x1_rows);
+int linear_wsp_launch(const float* x, const float* w, const float* bias, int64_t M, int64_t N, float* y,
+                      float* stats_partial, int64_t stats_block0, int64_t store_rows, bool bt, const float* x1,
+                      const float* w1, int64_t x1_rows, hipStream_t st);
 
 // csrc/wsgemm.hip: the weight-stationary dense product (K == 128): rows row_base.. of  y = x w^T + b  (bt: y = x w with w
 // given as [K][N]); stats_partial[stats_block0 + tile][2][N] takes the column sums / sums of squares per 128-row tile

@@ -1393,8 +1393,17 @@ int stemgnn_linear_fwd_rows_k(const float* x1, const float* w1, int64_t K1, cons
     const float *xs = nullptr, *wsrc = nullptr;
     if (K2 == 0 && K1 == 128 && x1r >= M) { xs = x1; wsrc = w1; }
     else if (K2 == 128 && x1r == 0) { xs = x2; wsrc = w2; }  // no row carries the first operand
+    // pair format (csrc/wspair.hip): three matrix passes instead of six, and the sampled batch's two-operand layer product
+    // too (the leading rows' aggregate is multiplied in the blocks' prologues)
+    const float *xh = nullptr, *wh = nullptr;
+    int64_t hr = 0;
+    const bool pair = linear_pair_on();
+    if (pair && !xs && K1 == 128 && K2 == 128 && x1r > 0 && x1r < M && linear_wsp_ok(M, N, 128, x1r)) {
+      xs = x2; wsrc = w2; xh = x1; wh = w1; hr = x1r;
+    }
     if (xs && tiles >= kWsMinTiles) {
-      const int rc = linear_ws_launch(xs, wsrc, bias, M, N, 128, y, stats_partial, 0, 0, sr, false, st);
+      const int rc = pair ? linear_wsp_launch(xs, wsrc, bias, M, N, y, stats_partial, 0, sr, false, xh, wh, hr, st)
+                          : linear_ws_launch(xs, wsrc, bias, M, N, 128, y, stats_partial, 0, 0, sr, false, st);
       if (rc != STEMGNN_OK) return rc;
       // what callers reduce over (stemgnn_linear_stats_blocks): the slabs past the 64-row tiles written here are zero
       const int64_t count = 2 * plan.main_tiles + plan.tail_tiles, written = (M + 63) / 64;
@@ -1437,7 +1446,8 @@ int stemgnn_linear_bwd_data(const float* dy, const float* w, int64_t M, int64_t 
   const int kc = static_cast<int>(N), n = static_cast<int>(K);
   const bool x3 = gemm_x3();
   if (x3 && ws_enabled() && N == 128 && K % kBN == 0 && (M + kBM - 1) / kBM >= kWsMinTiles)
-    return linear_ws_launch(dy, w, nullptr, M, K, 128, dx, nullptr, 0, 0, M, true, st);
+    return linear_pair_on() ? linear_wsp_launch(dy, w, nullptr, M, K, dx, nullptr, 0, M, true, nullptr, nullptr, 0, st)
+                            : linear_ws_launch(dy, w, nullptr, M, K, 128, dx, nullptr, 0, 0, M, true, st);
   const int mode = gemm_mode();
   if (bigtile(M, K, N)) STEMGNN_TRY_BIGTILE(bt_linear_bwd_data(bigtile_pieces(), dy, w, M, N, K, dx, st));
   if (plan.main_tiles > 0) {

@@ -1,0 +1,397 @@
+// Weight-stationary dense product in the PAIR format:  Y = X W^T + b  (and  dX = dY W)  for K = 128 contraction columns,
+// optionally  + X1 W1^T  on the leading rows -- the products of the D = 128 configurations (reference
+// model/encoder.py:62-70 lin_l / lin_r, model/pt_model.py decoders, vq.py project_in / project_out).
+//
+// csrc/wsgemm.hip runs these products from three exact bf16 pieces per operand: six matrix passes, and a cut that costs
+// more VALU instructions than the passes cost matrix cycles (round-4 counters: 3.5 - 9 VALU instructions per MFMA; the
+// matrix pipe 36 - 59 % busy; an HBM-bound shape running at a third of the HBM rate).  The pair format of
+// csrc/bigtile.hip -- hi = fp16(x s), lo = fp16(x s - hi) with s the power of two that puts the ROW's largest magnitude
+// at the top of fp16's range, a b = lo_a hi_b + hi_a lo_b + hi_a hi_b, fp32-accurate -- needs the row's largest magnitude
+// before its first element is cut.  With K = 128 a 64-row tile is 32 KB: a block holds the WHOLE tile in registers
+// (8 float4 per thread), so the maximum is a register reduction plus three cross-lane steps, and the tile is cut in one
+// go into LDS planes [64 rows][128 k] x {hi, lo}.  Per tile:
+//     wait for the tile's loads -> row maxima, cut -> barrier -> issue the next tile's loads (a whole tile per block, two
+//     blocks per CU: 64 KB in flight per CU while this one is multiplied and stored) -> 48 matrix instructions per wave
+//     from LDS fragments against the block's 128 weight columns held in registers as ready-made fragments (cut once
+//     per block, scaled per weight row) -> accumulators x (row factor x column factor) + bias through an LDS staging
+//     tile -> barrier -> 512-byte rows out, column sums for BatchNorm.
+// Two barriers per tile (the bf16-piece kernel: five), three passes instead of six, half the cut arithmetic.
+//
+// A sampled batch's layer product lin_l(agg) + lin_r(h) carries its first operand on the leading rows only (the nodes
+// that receive edges: a ninth of the batch at C4).  Those tiles are at most one per block and come first in a block's
+// walk: the block multiplies the aggregate's tile with lin_l's fragments in a prologue (own row factors), leaves the
+// scaled result in the staging tile and adds it in that tile's epilogue; lin_l's 64 registers are dead before lin_r's
+// are loaded.
+#include "common.h"
+
+#include <atomic>
+#include <cstdlib>
+
+namespace stemgnn {
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kPT = 256;                        // threads: four waves, wave w = columns 32 w .. of the block's 128
+constexpr int kPM = 64, kPN = 128, kPK = 128;   // tile rows, block columns, contraction columns
+constexpr int kPRow = 2 * kPK + 16;             // bytes per plane row: 68 dwords, conflict-free b128 fragment reads
+constexpr int kPPlane = kPM * kPRow;
+constexpr int kPLdT = kPN + 4;                  // fp32 row stride of the staging tile
+constexpr size_t kPPlanesBytes = 2 * static_cast<size_t>(kPPlane);
+constexpr size_t kPStageBytes = static_cast<size_t>(kPM) * kPLdT * sizeof(float);
+constexpr size_t kPStatsBytes = 2 * kPN * sizeof(float);
+constexpr size_t kPInvBytes = kPM * sizeof(float);
+constexpr size_t kPLdsBytes = kPPlanesBytes + kPStageBytes + kPStatsBytes + kPInvBytes;  // 69 888: two blocks per CU
+
+// rows of every group of eight in the order 0 4 1 5 2 6 3 7: the two rows one 16-lane ds_write_b64 group covers are
+// four rows apart (16 dwords of bank offset at this row stride: no overlap), csrc/linear.hip
+__device__ __forceinline__ int stage_row(int idx) {
+  const int r = idx >> 3;
+  return (r & ~7) | ((r & 1) << 2) | ((r >> 1) & 3);
+}
+
+template <int V> struct IntTag { static constexpr int value = V; };
+
+std::atomic<int64_t> g_wsp_calls{0};
+
+// The block's weight columns as matrix-core fragments: lane (lj, hi) holds column n, contraction steps
+// 16 ks + 8 hi .. + 7 of every 16-wide step -- the lane pair (hi = 0, 1) holds the whole weight row, whose largest
+// magnitude scales it.  Returns the inverse factor.  BT: the weight is [K][N] (column n read with stride N).
+template <bool BT>
+__device__ __forceinline__ float weight_fragments(const float* __restrict__ w, int N, int n, int hi, f16x8 (&bw)[8][2]) {
+  float4 q[16];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    const int k = 16 * ks + 8 * hi;
+    if (BT) {
+      const float* p = w + static_cast<int64_t>(k) * N + n;
+      const int64_t ld = N;
+      q[2 * ks] = make_float4(p[0], p[ld], p[2 * ld], p[3 * ld]);
+      q[2 * ks + 1] = make_float4(p[4 * ld], p[5 * ld], p[6 * ld], p[7 * ld]);
+    } else {
+      q[2 * ks] = ld4(w + static_cast<int64_t>(n) * kPK + k);
+      q[2 * ks + 1] = ld4(w + static_cast<int64_t>(n) * kPK + k + 4);
+    }
+  }
+  float mx = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) mx = max_abs4(mx, q[i]);
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float sc, inv;
+  pair_scale(mx, sc, inv);
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    uint2 h0, l0, h1, l1;
+    pair_cut4(q[2 * ks], sc, h0, l0);
+    pair_cut4(q[2 * ks + 1], sc, h1, l1);
+    bw[ks][0] = __builtin_bit_cast(f16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
+    bw[ks][1] = __builtin_bit_cast(f16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
+  }
+  return inv;
+}
+
+// STATS: per 64-row tile column sums / sums of squares of y (BatchNorm).  BT: weight given as [K][N].  HEAD: the leading
+// x1_rows rows also carry x1 w1^T (at most one such tile per block: the host checks).  N is a multiple of 128.
+// Loads and stores of the steady-state loop are unconditional (clamped rows), as in csrc/wsgemm.hip: the compiler can then
+// wait for "the tile fetched a tile ago" while the previous tile's stores stay in flight.
+template <bool STATS, bool BT, bool HEAD, bool DBG = false>
+__global__ void __launch_bounds__(kPT, 2)
+k_linear_wsp(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, int64_t M, int N,
+             float* __restrict__ y, float* __restrict__ stats_partial /*[64-row tiles][2][N]*/, int64_t stats_block0,
+             int64_t store_rows, const float* __restrict__ x1, const float* __restrict__ w1, int64_t x1_rows, int dbg) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const planes = smem;
+  float* const tile = reinterpret_cast<float*>(smem + kPPlanesBytes);
+  float* const s_stats = reinterpret_cast<float*>(smem + kPPlanesBytes + kPStageBytes);  // [sum|sumsq][128]
+  float* const s_inv = reinterpret_cast<float*>(smem + kPPlanesBytes + kPStageBytes + kPStatsBytes);  // [64] row factors
+
+  const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+  const int hi = lane >> 5, lj = lane & 31;
+  const int n0 = blockIdx.y * kPN, nl = 32 * wn + lj;
+  const int64_t row_end = store_rows < M ? store_rows : M;
+  const int64_t tiles = ((STATS ? M : row_end) + kPM - 1) / kPM;  // without statistics nothing past the stored rows is wanted
+
+  int64_t t = blockIdx.x;
+  if (t >= tiles) return;  // whole block
+  const int64_t stride = gridDim.x;
+
+  float4 ra[4][2];  // the tile: chunk s (32 columns), rows r0 / r1, columns 32 s + c4s .. + 3
+  const int r0 = stage_row(tid), r1 = stage_row(kPT + tid), c4s = 4 * (tid & 7);
+  auto fetch = [&](const float* __restrict__ src, int64_t tt, int64_t rows) {
+    const int64_t m0 = (tt < tiles ? tt : tiles - 1) * kPM;  // past the last tile: a harmless re-read
+    const int64_t ma = m0 + r0 < rows ? m0 + r0 : rows - 1, mb = m0 + r1 < rows ? m0 + r1 : rows - 1;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      ra[s][0] = ld4(src + ma * kPK + 32 * s + c4s);
+      ra[s][1] = ld4(src + mb * kPK + 32 * s + c4s);
+    }
+  };
+  // row maxima (8 lanes share a row), factors, the two planes of the whole tile; rows >= live count as zero
+  auto cut_tile = [&](int64_t m0, int64_t live) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = i ? r1 : r0;
+      if (HEAD && m0 + r >= live) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) ra[s][i] = zero4();
+      }
+      float mx = 0.f;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) mx = max_abs4(mx, ra[s][i]);
+      mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 4, 64));
+      float sc, inv;
+      pair_scale(mx, sc, inv);
+      if ((tid & 7) == 0) s_inv[r] = inv;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        uint2 h, l;
+        pair_cut4(ra[s][i], sc, h, l);
+        unsigned char* const o = planes + r * kPRow + 2 * (32 * s + c4s);
+        *reinterpret_cast<uint2*>(o) = h;
+        *reinterpret_cast<uint2*>(o + kPPlane) = l;
+      }
+    }
+  };
+  // fragments of k step ks + 1 are requested before the six matrix instructions of step ks are issued (an LDS round trip
+  // is about as long as those take); nothing crosses a step's end, so the requests stay one step ahead
+  auto multiply = [&](const f16x8 (&bf)[8][2], floatx16 (&acc)[2]) {
+    f16x8 a[2][2][2];  // [step parity][tm][plane]
+    auto request = [&](int ks) {
+      const int ko = 32 * ks + 16 * hi;  // bytes: lane half 0 takes k 0..7, half 1 k 8..15 of the 16-wide step
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+          a[ks & 1][tm][p] = *reinterpret_cast<const f16x8*>(planes + p * kPPlane + (tm * 32 + lj) * kPRow + ko);
+    };
+    request(0);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      if (ks + 1 < 8) request(ks + 1);
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm) {  // small terms first
+        acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks & 1][tm][1], bf[ks][0], acc[tm], 0, 0, 0);
+        acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks & 1][tm][0], bf[ks][1], acc[tm], 0, 0, 0);
+        acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks & 1][tm][0], bf[ks][0], acc[tm], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // this lane's 32 row factors: rows tm * 32 + 4 hi + (r & 3) + 8 (r >> 2), four consecutive rows per read
+  auto row_factors = [&](float (&f)[2][16]) {
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 v = ld4(s_inv + tm * 32 + 4 * hi + 8 * j);
+        f[tm][4 * j] = v.x; f[tm][4 * j + 1] = v.y; f[tm][4 * j + 2] = v.z; f[tm][4 * j + 3] = v.w;
+      }
+  };
+
+  // ---- the leading tile of a sampled batch: x1 w1^T into the staging tile (each lane keeps its own 32 entries there)
+  bool head_pending = false;
+  if (HEAD) {
+    const int64_t m0 = t * kPM;
+    if (m0 < x1_rows) {  // block-uniform
+      fetch(x1, t, x1_rows);  // the buffer may end at x1_rows: clamped reads, zeroed in the cut; requested BEFORE the
+      __builtin_amdgcn_sched_barrier(0);  // weight's loads: one memory latency for both
+      f16x8 bl[8][2];
+      const float inv_l = weight_fragments<false>(w1, N, n0 + nl, hi, bl);
+      cut_tile(m0, x1_rows);
+      __syncthreads();
+      floatx16 acc[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+      multiply(bl, acc);
+      float rf[2][16];
+      row_factors(rf);
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          tile[(tm * 32 + 4 * hi + (r & 3) + 8 * (r >> 2)) * kPLdT + nl] = acc[tm][r] * (rf[tm][r] * inv_l);
+      head_pending = true;
+      __syncthreads();  // the planes and the row factors are free again
+    }
+  }
+
+  fetch(x, t, M);  // the first tile's rows travel while the weight is loaded and cut
+  __builtin_amdgcn_sched_barrier(0);
+  f16x8 bw[8][2];
+  const float inv_w = weight_fragments<BT>(w, N, n0 + nl, hi, bw);
+  const float bias_v = bias != nullptr ? bias[n0 + nl] : 0.f;
+
+  // CLS 0: every row of the tile is stored; 1: none is (statistics only); 2: the boundary tile (predicated stores)
+  auto do_tile = [&](auto cls) {
+    constexpr int CLS = decltype(cls)::value;
+    const int64_t m0 = t * kPM;
+    if (!DBG || !(dbg & 2)) cut_tile(m0, M + kPM);  // (rows past M are copies of row M - 1: never stored nor counted)
+    __syncthreads();
+    if (!DBG || !(dbg & 8)) fetch(x, t + stride, M);  // a whole iteration ahead of its use: pinned here (the scheduler would sink the loads
+    __builtin_amdgcn_sched_barrier(0);  // behind the matrix work to save their registers)
+    floatx16 acc[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+    if (!DBG || !(dbg & 1)) multiply(bw, acc);
+    if (DBG && (dbg & 4)) {  // no epilogue: keep the accumulators alive
+      if (acc[0][0] + acc[1][5] == 123.456f) y[tid] = acc[0][0];
+      return;
+    }
+
+    // ---- epilogue: factors, bias (+ the leading operand's part), through the staging tile, out as 512-byte rows
+    float rf[2][16];
+    row_factors(rf);
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rs = tm * 32 + 4 * hi + (r & 3) + 8 * (r >> 2);
+        float v = acc[tm][r] * (rf[tm][r] * inv_w) + bias_v;
+        if (HEAD && head_pending) v += tile[rs * kPLdT + nl];
+        if (CLS != 1) tile[rs * kPLdT + nl] = v;
+        acc[tm][r] = v;
+      }
+    if (HEAD) head_pending = false;
+    if (STATS) {
+      float s1 = 0.f, s2 = 0.f;
+      if (m0 + kPM <= M) {  // block-uniform: every tile but the last
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { s1 += acc[tm][r]; s2 += acc[tm][r] * acc[tm][r]; }
+      } else {
+        const int live = static_cast<int>(M - m0) - 4 * hi;  // rows of this lane's sequence below M
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (tm * 32 + (r & 3) + 8 * (r >> 2) < live) { s1 += acc[tm][r]; s2 += acc[tm][r] * acc[tm][r]; }
+      }
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (hi == 0) { s_stats[nl] = s1; s_stats[kPN + nl] = s2; }
+    }
+    __syncthreads();
+    if (CLS != 1) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int rl = (tid >> 5) + 8 * i, c4 = tid & 31;
+        const int64_t m = m0 + rl;
+        if (CLS == 0 || m < row_end) st4(y + m * N + n0 + 4 * c4, ld4(tile + rl * kPLdT + 4 * c4));
+      }
+    }
+    if (STATS)  // 256 values per tile, one per thread
+      stats_partial[(stats_block0 + t) * 2 * N + static_cast<int64_t>(tid >> 7) * N + n0 + (tid & 127)] = s_stats[tid];
+  };
+
+  // Every loop is entered through a peeled first tile of its class only: at a loop header the compiler merges the wait
+  // counts of all entering paths to the smallest, and a path with fewer operations in flight (the prologue: loads, no
+  // stores) would make every iteration wait for the previous tile's stores before it cuts the next one.
+  auto full = [&]() { return t < tiles && (t + 1) * kPM <= row_end; };
+  if (full()) {
+    do_tile(IntTag<0>{});
+    t += stride;
+    while (full()) {
+      do_tile(IntTag<0>{});
+      t += stride;
+    }
+  }
+  if (t < tiles && t * kPM < row_end) {  // the boundary tile
+    do_tile(IntTag<2>{});
+    t += stride;
+  }
+  if (STATS && t < tiles) {
+    do_tile(IntTag<1>{});
+    t += stride;
+    while (t < tiles) {
+      do_tile(IntTag<1>{});
+      t += stride;
+    }
+  }
+}
+
+template <bool STATS, bool BT, bool HEAD>
+int launch_wsp(const float* x, const float* w, const float* bias, int64_t M, int N, float* y, float* stats_partial,
+               int64_t stats_block0, int64_t store_rows, const float* x1, const float* w1, int64_t x1_rows, int64_t gx,
+               hipStream_t st) {
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_linear_wsp<STATS, BT, HEAD>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     static_cast<int>(kPLdsBytes));
+  if (attr != hipSuccess) return STEMGNN_ERR_HIP;
+  dim3 grid(static_cast<unsigned>(gx), static_cast<unsigned>(N / kPN));
+  k_linear_wsp<STATS, BT, HEAD><<<grid, kPT, kPLdsBytes, st>>>(x, w, bias, M, N, y, stats_partial, stats_block0, store_rows,
+                                                              x1, w1, x1_rows, 0);
+  STEMGNN_LAUNCH_CHECK();
+  return STEMGNN_OK;
+}
+
+inline int64_t wsp_blocks(int64_t N) {
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1)
+      n = 256;
+    return n;
+  }();
+  const int64_t gx = 2 * cus / (N / kPN);  // two resident blocks per CU
+  return gx < 1 ? 1 : gx;
+}
+
+}  // namespace
+
+// x1_rows > 0: the leading-operand form -- its tiles must be the first of their blocks' walks
+bool linear_wsp_ok(int64_t M, int64_t N, int64_t K, int64_t x1_rows) {
+  if (K != kPK || N % kPN != 0 || N <= 0 || M <= 0) return false;
+  if (x1_rows <= 0) return true;
+  const int64_t tiles = (M + kPM - 1) / kPM;
+  const int64_t gx = wsp_blocks(N) < tiles ? wsp_blocks(N) : tiles;
+  return (x1_rows + kPM - 1) / kPM <= gx;
+}
+
+int linear_wsp_launch(const float* x, const float* w, const float* bias, int64_t M, int64_t N, float* y,
+                      float* stats_partial, int64_t stats_block0, int64_t store_rows, bool bt, const float* x1,
+                      const float* w1, int64_t x1_rows, hipStream_t st) {
+  const bool head = x1_rows > 0 && x1 != nullptr && w1 != nullptr;
+  if (!linear_wsp_ok(M, N, kPK, head ? x1_rows : 0) || (bt && (head || stats_partial))) return STEMGNN_ERR_INVALID_ARG;
+  const int n = static_cast<int>(N);
+  const int64_t row_end = store_rows < M ? store_rows : M;
+  const int64_t tiles = ((stats_partial ? M : row_end) + kPM - 1) / kPM;  // as in the kernel
+  if (tiles <= 0) return STEMGNN_OK;
+  g_wsp_calls.fetch_add(1, std::memory_order_relaxed);
+  int64_t gx = wsp_blocks(N);
+  if (gx > tiles) gx = tiles;
+  {  // head tiles that exist in this launch (rows past store_rows are not walked without statistics): one per block
+    const int64_t head_tiles = head ? (x1_rows + kPM - 1) / kPM : 0;
+    if ((head_tiles < tiles ? head_tiles : tiles) > gx) return STEMGNN_ERR_INVALID_ARG;
+  }
+  if (bt) {
+    static const int dbg = std::getenv("STEMGNN_WSP_DBG") ? std::atoi(std::getenv("STEMGNN_WSP_DBG")) : 0;
+    if (dbg) {
+      static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_linear_wsp<false, true, false, true>),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kPLdsBytes));
+      (void)attr;
+      dim3 grid(static_cast<unsigned>(gx), static_cast<unsigned>(N / kPN));
+      k_linear_wsp<false, true, false, true><<<grid, kPT, kPLdsBytes, st>>>(x, w, bias, M, n, y, nullptr, 0, store_rows, nullptr, nullptr, 0, dbg);
+      return STEMGNN_OK;
+    }
+    return launch_wsp<false, true, false>(x, w, bias, M, n, y, nullptr, 0, store_rows, nullptr, nullptr, 0, gx, st);
+  }
+  if (head) {
+    if (stats_partial)
+      return launch_wsp<true, false, true>(x, w, bias, M, n, y, stats_partial, stats_block0, store_rows, x1, w1, x1_rows, gx, st);
+    return launch_wsp<false, false, true>(x, w, bias, M, n, y, nullptr, 0, store_rows, x1, w1, x1_rows, gx, st);
+  }
+  if (stats_partial)
+    return launch_wsp<true, false, false>(x, w, bias, M, n, y, stats_partial, stats_block0, store_rows, nullptr, nullptr, 0, gx, st);
+  return launch_wsp<false, false, false>(x, w, bias, M, n, y, nullptr, 0, store_rows, nullptr, nullptr, 0, gx, st);
+}
+
+}  // namespace stemgnn
+
+extern "C" int64_t stemgnn_linear_wsp_calls(void) { return stemgnn::g_wsp_calls.load(std::memory_order_relaxed); }

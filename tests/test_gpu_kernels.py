@@ -968,13 +968,21 @@ def test_linear_with_zero_tail_promise(dev, m, rows, k1, k2, n):
 
 
 # ---------------------------------------------------------------------------- round-2 kernels
+@pytest.mark.parametrize("pair", [0, 1], ids=["bf16-pieces", "pair"])
 @pytest.mark.parametrize("m,k2,n,rows,store", [(1000, 0, 128, -1, -1), (777, 0, 512, -1, 300), (2000, 128, 128, 300, -1),
-                                               (1300, 128, 256, 0, -1), (4097, 0, 128, -1, 1000), (129, 0, 96, -1, -1)])
-def test_weight_stationary_product_returns_the_tile_kernels_bits(dev, m, k2, n, rows, store):
-    """csrc/wsgemm.hip (weights as register-resident matrix-core fragments, one persistent block per CU) against the
-    tile kernel of csrc/linear.hip on the products it takes over: a single 128-column operand (also as the second
+                                               (1300, 128, 256, 0, -1), (4097, 0, 128, -1, 1000), (129, 0, 96, -1, -1),
+                                               (40000, 128, 128, 4100, -1), (40000, 128, 256, 33000, 2000),
+                                               (70001, 128, 128, 1, 64)])
+def test_weight_stationary_product_returns_the_tile_kernels_bits(dev, m, k2, n, rows, store, pair):
+    """The weight-stationary kernels (weights as register-resident matrix-core fragments, persistent blocks) against the
+    tile kernel of csrc/linear.hip on the products they take over: a single 128-column operand (also as the second
     operand when no row carries the first), row-limited output, BatchNorm column sums, backward-data through the
-    weight as stored; shapes it does not take (two live operands, N not a multiple of 128) must fall through."""
+    weight as stored; shapes they do not take (N not a multiple of 128) must fall through.
+    bf16-pieces (stemgnn_linear_set_pair(0), csrc/wsgemm.hip): the tile kernel's BITS; two live operands fall through.
+    pair (the default, csrc/wspair.hip): fp32-accurate results from two fp16 pieces per scaled row -- compared with the
+    tile kernel at a few units of fp32 resolution of the row's product sum -- and the sampled batch's two-operand layer
+    product too: the aggregate's rows (a boundary inside a tile, one row only, more head tiles than a quarter of the
+    blocks) multiplied in the blocks' prologues."""
     from stem_gnn_amd import ops
     from stem_gnn_amd._lib import lib, check
     torch.manual_seed(m + n)
@@ -998,21 +1006,41 @@ def test_weight_stationary_product_returns_the_tile_kernels_bits(dev, m, k2, n, 
         dy = torch.randn(m, n, device=dev, generator=torch.Generator(device=dev).manual_seed(5))
         return y, part, ops.linear_bwd_data(dy, w) if n == 128 else None
 
-    prev = lib.stemgnn_linear_set_ws(0)
+    prev, was_pair = lib.stemgnn_linear_set_ws(0), ops.linear_set_pair(pair)
     try:
         y0, p0, d0 = run()
         lib.stemgnn_linear_set_ws(1)  # every eligible product, whatever its size
+        calls = lib.stemgnn_linear_wsp_calls()
         y1, p1, d1 = run()
+        calls = lib.stemgnn_linear_wsp_calls() - calls
     finally:
         lib.stemgnn_linear_set_ws(prev)
-    assert torch.equal(y1, y0)
+        ops.linear_set_pair(was_pair)
     assert bool((y1[sr:] == 7.0).all())
+    ref = a.double() @ w.double().t() + b.double() + (a2.double() @ w2.double().t() if k2 else 0)
+    if pair == 0:
+        assert calls == 0
+        assert torch.equal(y1, y0)
+        if d0 is not None:
+            assert torch.equal(d1, d0)
+    else:
+        # two live operands: taken when the aggregate's tiles are at most one per block (two blocks per CU and 128 columns)
+        two_live = k2 > 0 and 0 < rows < m and n % 128 == 0 and (rows + 63) // 64 <= min(512 // (n // 128), (m + 63) // 64)
+        fwd_taken = n % 128 == 0 and (k2 == 0 or rows == 0 or two_live)
+        assert calls == int(fwd_taken) + int(d0 is not None), (calls, fwd_taken)
+        # fp32 resolution of a row's product sum: |x| |w| summed over the contraction
+        den = (a.abs() @ w.abs().t() + (a2.abs() @ w2.abs().t() if k2 else 0) + b.abs())[:sr]
+        assert float(((y1[:sr] - y0[:sr]).abs() / den).max()) < 8 * 2.0 ** -24
+        assert float(((y1[:sr].double() - ref[:sr]).abs() / den.double()).max()) < 8 * 2.0 ** -24
+        if d0 is not None:
+            dy = torch.randn(m, n, device=dev, generator=torch.Generator(device=dev).manual_seed(5))
+            dden = dy.abs() @ w.abs()
+            assert float(((d1 - d0).abs() / dden).max()) < 8 * 2.0 ** -24
+            assert float(((d1.double() - dy.double() @ w.double()).abs() / dden.double()).max()) < 8 * 2.0 ** -24
     torch.testing.assert_close(p1.sum(0), p0.sum(0), rtol=1e-6, atol=1e-4 * max(p0.sum(0).abs().max().item(), 1.0))
-    ref = a @ w.t() + b + (a2 @ w2.t() if k2 else 0)
-    torch.testing.assert_close(y1[:sr], ref[:sr], rtol=1e-4, atol=1e-3)
-    torch.testing.assert_close(p1.sum(0)[0], ref.sum(0), rtol=1e-4, atol=2e-2)
-    if d0 is not None:
-        assert torch.equal(d1, d0)
+    torch.testing.assert_close(y1[:sr].double(), ref[:sr], rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(p1.sum(0)[0].double(), ref.sum(0), rtol=1e-4, atol=2e-2)
+    torch.testing.assert_close(p1.sum(0)[1].double(), (ref * ref).sum(0), rtol=1e-4, atol=2e-2)
 
 
 @pytest.mark.parametrize("m,n,k", [(1024, 128, 128), (11000, 128, 256), (33, 96, 48), (1, 32, 16), (5000, 256, 128)])

@@ -1,13 +1,14 @@
 #!/bin/bash
 # SQ stall / activity counters per kernel over a short C4 bench run (two rocprofv3 --pmc passes, nothing else traced).
 # usage (GPU box): tools/pmc_sq_step.sh [name-substring ...]   -> gpurun_out/pmc_sq_step${TAG}.txt
+# PMC_PROG="tools/wsp_bench.py --reps 3": another program than the bench
 R=$(pwd); cd /tmp && export TMPDIR=/tmp && cd $R
 P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAVES"
 P2="SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU"
 i=0
 for P in "$P1" "$P2"; do
   i=$((i+1)); rm -rf /tmp/pmcsq_$i
-  rocprofv3 --pmc $P --output-format csv -d /tmp/pmcsq_$i -o p -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extra --e2e-steps 0 --pmc-traffic off --preheat off --no-dense-profile $BENCH_ARGS > /tmp/pmcsq_$i.log 2>&1
+  rocprofv3 --pmc $P --output-format csv -d /tmp/pmcsq_$i -o p -- python3 ${PMC_PROG:-bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extra --e2e-steps 0 --pmc-traffic off --preheat off --no-dense-profile $BENCH_ARGS} > /tmp/pmcsq_$i.log 2>&1
   echo "pass $i rc=$?"
 done
 FILTER="$*" python3 - <<'PY' > gpurun_out/pmc_sq_step${TAG}.txt
