@@ -250,6 +250,12 @@ int linear_wsp_launch(const float* x, const float* w, const float* bias, int64_t
                       float* stats_partial, int64_t stats_block0, int64_t store_rows, bool bt, const float* x1,
                       const float* w1, int64_t x1_rows, hipStream_t st);
 
+// ... and the quantiser's fused backward on the same skeleton (D = Dc = 128)
+bool vq_bwd_wsp_ok(int64_t N, int64_t D, int64_t H, int64_t Dc);
+int vq_bwd_wsp_launch(const float* g_out, const float* w_out, const float* g_loss, float coef, const float* xp,
+                      const float* norm, const int64_t* ind, const float* embed, int64_t N, int64_t H, int64_t K,
+                      float* g_xp, hipStream_t st);
+
 // csrc/wsgemm.hip: the weight-stationary dense product (K == 128): rows row_base.. of  y = x w^T + b  (bt: y = x w with w
 // given as [K][N]); stats_partial[stats_block0 + tile][2][N] takes the column sums / sums of squares per 128-row tile
 bool linear_ws_ok(int64_t M, int64_t N, int64_t K);

@@ -877,6 +877,9 @@ int stemgnn_vq_assign_bwd_fused(const float* g_out, int64_t D, const float* w_ou
   if (N == 0) return STEMGNN_OK;
   if (!g_out || !w_out || !xp || !norm || !ind || !embed || !g_xp) return STEMGNN_ERR_INVALID_ARG;
   const float coef = commit_weight * 2.0f / static_cast<float>(static_cast<double>(N) * H * Dc);
+  // D = Dc = 128: the product in the pair format on the weight-stationary skeleton (csrc/wspair.hip)
+  if (linear_pair_on() && vq_bwd_wsp_ok(N, D, H, Dc))
+    return vq_bwd_wsp_launch(g_out, w_out, g_loss, coef, xp, norm, ind, embed, N, H, K, g_xp, st);
   // heads per 128-column tile: whole heads when Dc divides 128 (then Dc / 4 lanes per head is a power of two)
   const int hpt = (128 % Dc == 0) ? static_cast<int>(std::min<int64_t>(H, 128 / Dc)) : 1;
   const int col_tiles = static_cast<int>((H + hpt - 1) / hpt);

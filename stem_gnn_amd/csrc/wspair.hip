@@ -94,11 +94,26 @@ __device__ __forceinline__ float weight_fragments(const float* __restrict__ w, i
 // x1_rows rows also carry x1 w1^T (at most one such tile per block: the host checks).  N is a multiple of 128.
 // Loads and stores of the steady-state loop are unconditional (clamped rows), as in csrc/wsgemm.hip: the compiler can then
 // wait for "the tile fetched a tile ago" while the previous tile's stores stay in flight.
-template <bool STATS, bool BT, bool HEAD, bool DBG = false>
+// EPI = 1: the quantiser's backward with project_out's backward-data product inside (csrc/vq.hip: k_vq_assign_bwd_fused
+// describes the arithmetic; reference vq.py:937,1041): x = g_out [M, 128], w = W_out [128][H * 128] (BT), a block column =
+// one head; the product tile g_q never leaves LDS -- one 32-lane group per row turns it, the row of xp, the row's norm and
+// its code into the row of g_xp = y.
+struct WspVq {
+  const float* xp;       // [M][H * 128]
+  const float* norm;     // [M][H]
+  const int64_t* ind;    // [M][H]
+  const float* embed;    // [H][K][128]
+  const float* g_loss;   // [1] or null
+  float coef;
+  int H, K;
+};
+
+template <bool STATS, bool BT, bool HEAD, int EPI = 0, bool DBG = false>
 __global__ void __launch_bounds__(kPT, 2)
 k_linear_wsp(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, int64_t M, int N,
              float* __restrict__ y, float* __restrict__ stats_partial /*[64-row tiles][2][N]*/, int64_t stats_block0,
-             int64_t store_rows, const float* __restrict__ x1, const float* __restrict__ w1, int64_t x1_rows, int dbg) {
+             int64_t store_rows, const float* __restrict__ x1, const float* __restrict__ w1, int64_t x1_rows, int dbg,
+             const WspVq vq) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const planes = smem;
   float* const tile = reinterpret_cast<float*>(smem + kPPlanesBytes);
@@ -224,6 +239,7 @@ k_linear_wsp(const float* __restrict__ x, const float* __restrict__ w, const flo
   f16x8 bw[8][2];
   const float inv_w = weight_fragments<BT>(w, N, n0 + nl, hi, bw);
   const float bias_v = bias != nullptr ? bias[n0 + nl] : 0.f;
+  const float vq_s = (EPI == 1 && vq.g_loss) ? vq.g_loss[0] * vq.coef : 0.f;
 
   // CLS 0: every row of the tile is stored; 1: none is (statistics only); 2: the boundary tile (predicated stores)
   auto do_tile = [&](auto cls) {
@@ -233,6 +249,29 @@ k_linear_wsp(const float* __restrict__ x, const float* __restrict__ w, const flo
     __syncthreads();
     if (!DBG || !(dbg & 8)) fetch(x, t + stride, M);  // a whole iteration ahead of its use: pinned here (the scheduler would sink the loads
     __builtin_amdgcn_sched_barrier(0);  // behind the matrix work to save their registers)
+    // EPI = 1: what the row-wise part needs from memory is requested before the matrix work -- codes, norms and the xp
+    // rows of this thread's eight rows (lane group g serves rows g, g + 8, ...) --, the code rows right after it
+    const int l32 = tid & 31, grp = tid >> 5;
+    int code[EPI == 1 ? 8 : 1];
+    float nrm[EPI == 1 ? 8 : 1];
+    float4 xv[EPI == 1 ? 8 : 1], qv[EPI == 1 ? 8 : 1];
+    // (addresses: a block-uniform base per row step + one 32-bit lane offset that never changes -- eight 64-bit lane
+    // addresses per array cost more registers than the kernel has; only the boundary tile clamps rows per lane)
+    const int xoff = grp * N + n0 + 4 * l32, ioff = grp * vq.H + static_cast<int>(blockIdx.y);
+    auto row_of = [&](int i) -> int64_t {  // first row of step i for the uniform base; lanes add grp through xoff / ioff
+      return m0 + 8 * i;
+    };
+    auto lane_row_ok = [&](int i) { return CLS == 0 || m0 + grp + 8 * i < M; };
+    if (EPI == 1) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const bool ok = lane_row_ok(i);
+        const int64_t base = ok ? row_of(i) : M - 1 - grp;  // a row past M reads row M - 1 again (never stored)
+        code[i] = static_cast<int>((vq.ind + base * vq.H)[ioff]);
+        nrm[i] = (vq.norm + base * vq.H)[ioff];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
     floatx16 acc[2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -242,6 +281,15 @@ k_linear_wsp(const float* __restrict__ x, const float* __restrict__ w, const flo
     if (DBG && (dbg & 4)) {  // no epilogue: keep the accumulators alive
       if (acc[0][0] + acc[1][5] == 123.456f) y[tid] = acc[0][0];
       return;
+    }
+    if (EPI == 1) {
+      const float* erow = vq.embed + static_cast<int64_t>(blockIdx.y) * vq.K * kPK + 4 * l32;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        int c = code[i];
+        if (c < 0 || c >= vq.K) c = 0;
+        qv[i] = ld4(erow + static_cast<int64_t>(c) * kPK);
+      }
     }
 
     // ---- epilogue: factors, bias (+ the leading operand's part), through the staging tile, out as 512-byte rows
@@ -258,6 +306,14 @@ k_linear_wsp(const float* __restrict__ x, const float* __restrict__ w, const flo
         acc[tm][r] = v;
       }
     if (HEAD) head_pending = false;
+    if (EPI == 1) {  // the xp rows: requested once the accumulators have left for the staging tile (registers)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int64_t base = lane_row_ok(i) ? row_of(i) : M - 1 - grp;
+        xv[i] = ld4(vq.xp + base * N + xoff);
+      }
+    }
     if (STATS) {
       float s1 = 0.f, s2 = 0.f;
       if (m0 + kPM <= M) {  // block-uniform: every tile but the last
@@ -278,7 +334,29 @@ k_linear_wsp(const float* __restrict__ x, const float* __restrict__ w, const flo
       if (hi == 0) { s_stats[nl] = s1; s_stats[kPN + nl] = s2; }
     }
     __syncthreads();
-    if (CLS != 1) {
+    if (EPI == 1) {
+      constexpr float kNormEps = 1e-12f;  // F.normalize eps (csrc/vq.hip)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int rl = grp + 8 * i;
+        const float nr = nrm[i];
+        const bool clamped = nr < kNormEps;
+        const float inv = 1.0f / fmaxf(nr, kNormEps);
+        const float4 gq = ld4(tile + rl * kPLdT + 4 * l32);
+        const float4 xq = xv[i], q = qv[i];
+        const float4 n = make_float4(xq.x * inv, xq.y * inv, xq.z * inv, xq.w * inv);
+        const float4 gx = make_float4(gq.x + vq_s * (n.x - q.x), gq.y + vq_s * (n.y - q.y), gq.z + vq_s * (n.z - q.z),
+                                      gq.w + vq_s * (n.w - q.w));
+        float dot = gx.x * n.x + gx.y * n.y + gx.z * n.z + gx.w * n.w;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 32);
+        if (clamped) dot = 0.f;  // the x / eps branch of F.normalize: plain scaling
+        if (lane_row_ok(i))
+          st4(y + row_of(i) * N + xoff,
+              make_float4((gx.x - n.x * dot) * inv, (gx.y - n.y * dot) * inv, (gx.z - n.z * dot) * inv,
+                          (gx.w - n.w * dot) * inv));
+      }
+    } else if (CLS != 1) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int rl = (tid >> 5) + 8 * i, c4 = tid & 31;
@@ -316,17 +394,17 @@ k_linear_wsp(const float* __restrict__ x, const float* __restrict__ w, const flo
   }
 }
 
-template <bool STATS, bool BT, bool HEAD>
+template <bool STATS, bool BT, bool HEAD, int EPI = 0, bool DBG = false>
 int launch_wsp(const float* x, const float* w, const float* bias, int64_t M, int N, float* y, float* stats_partial,
                int64_t stats_block0, int64_t store_rows, const float* x1, const float* w1, int64_t x1_rows, int64_t gx,
-               hipStream_t st) {
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_linear_wsp<STATS, BT, HEAD>),
+               hipStream_t st, const WspVq& vq = WspVq{}, int dbg = 0) {
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_linear_wsp<STATS, BT, HEAD, EPI, DBG>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize,
                                                      static_cast<int>(kPLdsBytes));
   if (attr != hipSuccess) return STEMGNN_ERR_HIP;
   dim3 grid(static_cast<unsigned>(gx), static_cast<unsigned>(N / kPN));
-  k_linear_wsp<STATS, BT, HEAD><<<grid, kPT, kPLdsBytes, st>>>(x, w, bias, M, N, y, stats_partial, stats_block0, store_rows,
-                                                              x1, w1, x1_rows, 0);
+  k_linear_wsp<STATS, BT, HEAD, EPI, DBG><<<grid, kPT, kPLdsBytes, st>>>(x, w, bias, M, N, y, stats_partial, stats_block0,
+                                                                        store_rows, x1, w1, x1_rows, dbg, vq);
   STEMGNN_LAUNCH_CHECK();
   return STEMGNN_OK;
 }
@@ -372,14 +450,9 @@ int linear_wsp_launch(const float* x, const float* w, const float* bias, int64_t
   }
   if (bt) {
     static const int dbg = std::getenv("STEMGNN_WSP_DBG") ? std::atoi(std::getenv("STEMGNN_WSP_DBG")) : 0;
-    if (dbg) {
-      static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_linear_wsp<false, true, false, true>),
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kPLdsBytes));
-      (void)attr;
-      dim3 grid(static_cast<unsigned>(gx), static_cast<unsigned>(N / kPN));
-      k_linear_wsp<false, true, false, true><<<grid, kPT, kPLdsBytes, st>>>(x, w, bias, M, n, y, nullptr, 0, store_rows, nullptr, nullptr, 0, dbg);
-      return STEMGNN_OK;
-    }
+    if (dbg)
+      return launch_wsp<false, true, false, 0, true>(x, w, bias, M, n, y, nullptr, 0, store_rows, nullptr, nullptr, 0, gx, st,
+                                                     WspVq{}, dbg);
     return launch_wsp<false, true, false>(x, w, bias, M, n, y, nullptr, 0, store_rows, nullptr, nullptr, 0, gx, st);
   }
   if (head) {
@@ -390,6 +463,22 @@ int linear_wsp_launch(const float* x, const float* w, const float* bias, int64_t
   if (stats_partial)
     return launch_wsp<true, false, false>(x, w, bias, M, n, y, stats_partial, stats_block0, store_rows, nullptr, nullptr, 0, gx, st);
   return launch_wsp<false, false, false>(x, w, bias, M, n, y, nullptr, 0, store_rows, nullptr, nullptr, 0, gx, st);
+}
+
+// the quantiser's fused backward (csrc/vq.hip: stemgnn_vq_assign_bwd_fused) at D = Dc = 128
+bool vq_bwd_wsp_ok(int64_t N, int64_t D, int64_t H, int64_t Dc) { return D == kPK && Dc == kPK && H >= 1 && N >= 8192; }
+
+int vq_bwd_wsp_launch(const float* g_out, const float* w_out, const float* g_loss, float coef, const float* xp,
+                      const float* norm, const int64_t* ind, const float* embed, int64_t N, int64_t H, int64_t K,
+                      float* g_xp, hipStream_t st) {
+  const int64_t HD = H * kPK;
+  const int64_t tiles = (N + kPM - 1) / kPM;
+  int64_t gx = wsp_blocks(HD);
+  if (gx > tiles) gx = tiles;
+  g_wsp_calls.fetch_add(1, std::memory_order_relaxed);
+  const WspVq vq{xp, norm, ind, embed, g_loss, coef, static_cast<int>(H), static_cast<int>(K)};
+  return launch_wsp<false, true, false, 1>(g_out, w_out, nullptr, N, static_cast<int>(HD), g_xp, nullptr, 0, N, nullptr,
+                                           nullptr, 0, gx, st, vq);
 }
 
 }  // namespace stemgnn

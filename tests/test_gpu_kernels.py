@@ -1270,10 +1270,13 @@ def test_sage_agg_bwd_accumulates(dev):
 
 
 @pytest.mark.parametrize("N,H,K,D,Dc", [(1000, 4, 128, 128, 128), (333, 2, 40, 96, 48), (50, 1, 8, 32, 32), (2500, 4, 16, 64, 64),
-                                        (1000, 4, 64, 128, 32), (700, 6, 24, 128, 32), (300, 5, 12, 64, 8)])
+                                        (1000, 4, 64, 128, 32), (700, 6, 24, 128, 32), (300, 5, 12, 64, 8),
+                                        (9001, 4, 128, 128, 128), (20000, 2, 64, 128, 128)])
 def test_vq_project_out_algebra_and_fused_backward(dev, N, H, K, D, Dc):
     """The code-table form of project_out (table read, segment-sum weight gradient) and the assignment backward with
-    project_out's backward-data product inside, against the plain products they replace."""
+    project_out's backward-data product inside, against the plain products they replace.  From 8 192 rows at D = Dc = 128
+    the fused backward runs on the pair-format weight-stationary skeleton (csrc/wspair.hip, EPI = 1: a ragged last tile
+    and a row under the eps clamp included)."""
     from stem_gnn_amd import ops
     from stem_gnn_amd._lib import lib, check
     torch.manual_seed(N + K)
@@ -1317,10 +1320,21 @@ def test_vq_project_out_algebra_and_fused_backward(dev, N, H, K, D, Dc):
     check(lib.stemgnn_vq_assign_bwd(g_q.data_ptr(), g_loss.data_ptr(), 10.0, xp.data_ptr(), norm.data_ptr(), ind.data_ptr(),
                                     embed.data_ptr(), N, H, Dc, K, ref.data_ptr(), st))
     got = torch.full_like(xp, float("nan"))
+    calls = lib.stemgnn_linear_wsp_calls()
     check(lib.stemgnn_vq_assign_bwd_fused(g.data_ptr(), D, w_out.data_ptr(), g_loss.data_ptr(), 10.0, xp.data_ptr(),
                                           norm.data_ptr(), ind.data_ptr(), embed.data_ptr(), N, H, Dc, K, got.data_ptr(), st))
+    assert lib.stemgnn_linear_wsp_calls() - calls == int(N >= 8192 and D == 128 and Dc == 128)
     scale = ref.abs().max().item()
     torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-6 * max(scale, 1.0))
+    if N >= 8192:  # ... and against the bf16-piece tile form of the same fused kernel
+        was = ops.linear_set_pair(0)
+        try:
+            old = torch.full_like(xp, float("nan"))
+            check(lib.stemgnn_vq_assign_bwd_fused(g.data_ptr(), D, w_out.data_ptr(), g_loss.data_ptr(), 10.0, xp.data_ptr(),
+                                                  norm.data_ptr(), ind.data_ptr(), embed.data_ptr(), N, H, Dc, K, old.data_ptr(), st))
+        finally:
+            ops.linear_set_pair(was)
+        torch.testing.assert_close(got, old, rtol=1e-4, atol=1e-6 * max(scale, 1.0))
 
 
 # ---------------------------------------------------------------------------- round-3: the "last block finishes" protocol
