@@ -256,6 +256,11 @@ int vq_bwd_wsp_launch(const float* g_out, const float* w_out, const float* g_los
                       const float* norm, const int64_t* ind, const float* embed, int64_t N, int64_t H, int64_t K,
                       float* g_xp, hipStream_t st);
 
+// ... and the code assignment (K = Dc = 128; eligibility and outputs as vq_assign_ws_launch)
+int vq_assign_wsp_launch(const float* xp, int64_t N, int64_t H, const float* embed, const float* esq, float* norm,
+                         int64_t* ind, float* sq_partial, unsigned int* counter, double sq_scale, float* sq_out,
+                         hipStream_t st);
+
 // csrc/wsgemm.hip: the weight-stationary dense product (K == 128): rows row_base.. of  y = x w^T + b  (bt: y = x w with w
 // given as [K][N]); stats_partial[stats_block0 + tile][2][N] takes the column sums / sums of squares per 128-row tile
 bool linear_ws_ok(int64_t M, int64_t N, int64_t K);

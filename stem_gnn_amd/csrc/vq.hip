@@ -724,7 +724,7 @@ using namespace stemgnn;
 
 extern "C" {
 
-static thread_local int g_last_assign_path = 0;  // 0 none yet, 1 k_vq_assign (tile form), 2 k_vq_assign_ws, 4 the big-tile core
+static thread_local int g_last_assign_path = 0;  // 0 none yet, 1 k_vq_assign (tile form), 2 k_vq_assign_ws, 3 k_vq_assign_wsp (pair format), 4 the big-tile core
 int stemgnn_vq_assign_last_path(void) { return g_last_assign_path; }
 
 size_t stemgnn_vq_workspace_bytes(int64_t N, int64_t H, int64_t Dc, int64_t K) {
@@ -810,6 +810,10 @@ static int vq_assign_impl(const float* xp, int64_t N, int64_t H, int64_t Dc, con
   // lean form at K = Dc = 128: the weight-stationary kernel (csrc/wsgemm.hip), same results
   if (x3 && !quant && esq && stemgnn_linear_set_ws(-1) > 0 && vq_assign_ws_ok(N, H, Dc, K))
   {
+    if (linear_pair_on()) {  // the pair format: three matrix passes (csrc/wspair.hip)
+      g_last_assign_path = 3;
+      return vq_assign_wsp_launch(xp, N, H, embed, esq, norm, ind, partial, counter, sq_scale, sqerr, st);
+    }
     g_last_assign_path = 2;
     return vq_assign_ws_launch(xp, N, H, embed, esq, norm, ind, partial, counter, sq_scale, sqerr, st);
   }

@@ -465,6 +465,230 @@ int linear_wsp_launch(const float* x, const float* w, const float* bias, int64_t
   return launch_wsp<false, false, false>(x, w, bias, M, n, y, nullptr, 0, store_rows, nullptr, nullptr, 0, gx, st);
 }
 
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------
+// Code assignment of the vector quantiser (reference model/vq.py:28-29,650-657: l2-normalise the head's rows, cosine
+// similarity with the head's codes, arg-max; commitment term vq.py:1007-1009) at K = Dc = 128 on the same skeleton:
+// the head's 128 codes are the register-resident operand (each code row scaled by its own power of two), the rows of
+// xp stream through the planes, and the arg-max is taken from the accumulators -- rows of the accumulator are CODES
+// (operands swapped, as in k_vq_assign_ws), so a lane compares 16 codes of one data row in registers: the candidates
+// are accumulator x code factor (the row's factor is positive and common to its candidates), lowest index among
+// equals; the similarity that leaves is candidate x row factor, an fp32-accurate dot product (the reference forces
+// fp32 here, vq.py:623,634).  Row norms from the fp32 values as they are cut.  Outputs as k_vq_assign's lean form.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr size_t kAqBest = 4 * kPM * sizeof(float), kAqCode = 4 * kPM * sizeof(int);
+constexpr size_t kAqLdsBytes = kPPlanesBytes + kAqBest + kAqCode + 2 * 2 * kPM * sizeof(float) + kPN * sizeof(float);
+
+__global__ void __launch_bounds__(kPT, 2)
+k_vq_assign_wsp(const float* __restrict__ xp, int64_t N, int H, const float* __restrict__ embed,
+                const float* __restrict__ esq, float* __restrict__ norm_out, int64_t* __restrict__ ind_out,
+                float* __restrict__ sq_partial, unsigned int* counter, double sq_scale, float* __restrict__ sq_out) {
+  constexpr int K = 128;
+  constexpr float kNormEps = 1e-12f;  // F.normalize eps
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const planes = smem;
+  float* const s_best = reinterpret_cast<float*>(smem + kPPlanesBytes);                 // [4 waves][64 rows]
+  int* const s_code = reinterpret_cast<int*>(smem + kPPlanesBytes + kAqBest);           // [4 waves][64 rows]
+  float* const s_row = reinterpret_cast<float*>(smem + kPPlanesBytes + kAqBest + kAqCode);  // [parity][inv | ssq][64]
+  float* const s_cf = s_row + 2 * 2 * kPM;                                              // [128] code factors
+
+  const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+  const int hi = lane >> 5, lj = lane & 31;
+  const int h = blockIdx.y;
+  const int64_t HD = static_cast<int64_t>(H) * kPK;
+  const float* const xh = xp + static_cast<int64_t>(h) * kPK;
+  const float* const emb = embed + static_cast<int64_t>(h) * K * kPK;
+  const int64_t tiles = (N + kPM - 1) / kPM;
+  int64_t t = blockIdx.x;
+  if (t >= tiles) return;  // never: the grid has at most `tiles` blocks per head
+  const int64_t stride = gridDim.x;
+
+  float4 ra[4][2];
+  const int r0 = stage_row(tid), r1 = stage_row(kPT + tid), c4s = 4 * (tid & 7);
+  auto fetch = [&](int64_t tt) {
+    const int64_t m0 = (tt < tiles ? tt : tiles - 1) * kPM;
+    const int64_t ma = m0 + r0 < N ? m0 + r0 : N - 1, mb = m0 + r1 < N ? m0 + r1 : N - 1;  // past N: row N - 1 again
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      ra[s][0] = ld4(xh + ma * HD + 32 * s + c4s);
+      ra[s][1] = ld4(xh + mb * HD + 32 * s + c4s);
+    }
+  };
+  fetch(t);
+  __builtin_amdgcn_sched_barrier(0);
+  f16x8 bw[8][2];
+  {
+    const float inv_c = weight_fragments<false>(emb, K, 32 * wn + lj, hi, bw);
+    if (hi == 0) s_cf[32 * wn + lj] = inv_c;
+  }
+  __syncthreads();
+  float cf[16];  // factors of this lane's 16 codes 32 wn + 4 hi + (r & 3) + 8 (r >> 2)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float4 v = ld4(s_cf + 32 * wn + 4 * hi + 8 * j);
+    cf[4 * j] = v.x; cf[4 * j + 1] = v.y; cf[4 * j + 2] = v.z; cf[4 * j + 3] = v.w;
+  }
+
+  float sq_acc = 0.f;  // commitment terms of the rows this thread reports
+  int par = 0;
+  // (entered through a peeled first tile, csrc/wspair.hip k_linear_wsp: counted waits in the loop)
+  auto do_tile = [&]() {
+    const int64_t m0 = t * kPM;
+    float* const s_inv = s_row + par * 2 * kPM;
+    float* const s_ssq = s_inv + kPM;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = i ? r1 : r0;
+      float mx = 0.f, sq = 0.f;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float4 v = ra[s][i];
+        mx = max_abs4(mx, v);
+        sq += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+      }
+#pragma unroll
+      for (int o = 1; o < 8; o <<= 1) {
+        mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        sq += __shfl_xor(sq, o, 64);
+      }
+      float sc, inv;
+      pair_scale(mx, sc, inv);
+      if ((tid & 7) == 0) { s_inv[r] = inv; s_ssq[r] = sq; }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        uint2 ph, pl;
+        pair_cut4(ra[s][i], sc, ph, pl);
+        unsigned char* const o = planes + r * kPRow + 2 * (32 * s + c4s);
+        *reinterpret_cast<uint2*>(o) = ph;
+        *reinterpret_cast<uint2*>(o + kPPlane) = pl;
+      }
+    }
+    __syncthreads();
+    fetch(t + stride);
+    __builtin_amdgcn_sched_barrier(0);
+    floatx16 acc[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+    {
+      f16x8 a[2][2][2];  // [step parity][tm][plane]
+      auto request = [&](int ks) {
+        const int ko = 32 * ks + 16 * hi;
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+          for (int tm = 0; tm < 2; ++tm)
+            a[ks & 1][tm][p] = *reinterpret_cast<const f16x8*>(planes + p * kPPlane + (tm * 32 + lj) * kPRow + ko);
+      };
+      request(0);
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        if (ks + 1 < 8) request(ks + 1);
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) {  // codes x rows; small terms first
+          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bw[ks][1], a[ks & 1][tm][0], acc[tm], 0, 0, 0);
+          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bw[ks][0], a[ks & 1][tm][1], acc[tm], 0, 0, 0);
+          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bw[ks][0], a[ks & 1][tm][0], acc[tm], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // ---- arg-max: 16 codes per lane in ascending order (strict '>' keeps the lowest), the two lane halves through one
+    // shuffle, the four waves through LDS
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+      float best = -INFINITY;
+      int bi = 0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = acc[tm][r] * cf[r];
+        if (v > best) { best = v; bi = 32 * wn + 4 * hi + (r & 3) + 8 * (r >> 2); }
+      }
+      const float ov = __shfl_xor(best, 32, 64);
+      const int oi = __shfl_xor(bi, 32, 64);
+      if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+      if (hi == 0) {
+        s_best[wn * kPM + tm * 32 + lj] = best;
+        s_code[wn * kPM + tm * 32 + lj] = bi;
+      }
+    }
+    __syncthreads();
+    if ((tid & 3) == 0) {  // one thread per row
+      const int row = tid >> 2;
+      float best = s_best[row];
+      int bi = s_code[row];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) {  // waves in ascending code order: strict '>' keeps the lowest index
+        const float ov = s_best[w * kPM + row];
+        if (ov > best) { best = ov; bi = s_code[w * kPM + row]; }
+      }
+      best *= s_inv[row];  // the row's factor: now the dot product of the row with its code
+      const float nrm = sqrtf(s_ssq[row]);
+      const float inv = 1.0f / fmaxf(nrm, kNormEps), xn2 = nrm * inv;
+      const int64_t m = m0 + row < N ? m0 + row : N - 1;  // a row past N is a copy of row N - 1: the same values again
+      ind_out[m * H + h] = static_cast<int64_t>(bi);
+      norm_out[m * H + h] = nrm;
+      if (m0 + row < N) sq_acc += esq[static_cast<int64_t>(h) * K + bi] + xn2 * xn2 - 2.0f * best * inv;
+    }
+    par ^= 1;  // the next tile's cut writes the other set of row factors while slow waves still read this one
+  };
+  do_tile();
+  t += stride;
+  while (t < tiles) {
+    do_tile();
+    t += stride;
+  }
+
+  // ---- the block's commitment sum; the last block to arrive adds all of them in index order (common.h: ticket_last)
+  __shared__ double red[kPT];
+  __syncthreads();
+  red[tid] = static_cast<double>(sq_acc);
+  __syncthreads();
+  for (int o = kPT / 2; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    st_agent(sq_partial + static_cast<int64_t>(blockIdx.y) * gridDim.x + blockIdx.x, static_cast<float>(red[0]));
+    wait_stores();
+  }
+  if (!ticket_last(counter)) return;
+  double tot = 0.0;
+  const int64_t nb = static_cast<int64_t>(gridDim.x) * gridDim.y;
+  for (int64_t i = tid; i < nb; i += kPT) tot += ld_agent(sq_partial + i);
+  red[tid] = tot;
+  __syncthreads();
+  for (int o = kPT / 2; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) sq_out[0] = static_cast<float>(red[0] * sq_scale);
+}
+
+}  // namespace
+
+int vq_assign_wsp_launch(const float* xp, int64_t N, int64_t H, const float* embed, const float* esq, float* norm,
+                         int64_t* ind, float* sq_partial, unsigned int* counter, double sq_scale, float* sq_out,
+                         hipStream_t st) {
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_vq_assign_wsp),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     static_cast<int>(kAqLdsBytes));
+  if (attr != hipSuccess) return STEMGNN_ERR_HIP;
+  const int64_t tiles = (N + kPM - 1) / kPM;
+  int64_t gx = wsp_blocks(H * kPN);
+  if (gx > tiles) gx = tiles;
+  if (gx * H > 1024) gx = 1024 / H;  // the partials the caller's workspace reserves (csrc/vq.hip: kWsPartials)
+  if (gx < 1) gx = 1;
+  g_wsp_calls.fetch_add(1, std::memory_order_relaxed);
+  dim3 grid(static_cast<unsigned>(gx), static_cast<unsigned>(H));
+  k_vq_assign_wsp<<<grid, kPT, kAqLdsBytes, st>>>(xp, N, static_cast<int>(H), embed, esq, norm, ind, sq_partial, counter,
+                                                  sq_scale, sq_out);
+  STEMGNN_LAUNCH_CHECK();
+  return STEMGNN_OK;
+}
+
 // the quantiser's fused backward (csrc/vq.hip: stemgnn_vq_assign_bwd_fused) at D = Dc = 128
 bool vq_bwd_wsp_ok(int64_t N, int64_t D, int64_t H, int64_t Dc) { return D == kPK && Dc == kPK && H >= 1 && N >= 8192; }
 

@@ -1071,11 +1071,15 @@ def test_few_row_product_returns_the_tile_kernels_bits(dev, m, n, k):
         assert torch.equal(d1, d0)
 
 
+@pytest.mark.parametrize("pair", [0, 1], ids=["bf16-pieces", "pair"])
 @pytest.mark.parametrize("N,H", [(20000, 4), (16390, 2)])
-def test_vq_assign_weight_stationary_matches_the_tile_form(dev, N, H):
-    """The lean code assignment at K = Dc = 128 on the weight-stationary skeleton (csrc/wsgemm.hip: k_vq_assign_ws)
-    against k_vq_assign and against torch: indices, row norms, commitment sum; a zero row and a duplicated code (tie:
-    lowest index) included."""
+def test_vq_assign_weight_stationary_matches_the_tile_form(dev, N, H, pair):
+    """The lean code assignment at K = Dc = 128 on the weight-stationary skeletons against k_vq_assign and against torch:
+    indices, row norms, commitment sum; a zero row and a duplicated code (tie: lowest index) included.
+    bf16-pieces (csrc/wsgemm.hip: k_vq_assign_ws): the tile form's arithmetic, the same indices.
+    pair (the default, csrc/wspair.hip: k_vq_assign_wsp): an fp32-accurate product summed in another order -- an index may
+    differ from the tile form's only where the row's two best similarities are within rounding of each other."""
+    from stem_gnn_amd import ops
     from stem_gnn_amd._lib import lib, check
     torch.manual_seed(N + H)
     st = torch.cuda.current_stream().cuda_stream
@@ -1094,28 +1098,38 @@ def test_vq_assign_weight_stationary_matches_the_tile_form(dev, N, H):
         ws = torch.empty(int(lib.stemgnn_vq_workspace_bytes(N, H, Dc, K)), dtype=torch.uint8, device=dev)
         check(lib.stemgnn_vq_assign_lean(xp.data_ptr(), N, H, Dc, embed.data_ptr(), esq.data_ptr(), K, norm.data_ptr(),
                                          ind.data_ptr(), sq.data_ptr(), 0.25, ws.data_ptr(), ws.numel(), st))
-        return norm, ind, sq
+        return norm, ind, sq, lib.stemgnn_vq_assign_last_path()
 
-    prev = lib.stemgnn_linear_set_ws(0)
+    prev, was_pair = lib.stemgnn_linear_set_ws(0), ops.linear_set_pair(pair)
     try:
-        n0, i0, s0 = run()
+        n0, i0, s0, p0 = run()
         lib.stemgnn_linear_set_ws(1)
-        n1, i1, s1 = run()
+        n1, i1, s1, p1 = run()
     finally:
         lib.stemgnn_linear_set_ws(prev)
-    assert torch.equal(i1, i0)
-    # the row norms: the same chunk order, but the two kernels' compilers contract the sums of squares differently --
-    # a few units in the last place (these sizes ran the tile form twice until round 3 lifted the row gate)
+        ops.linear_set_pair(was_pair)
+    assert (p0, p1) == (1, 3 if pair else 2)
+    xh = xp.view(N, H, Dc)
+    if pair == 0:
+        assert torch.equal(i1, i0)
+    else:
+        sim64 = torch.einsum("nhd,hkd->nhk", xh.double(), embed.double())
+        top2 = sim64.topk(2, dim=-1).values
+        gap = (top2[..., 0] - top2[..., 1]) / xh.double().norm(dim=-1).clamp_min(1e-30)
+        differ = i1 != i0
+        assert float(differ.float().mean()) < 1e-3 and bool((gap[differ] < 1e-5).all())
+        assert bool((i1[7] == i0[7]).all())  # the zero row: every similarity equal, index 0
+    # the row norms: the same values summed in another order -- a few units in the last place
     rel = ((n1 - n0).abs() / n0.clamp_min(1e-30)).max().item()
     assert rel <= 4e-7, rel
     torch.testing.assert_close(s1, s0, rtol=1e-5, atol=1e-6)
-    xh = xp.view(N, H, Dc)
     torch.testing.assert_close(n1, xh.norm(dim=-1), rtol=1e-5, atol=1e-6)
     sim = torch.einsum("nhd,hkd->nhk", torch.nn.functional.normalize(xh, dim=-1), embed)
     ref = sim.argmax(-1)
     agree = (ref == i1).float().mean().item()
     assert agree > 0.999  # fp32 rounding differs in the last bit between the two products; exact ties go to the lowest index
     assert int((i1 == 90).sum()) == 0 or bool(((i1 == 90) <= (ref != 17)).all())
+    assert int((i1 == 90).sum()) == 0  # the duplicate never wins: the lowest index does
 
 
 @pytest.mark.parametrize("N,H,K,Dc", [(9000, 2, 512, 256), (8192, 3, 2048, 768)])
