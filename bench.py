@@ -648,8 +648,12 @@ def main():
                            ("fp32 results on the 16-bit matrix cores, fp32 accumulation: big-tile core -- forward / "
                             "backward-data / code assignment from two fp16 pieces of power-of-two scaled rows (3 passes), "
                             "weight gradients from three exact bf16 pieces (6 passes)" if D >= 256 else
-                            "fp32 results from three exact bf16 pieces per operand (6 bf16 MFMA passes), fp32 accumulation: "
-                            "128-row tile / weight-stationary kernels")), "edge_attr": "type-indexed (4E + T*D*4 bytes)",
+                            ("fp32 results on the 16-bit matrix cores, fp32 accumulation: forward / backward-data / code "
+                             "assignment of the 128-column products from two fp16 pieces of power-of-two scaled rows (3 passes, "
+                             "weight-stationary kernels); weight gradients and the K = 512 backward-data product from three "
+                             "exact bf16 pieces (6 passes)" if ops.linear_set_pair(-1) else
+                             "fp32 results from three exact bf16 pieces per operand (6 bf16 MFMA passes), fp32 accumulation: "
+                             "128-row tile / weight-stationary kernels"))), "edge_attr": "type-indexed (4E + T*D*4 bytes)",
                        "preheat_steps": preheat_steps, "preheat_s": round(preheat_s, 3),
                        "loader_ms_per_batch_outside_timed_region": round(sampler_ms, 3),
                        "ms_per_step_with_loader_in_loop": None if e2e_ms is None else round(e2e_ms, 3)},

@@ -252,9 +252,19 @@ int linear_wsp_launch(const float* x, const float* w, const float* bias, int64_t
 
 // ... and the quantiser's fused backward on the same skeleton (D = Dc = 128)
 bool vq_bwd_wsp_ok(int64_t N, int64_t D, int64_t H, int64_t Dc);
+// (rowmax [N][H], may be null: the largest magnitude of every (row, head) stretch of g_xp, for linear_ksp_launch)
 int vq_bwd_wsp_launch(const float* g_out, const float* w_out, const float* g_loss, float coef, const float* xp,
                       const float* norm, const int64_t* ind, const float* embed, int64_t N, int64_t H, int64_t K,
-                      float* g_xp, hipStream_t st);
+                      float* g_xp, float* rowmax, hipStream_t st);
+int vq_assign_bwd_fused_rowmax(const float* g_out, int64_t D, const float* w_out, const float* g_loss, float commit_weight,
+                               const float* xp, const float* norm, const int64_t* ind, const float* embed, int64_t N,
+                               int64_t H, int64_t Dc, int64_t K, float* g_xp, float* rowmax, bool* rowmax_written,
+                               void* stream_);
+// ... and the backward-data product of a 128 -> 512 Linear (project_in): dx [M, 128] = dy [M, 512] w, w [512][128] as
+// stored; rowmax [M][4] as above; scratch (256-byte aligned) of linear_ksp_scratch_bytes(512)
+bool linear_ksp_ok(int64_t M, int64_t N_in, int64_t K_out);
+size_t linear_ksp_scratch_bytes(int64_t N_in);
+int linear_ksp_launch(const float* dy, const float* rowmax, const float* w, int64_t M, float* dx, void* scratch, hipStream_t st);
 
 // ... and the code assignment (K = Dc = 128; eligibility and outputs as vq_assign_ws_launch)
 int vq_assign_wsp_launch(const float* xp, int64_t N, int64_t H, const float* embed, const float* esq, float* norm,

@@ -411,13 +411,23 @@ int stemgnn_vq_bwd(const stemgnn_vq_params* p, const float* z, int64_t N, const 
   }
   // through the commitment term and the l2 normalisation
   const float* gl = p->commitment_weight > 0.f ? g_loss : nullptr;
+  // (fused: the [N, HD] buffer of g_q is free -- it takes the row maxima of g_xp and the cut weight of project_in's
+  // backward-data product in the pair format, csrc/wspair.hip: k_linear_ksp)
+  bool have_rowmax = false;
+  float* rowmax = g_q;
+  void* ksp_scratch = reinterpret_cast<void*>(a256(reinterpret_cast<uintptr_t>(g_q + static_cast<size_t>(N) * H)));
   if (fuse) {
-    STEMGNN_TRY(stemgnn_vq_assign_bwd_fused(g_quantize, D, p->w_out, gl, p->commitment_weight, s.xp, s.norm, ind, p->embed,
-                                            N, H, Dc, K, g_xp, stream));
+    const bool want = g_z && linear_ksp_ok(N, HD, D) &&
+                      static_cast<size_t>(N) * H * 4 + 256 + linear_ksp_scratch_bytes(HD) <= static_cast<size_t>(N) * HD * 4;
+    STEMGNN_TRY(vq_assign_bwd_fused_rowmax(g_quantize, D, p->w_out, gl, p->commitment_weight, s.xp, s.norm, ind, p->embed, N,
+                                           H, Dc, K, g_xp, want ? rowmax : nullptr, &have_rowmax, stream));
   } else {
     STEMGNN_TRY(stemgnn_vq_assign_bwd(g_q, gl, p->commitment_weight, s.xp, s.norm, ind, p->embed, N, H, Dc, K, g_xp, stream));
   }
-  if (g_z) STEMGNN_TRY(stemgnn_linear_bwd_data(g_xp, p->w_in, N, HD, D, g_z, stream));
+  if (g_z) {
+    if (have_rowmax) STEMGNN_TRY(linear_ksp_launch(g_xp, rowmax, p->w_in, N, g_z, ksp_scratch, st));
+    else STEMGNN_TRY(stemgnn_linear_bwd_data(g_xp, p->w_in, N, HD, D, g_z, stream));
+  }
   if (p->g_w_in || p->g_b_in) {
     if (!p->g_w_in) return STEMGNN_ERR_INVALID_ARG;
     STEMGNN_TRY(stemgnn_linear_bwd_weight(g_xp, z, N, HD, D, p->g_w_in, p->b_in ? p->g_b_in : nullptr, dw_ws, dw_ws_bytes,

@@ -875,6 +875,19 @@ int stemgnn_vq_assign_bwd_fused(const float* g_out, int64_t D, const float* w_ou
                                 float commit_weight, const float* xp, const float* norm, const int64_t* ind,
                                 const float* embed, int64_t N, int64_t H, int64_t Dc, int64_t K, float* g_xp,
                                 void* stream_) {
+  return stemgnn::vq_assign_bwd_fused_rowmax(g_out, D, w_out, g_loss, commit_weight, xp, norm, ind, embed, N, H, Dc, K, g_xp,
+                                             nullptr, nullptr, stream_);
+}
+}  // extern "C"
+
+namespace stemgnn {
+// *rowmax_written (may be null) tells whether `rowmax` [N][H] (may be null) received the largest magnitude of every
+// (row, head) stretch of g_xp: only the pair-format kernel writes it
+int vq_assign_bwd_fused_rowmax(const float* g_out, int64_t D, const float* w_out, const float* g_loss, float commit_weight,
+                               const float* xp, const float* norm, const int64_t* ind, const float* embed, int64_t N,
+                               int64_t H, int64_t Dc, int64_t K, float* g_xp, float* rowmax, bool* rowmax_written,
+                               void* stream_) {
+  if (rowmax_written) *rowmax_written = false;
   hipStream_t st = static_cast<hipStream_t>(stream_);
   if (!vq_dims_ok(N, H, Dc, K) || Dc > 128 || D <= 0 || D % 4 != 0 || D > 65536) return STEMGNN_ERR_INVALID_ARG;
   if (!fits_i32(N * H)) return STEMGNN_ERR_TOO_LARGE;
@@ -882,8 +895,10 @@ int stemgnn_vq_assign_bwd_fused(const float* g_out, int64_t D, const float* w_ou
   if (!g_out || !w_out || !xp || !norm || !ind || !embed || !g_xp) return STEMGNN_ERR_INVALID_ARG;
   const float coef = commit_weight * 2.0f / static_cast<float>(static_cast<double>(N) * H * Dc);
   // D = Dc = 128: the product in the pair format on the weight-stationary skeleton (csrc/wspair.hip)
-  if (linear_pair_on() && vq_bwd_wsp_ok(N, D, H, Dc))
-    return vq_bwd_wsp_launch(g_out, w_out, g_loss, coef, xp, norm, ind, embed, N, H, K, g_xp, st);
+  if (linear_pair_on() && vq_bwd_wsp_ok(N, D, H, Dc)) {
+    if (rowmax_written) *rowmax_written = rowmax != nullptr;
+    return vq_bwd_wsp_launch(g_out, w_out, g_loss, coef, xp, norm, ind, embed, N, H, K, g_xp, rowmax, st);
+  }
   // heads per 128-column tile: whole heads when Dc divides 128 (then Dc / 4 lanes per head is a power of two)
   const int hpt = (128 % Dc == 0) ? static_cast<int>(std::min<int64_t>(H, 128 / Dc)) : 1;
   const int col_tiles = static_cast<int>((H + hpt - 1) / hpt);
@@ -898,6 +913,9 @@ int stemgnn_vq_assign_bwd_fused(const float* g_out, int64_t D, const float* w_ou
   STEMGNN_LAUNCH_CHECK();
   return STEMGNN_OK;
 }
+}  // namespace stemgnn
+
+extern "C" {
 
 size_t stemgnn_vq_ema_workspace_bytes(int64_t N, int64_t H, int64_t Dc, int64_t K) {
   if (!vq_dims_ok(N, H, Dc, K)) return 0;

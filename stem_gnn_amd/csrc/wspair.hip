@@ -106,6 +106,7 @@ struct WspVq {
   const float* g_loss;   // [1] or null
   float coef;
   int H, K;
+  float* rowmax;         // [M][H] or null: largest magnitude of every (row, head) stretch of y (k_linear_ksp's row factors)
 };
 
 template <bool STATS, bool BT, bool HEAD, int EPI = 0, bool DBG = false>
@@ -351,10 +352,15 @@ k_linear_wsp(const float* __restrict__ x, const float* __restrict__ w, const flo
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 32);
         if (clamped) dot = 0.f;  // the x / eps branch of F.normalize: plain scaling
-        if (lane_row_ok(i))
-          st4(y + row_of(i) * N + xoff,
-              make_float4((gx.x - n.x * dot) * inv, (gx.y - n.y * dot) * inv, (gx.z - n.z * dot) * inv,
-                          (gx.w - n.w * dot) * inv));
+        const float4 o4 = make_float4((gx.x - n.x * dot) * inv, (gx.y - n.y * dot) * inv, (gx.z - n.z * dot) * inv,
+                                      (gx.w - n.w * dot) * inv);
+        if (lane_row_ok(i)) st4(y + row_of(i) * N + xoff, o4);
+        if (vq.rowmax) {  // block-uniform
+          float mx = max_abs4(0.f, o4);
+#pragma unroll
+          for (int o = 16; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 32));
+          if (l32 == 0 && lane_row_ok(i)) (vq.rowmax + row_of(i) * vq.H)[ioff] = mx;
+        }
       }
     } else if (CLS != 1) {
 #pragma unroll
@@ -689,18 +695,233 @@ int vq_assign_wsp_launch(const float* xp, int64_t N, int64_t H, const float* emb
   return STEMGNN_OK;
 }
 
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------
+// y [M, 128] = x [M, S * 128] w  with w given as [S * 128][128] (the backward-data product of a Linear with 128 inputs and
+// S * 128 outputs: project_in's, dz = g_xp W_in) in the pair format.  The contraction is S segments of 128 columns; the
+// weight does not fit the registers (S x 64 per lane), so its fragments are cut ONCE per launch by k_ksp_weight_frags into a
+// buffer laid out exactly as the registers want them (one coalesced 1 KB load per fragment and wave, L2-resident: 64 KB
+// per segment) and a block reloads the 64 registers per segment while it cuts the segment's rows.  One power-of-two
+// factor per ROW over all S segments -- its largest magnitude comes from `rowmax` [M][S], which the producer of x writes
+// (EPI = 1 above) -- and one per weight column over the whole contraction: a single accumulator runs through the segments.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kKspFragU4 = 4 * 16 * 64;  // uint4 per segment: 4 waves x (8 k steps x 2 planes) x 64 lanes
+
+__global__ void __launch_bounds__(kPT)
+k_ksp_weight_frags(const float* __restrict__ w /*[K][128]*/, int K, uint4* __restrict__ frag, float* __restrict__ inv_w) {
+  __shared__ float s_part[8][kPN];
+  __shared__ float s_scale[kPN];
+  const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6, hi = lane >> 5, lj = lane & 31;
+  const int seg = blockIdx.x;
+  {  // largest magnitude of every weight column over the whole contraction (every segment's block computes all of them)
+    const int c4 = 4 * (tid & 31), rg = tid >> 5;
+    float4 mx = zero4();
+    for (int k = rg; k < K; k += 8) {
+      const float4 v = ld4(w + static_cast<int64_t>(k) * kPN + c4);
+      mx = make_float4(fmaxf(mx.x, fabsf(v.x)), fmaxf(mx.y, fabsf(v.y)), fmaxf(mx.z, fabsf(v.z)), fmaxf(mx.w, fabsf(v.w)));
+    }
+    st4(&s_part[rg][c4], mx);
+    __syncthreads();
+    if (tid < kPN) {
+      float m = 0.f;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) m = fmaxf(m, s_part[g][tid]);
+      float sc, inv;
+      pair_scale(m, sc, inv);
+      s_scale[tid] = sc;
+      if (seg == 0) inv_w[tid] = inv;
+    }
+    __syncthreads();
+  }
+  const int n = 32 * wn + lj;
+  const float sc = s_scale[n];
+  const float* p = w + (static_cast<int64_t>(seg) * kPK + 8 * hi) * kPN + n;
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    const float* q = p + static_cast<int64_t>(16 * ks) * kPN;
+    uint2 h0, l0, h1, l1;
+    pair_cut4(make_float4(q[0], q[kPN], q[2 * kPN], q[3 * kPN]), sc, h0, l0);
+    pair_cut4(make_float4(q[4 * kPN], q[5 * kPN], q[6 * kPN], q[7 * kPN]), sc, h1, l1);
+    uint4* o = frag + static_cast<int64_t>(seg) * kKspFragU4 + (wn * 16 + 2 * ks) * 64 + lane;
+    o[0] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+    o[64] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+  }
+}
+
+template <int S>
+__global__ void __launch_bounds__(kPT, 2)
+k_linear_ksp(const float* __restrict__ x /*[M][S * 128]*/, const float* __restrict__ rowmax /*[M][S]*/,
+             const uint4* __restrict__ frag, const float* __restrict__ inv_w_all, int64_t M, float* __restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const planes = smem;
+  float* const tile = reinterpret_cast<float*>(smem + kPPlanesBytes);
+  float* const s_inv = reinterpret_cast<float*>(smem + kPPlanesBytes + kPStageBytes + kPStatsBytes);  // [64] row factors
+  constexpr int64_t ldx = static_cast<int64_t>(S) * kPK;
+
+  const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+  const int hi = lane >> 5, lj = lane & 31, nl = 32 * wn + lj;
+  const int64_t tiles = (M + kPM - 1) / kPM;
+  int64_t t = blockIdx.x;
+  if (t >= tiles) return;
+  const int64_t stride = gridDim.x;
+  const float inv_w = inv_w_all[nl];
+
+  float4 ra[4][2];
+  const int r0 = stage_row(tid), r1 = stage_row(kPT + tid), c4s = 4 * (tid & 7);
+  // segment `seg` of tile `tt` (seg == S: segment 0 of the block's next tile)
+  auto fetch = [&](int64_t tt, int seg) {
+    if (seg == S) { tt += stride; seg = 0; }
+    const int64_t m0 = (tt < tiles ? tt : tiles - 1) * kPM;
+    const int64_t ma = m0 + r0 < M ? m0 + r0 : M - 1, mb = m0 + r1 < M ? m0 + r1 : M - 1;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      ra[s][0] = ld4(x + ma * ldx + seg * kPK + 32 * s + c4s);
+      ra[s][1] = ld4(x + mb * ldx + seg * kPK + 32 * s + c4s);
+    }
+  };
+  fetch(t, 0);
+
+  auto do_tile = [&](auto cls) {
+    constexpr int CLS = decltype(cls)::value;
+    const int64_t m0 = t * kPM;
+    // the rows' factors: largest magnitude over the S stretches
+    float sc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = i ? r1 : r0;
+      const int64_t m = m0 + r < M ? m0 + r : M - 1;
+      float mx = 0.f;
+#pragma unroll
+      for (int q = 0; q < S; ++q) mx = fmaxf(mx, rowmax[m * S + q]);
+      float inv;
+      pair_scale(mx, sc[i], inv);
+      if ((tid & 7) == 0) s_inv[r] = inv;
+    }
+    floatx16 acc[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+#pragma unroll 1  // (unrolled, the compiler hoists every segment's 64 fragment registers to the top: 129 spills)
+    for (int seg = 0; seg < S; ++seg) {
+      // this segment's weight fragments travel while the rows are cut
+      f16x8 bw[8][2];
+      const uint4* fp = frag + static_cast<int64_t>(seg) * kKspFragU4 + wn * 16 * 64 + lane;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        bw[ks][0] = __builtin_bit_cast(f16x8, fp[(2 * ks) * 64]);
+        bw[ks][1] = __builtin_bit_cast(f16x8, fp[(2 * ks + 1) * 64]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int r = i ? r1 : r0;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          uint2 ph, pl;
+          pair_cut4(ra[s][i], sc[i], ph, pl);
+          unsigned char* const o = planes + r * kPRow + 2 * (32 * s + c4s);
+          *reinterpret_cast<uint2*>(o) = ph;
+          *reinterpret_cast<uint2*>(o + kPPlane) = pl;
+        }
+      }
+      __syncthreads();
+      fetch(t, seg + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        f16x8 a[2][2][2];  // [step parity][tm][plane]
+        auto request = [&](int ks) {
+          const int ko = 32 * ks + 16 * hi;
+#pragma unroll
+          for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+              a[ks & 1][tm][p] = *reinterpret_cast<const f16x8*>(planes + p * kPPlane + (tm * 32 + lj) * kPRow + ko);
+        };
+        request(0);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          if (ks + 1 < 8) request(ks + 1);
+#pragma unroll
+          for (int tm = 0; tm < 2; ++tm) {  // small terms first
+            acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks & 1][tm][1], bw[ks][0], acc[tm], 0, 0, 0);
+            acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks & 1][tm][0], bw[ks][1], acc[tm], 0, 0, 0);
+            acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks & 1][tm][0], bw[ks][0], acc[tm], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if (seg + 1 < S) __syncthreads();  // every wave has read the planes: the next segment's cut may overwrite them
+    }
+    // ---- epilogue: factors, through the staging tile, out as 512-byte rows
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 f = ld4(s_inv + tm * 32 + 4 * hi + 8 * j);
+        const float ff[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          tile[(tm * 32 + 4 * hi + q + 8 * j) * kPLdT + nl] = acc[tm][4 * j + q] * (ff[q] * inv_w);
+      }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int rl = (tid >> 5) + 8 * i, c4 = tid & 31;
+      const int64_t m = m0 + rl;
+      if (CLS == 0 || m < M) st4(y + m * kPN + 4 * c4, ld4(tile + rl * kPLdT + 4 * c4));
+    }
+  };
+  auto full = [&]() { return t < tiles && (t + 1) * kPM <= M; };
+  if (full()) {
+    do_tile(IntTag<0>{});
+    t += stride;
+    while (full()) {
+      do_tile(IntTag<0>{});
+      t += stride;
+    }
+  }
+  if (t < tiles) do_tile(IntTag<2>{});
+}
+
+}  // namespace
+
+bool linear_ksp_ok(int64_t M, int64_t N_in, int64_t K_out) { return K_out == kPN && N_in == 4 * kPK && M >= 8192; }
+size_t linear_ksp_scratch_bytes(int64_t N_in) { return static_cast<size_t>(N_in / kPK) * kKspFragU4 * sizeof(uint4) + 1024; }
+
+// dx [M, 128] = dy [M, 512] w  (w [512][128] as stored); rowmax [M][4] = largest magnitude of every 128-column stretch of
+// dy's rows; scratch: linear_ksp_scratch_bytes, 256-byte aligned
+int linear_ksp_launch(const float* dy, const float* rowmax, const float* w, int64_t M, float* dx, void* scratch, hipStream_t st) {
+  constexpr int S = 4;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_linear_ksp<S>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     static_cast<int>(kPLdsBytes));
+  if (attr != hipSuccess) return STEMGNN_ERR_HIP;
+  float* inv_w = static_cast<float*>(scratch);
+  uint4* frag = reinterpret_cast<uint4*>(static_cast<unsigned char*>(scratch) + 1024);
+  k_ksp_weight_frags<<<S, kPT, 0, st>>>(w, S * kPK, frag, inv_w);
+  STEMGNN_LAUNCH_CHECK();
+  const int64_t tiles = (M + kPM - 1) / kPM;
+  int64_t gx = wsp_blocks(kPN);
+  if (gx > tiles) gx = tiles;
+  g_wsp_calls.fetch_add(1, std::memory_order_relaxed);
+  k_linear_ksp<S><<<static_cast<unsigned>(gx), kPT, kPLdsBytes, st>>>(dy, rowmax, frag, inv_w, M, dx);
+  STEMGNN_LAUNCH_CHECK();
+  return STEMGNN_OK;
+}
+
 // the quantiser's fused backward (csrc/vq.hip: stemgnn_vq_assign_bwd_fused) at D = Dc = 128
 bool vq_bwd_wsp_ok(int64_t N, int64_t D, int64_t H, int64_t Dc) { return D == kPK && Dc == kPK && H >= 1 && N >= 8192; }
 
 int vq_bwd_wsp_launch(const float* g_out, const float* w_out, const float* g_loss, float coef, const float* xp,
                       const float* norm, const int64_t* ind, const float* embed, int64_t N, int64_t H, int64_t K,
-                      float* g_xp, hipStream_t st) {
+                      float* g_xp, float* rowmax, hipStream_t st) {
   const int64_t HD = H * kPK;
   const int64_t tiles = (N + kPM - 1) / kPM;
   int64_t gx = wsp_blocks(HD);
   if (gx > tiles) gx = tiles;
   g_wsp_calls.fetch_add(1, std::memory_order_relaxed);
-  const WspVq vq{xp, norm, ind, embed, g_loss, coef, static_cast<int>(H), static_cast<int>(K)};
+  const WspVq vq{xp, norm, ind, embed, g_loss, coef, static_cast<int>(H), static_cast<int>(K), rowmax};
   return launch_wsp<false, true, false, 1>(g_out, w_out, nullptr, N, static_cast<int>(HD), g_xp, nullptr, 0, N, nullptr,
                                            nullptr, 0, gx, st, vq);
 }

@@ -188,7 +188,9 @@ def test_vq_matches_reference_golden_at_production_shapes(dev, path, gemm_mode, 
         q, ind, loss, oq = vq(z)
         served_by = int(lib.stemgnn_vq_assign_last_path())
         if lean and gemm_mode == 1 and K == 128 and Dc == 128 and N >= 16384:
-            assert served_by == 2, "the weight-stationary assignment kernel must serve the production-shape case"
+            # k_vq_assign_wsp (pair format, the default) / k_vq_assign_ws (stemgnn_linear_set_pair(0))
+            assert served_by == (3 if ops.linear_set_pair(-1) else 2), \
+                "a weight-stationary assignment kernel must serve the production-shape case"
         elif gemm_mode == 1 and K >= 512 and Dc >= 256 and N >= 8192:
             assert served_by == 4, "the big-tile core must serve the (9000, 256, 2, 512, 256) case"
         elif lean:
@@ -223,11 +225,14 @@ def test_vq_matches_reference_golden_at_production_shapes(dev, path, gemm_mode, 
 
 
 @pytest.mark.parametrize("N,D,H,K,Dc", [(1, 32, 2, 8, 16), (127, 32, 4, 33, 32), (129, 64, 4, 128, 64),
-                                        (1000, 128, 4, 512, 128), (300, 96, 2, 200, 100), (260, 768, 4, 128, 768)])
+                                        (1000, 128, 4, 512, 128), (300, 96, 2, 200, 100), (260, 768, 4, 128, 768),
+                                        (9001, 128, 4, 128, 128)])
 @pytest.mark.parametrize("lean", [False, True], ids=["codes", "phase"])
 def test_vq_vs_oracle_sizes(dev, N, D, H, K, Dc, lean):
     """Ragged tiles (N not a multiple of 128, K not a multiple of 32, Dc not a multiple of 32), through the per-op
-    path and through the one-call module phase."""
+    path and through the one-call module phase.  (9001, 128, 4, 128, 128): past the row gate of the pair-format
+    weight-stationary kernels -- in the phase form the backward runs the quantiser's fused backward and project_in's
+    backward-data product (k_linear_ksp, rows scaled by the maxima the fused kernel wrote) from csrc/wspair.hip."""
     torch.manual_seed(N + K)
     ovq = O.OracleVectorQuantize(D, K, Dc, H, commitment_weight=10.0, orthogonal_reg_weight=1.0,
                                  orthogonal_reg_max_codes=32, ema_update=False)
