@@ -94,7 +94,7 @@ __device__ __forceinline__ float weight_fragments(const float* __restrict__ w, i
 // x1_rows rows also carry x1 w1^T (at most one such tile per block: the host checks).  N is a multiple of 128.
 // Loads and stores of the steady-state loop are unconditional (clamped rows), as in csrc/wsgemm.hip: the compiler can then
 // wait for "the tile fetched a tile ago" while the previous tile's stores stay in flight.
-// EPI = 1: the quantiser's backward with project_out's backward-data product inside (csrc/vq.hip: k_vq_assign_bwd_fused
+// EPI = 1 / 2: the quantiser's backward with project_out's backward-data product inside (csrc/vq.hip: k_vq_assign_bwd_fused
 // describes the arithmetic; reference vq.py:937,1041): x = g_out [M, 128], w = W_out [128][H * 128] (BT), a block column =
 // one head; the product tile g_q never leaves LDS -- one 32-lane group per row turns it, the row of xp, the row's norm and
 // its code into the row of g_xp = y.
@@ -106,7 +106,7 @@ struct WspVq {
   const float* g_loss;   // [1] or null
   float coef;
   int H, K;
-  float* rowmax;         // [M][H] or null: largest magnitude of every (row, head) stretch of y (k_linear_ksp's row factors)
+  float* rowmax;         // EPI = 2: [M][H], largest magnitude of every (row, head) stretch of y (k_linear_ksp's row factors)
 };
 
 template <bool STATS, bool BT, bool HEAD, int EPI = 0, bool DBG = false>
@@ -121,6 +121,7 @@ k_linear_wsp(const float* __restrict__ x, const float* __restrict__ w, const flo
   float* const s_stats = reinterpret_cast<float*>(smem + kPPlanesBytes + kPStageBytes);  // [sum|sumsq][128]
   float* const s_inv = reinterpret_cast<float*>(smem + kPPlanesBytes + kPStageBytes + kPStatsBytes);  // [64] row factors
 
+  constexpr bool VQB = EPI == 1 || EPI == 2;  // the quantiser's backward as the epilogue; EPI == 2: row maxima as well
   const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
   const int hi = lane >> 5, lj = lane & 31;
   const int n0 = blockIdx.y * kPN, nl = 32 * wn + lj;
@@ -240,7 +241,7 @@ k_linear_wsp(const float* __restrict__ x, const float* __restrict__ w, const flo
   f16x8 bw[8][2];
   const float inv_w = weight_fragments<BT>(w, N, n0 + nl, hi, bw);
   const float bias_v = bias != nullptr ? bias[n0 + nl] : 0.f;
-  const float vq_s = (EPI == 1 && vq.g_loss) ? vq.g_loss[0] * vq.coef : 0.f;
+  const float vq_s = (VQB && vq.g_loss) ? vq.g_loss[0] * vq.coef : 0.f;
 
   // CLS 0: every row of the tile is stored; 1: none is (statistics only); 2: the boundary tile (predicated stores)
   auto do_tile = [&](auto cls) {
@@ -253,9 +254,9 @@ k_linear_wsp(const float* __restrict__ x, const float* __restrict__ w, const flo
     // EPI = 1: what the row-wise part needs from memory is requested before the matrix work -- codes, norms and the xp
     // rows of this thread's eight rows (lane group g serves rows g, g + 8, ...) --, the code rows right after it
     const int l32 = tid & 31, grp = tid >> 5;
-    int code[EPI == 1 ? 8 : 1];
-    float nrm[EPI == 1 ? 8 : 1];
-    float4 xv[EPI == 1 ? 8 : 1], qv[EPI == 1 ? 8 : 1];
+    int code[VQB ? 8 : 1];
+    float nrm[VQB ? 8 : 1];
+    float4 xv[VQB ? 8 : 1], qv[VQB ? 8 : 1];
     // (addresses: a block-uniform base per row step + one 32-bit lane offset that never changes -- eight 64-bit lane
     // addresses per array cost more registers than the kernel has; only the boundary tile clamps rows per lane)
     const int xoff = grp * N + n0 + 4 * l32, ioff = grp * vq.H + static_cast<int>(blockIdx.y);
@@ -263,7 +264,7 @@ k_linear_wsp(const float* __restrict__ x, const float* __restrict__ w, const flo
       return m0 + 8 * i;
     };
     auto lane_row_ok = [&](int i) { return CLS == 0 || m0 + grp + 8 * i < M; };
-    if (EPI == 1) {
+    if (VQB) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const bool ok = lane_row_ok(i);
@@ -283,7 +284,7 @@ k_linear_wsp(const float* __restrict__ x, const float* __restrict__ w, const flo
       if (acc[0][0] + acc[1][5] == 123.456f) y[tid] = acc[0][0];
       return;
     }
-    if (EPI == 1) {
+    if (VQB) {
       const float* erow = vq.embed + static_cast<int64_t>(blockIdx.y) * vq.K * kPK + 4 * l32;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -307,7 +308,7 @@ k_linear_wsp(const float* __restrict__ x, const float* __restrict__ w, const flo
         acc[tm][r] = v;
       }
     if (HEAD) head_pending = false;
-    if (EPI == 1) {  // the xp rows: requested once the accumulators have left for the staging tile (registers)
+    if (VQB) {  // the xp rows: requested once the accumulators have left for the staging tile (registers)
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -335,8 +336,9 @@ k_linear_wsp(const float* __restrict__ x, const float* __restrict__ w, const flo
       if (hi == 0) { s_stats[nl] = s1; s_stats[kPN + nl] = s2; }
     }
     __syncthreads();
-    if (EPI == 1) {
+    if (VQB) {
       constexpr float kNormEps = 1e-12f;  // F.normalize eps (csrc/vq.hip)
+      float rmx[EPI == 2 ? 8 : 1];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int rl = grp + 8 * i;
@@ -355,12 +357,29 @@ k_linear_wsp(const float* __restrict__ x, const float* __restrict__ w, const flo
         const float4 o4 = make_float4((gx.x - n.x * dot) * inv, (gx.y - n.y * dot) * inv, (gx.z - n.z * dot) * inv,
                                       (gx.w - n.w * dot) * inv);
         if (lane_row_ok(i)) st4(y + row_of(i) * N + xoff, o4);
-        if (vq.rowmax) {  // block-uniform
-          float mx = max_abs4(0.f, o4);
+        if (EPI == 2) rmx[i] = max_abs4(0.f, o4);
+      }
+      if (EPI == 2) {
+        // the eight rows' maxima over the group's 32 lanes as ONE butterfly: a lane keeps the half of the rows its own
+        // bit selects and hands the other half over -- 4 + 2 + 1 + 1 + 1 cross-lane steps instead of 8 x 5 -- and lane
+        // 4 i of the group ends up with row i's maximum: one store instruction per thread
+        const bool b16 = (l32 & 16) != 0, b8 = (l32 & 8) != 0, b4 = (l32 & 4) != 0;
+        float m4[4], m2[2];
 #pragma unroll
-          for (int o = 16; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 32));
-          if (l32 == 0 && lane_row_ok(i)) (vq.rowmax + row_of(i) * vq.H)[ioff] = mx;
+        for (int j = 0; j < 4; ++j) {
+          const float keep = b16 ? rmx[j + 4] : rmx[j], send = b16 ? rmx[j] : rmx[j + 4];
+          m4[j] = fmaxf(keep, __shfl_xor(send, 16, 32));
         }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const float keep = b8 ? m4[j + 2] : m4[j], send = b8 ? m4[j] : m4[j + 2];
+          m2[j] = fmaxf(keep, __shfl_xor(send, 8, 32));
+        }
+        float m1 = fmaxf(b4 ? m2[1] : m2[0], __shfl_xor(b4 ? m2[0] : m2[1], 4, 32));
+        m1 = fmaxf(m1, __shfl_xor(m1, 2, 32));
+        m1 = fmaxf(m1, __shfl_xor(m1, 1, 32));
+        const int ri = (b4 ? 1 : 0) | (b8 ? 2 : 0) | (b16 ? 4 : 0);  // the row step this lane reports
+        if ((l32 & 3) == 0 && (CLS == 0 || m0 + grp + 8 * ri < M)) (vq.rowmax + (m0 + 8 * ri) * vq.H)[ioff] = m1;
       }
     } else if (CLS != 1) {
 #pragma unroll
@@ -717,9 +736,17 @@ k_ksp_weight_frags(const float* __restrict__ w /*[K][128]*/, int K, uint4* __res
   {  // largest magnitude of every weight column over the whole contraction (every segment's block computes all of them)
     const int c4 = 4 * (tid & 31), rg = tid >> 5;
     float4 mx = zero4();
-    for (int k = rg; k < K; k += 8) {
-      const float4 v = ld4(w + static_cast<int64_t>(k) * kPN + c4);
-      mx = make_float4(fmaxf(mx.x, fabsf(v.x)), fmaxf(mx.y, fabsf(v.y)), fmaxf(mx.z, fabsf(v.z)), fmaxf(mx.w, fabsf(v.w)));
+    for (int k = rg; k < K; k += 8 * 16) {  // sixteen rows in flight per thread (one at a time: 64 memory latencies)
+      float4 v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int kk = k + 8 * u < K ? k + 8 * u : rg;  // a short last batch re-reads the thread's first row
+        v[u] = ld4(w + static_cast<int64_t>(kk) * kPN + c4);
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        mx = make_float4(fmaxf(mx.x, fabsf(v[u].x)), fmaxf(mx.y, fabsf(v[u].y)), fmaxf(mx.z, fabsf(v[u].z)),
+                         fmaxf(mx.w, fabsf(v[u].w)));
     }
     st4(&s_part[rg][c4], mx);
     __syncthreads();
@@ -753,10 +780,12 @@ template <int S>
 __global__ void __launch_bounds__(kPT, 2)
 k_linear_ksp(const float* __restrict__ x /*[M][S * 128]*/, const float* __restrict__ rowmax /*[M][S]*/,
              const uint4* __restrict__ frag, const float* __restrict__ inv_w_all, int64_t M, float* __restrict__ y) {
+  // two sets of planes: segment s + 1 is cut into the other set while slow waves still multiply segment s -- ONE barrier
+  // per segment.  The staging tile of the epilogue lies over the set the tile's last segment did NOT use, and the next
+  // tile starts with the other set (`par`), so nothing is overwritten while a wave still reads it.
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* const planes = smem;
-  float* const tile = reinterpret_cast<float*>(smem + kPPlanesBytes);
-  float* const s_inv = reinterpret_cast<float*>(smem + kPPlanesBytes + kPStageBytes + kPStatsBytes);  // [64] row factors
+  float* const s_inv = reinterpret_cast<float*>(smem + 2 * kPPlanesBytes);  // [64] row factors
+  int par = 0;
   constexpr int64_t ldx = static_cast<int64_t>(S) * kPK;
 
   const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
@@ -798,6 +827,7 @@ k_linear_ksp(const float* __restrict__ x /*[M][S * 128]*/, const float* __restri
       pair_scale(mx, sc[i], inv);
       if ((tid & 7) == 0) s_inv[r] = inv;
     }
+    float* const tile = reinterpret_cast<float*>(smem + par * kPPlanesBytes);
     floatx16 acc[2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -805,6 +835,7 @@ k_linear_ksp(const float* __restrict__ x /*[M][S * 128]*/, const float* __restri
       for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
 #pragma unroll 1  // (unrolled, the compiler hoists every segment's 64 fragment registers to the top: 129 spills)
     for (int seg = 0; seg < S; ++seg) {
+      unsigned char* const planes = smem + ((seg + par) & 1) * kPPlanesBytes;
       // this segment's weight fragments travel while the rows are cut
       f16x8 bw[8][2];
       const uint4* fp = frag + static_cast<int64_t>(seg) * kKspFragU4 + wn * 16 * 64 + lane;
@@ -851,7 +882,6 @@ k_linear_ksp(const float* __restrict__ x /*[M][S * 128]*/, const float* __restri
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-      if (seg + 1 < S) __syncthreads();  // every wave has read the planes: the next segment's cut may overwrite them
     }
     // ---- epilogue: factors, through the staging tile, out as 512-byte rows
 #pragma unroll
@@ -871,6 +901,7 @@ k_linear_ksp(const float* __restrict__ x /*[M][S * 128]*/, const float* __restri
       const int64_t m = m0 + rl;
       if (CLS == 0 || m < M) st4(y + m * kPN + 4 * c4, ld4(tile + rl * kPLdT + 4 * c4));
     }
+    par ^= 1;
   };
   auto full = [&]() { return t < tiles && (t + 1) * kPM <= M; };
   if (full()) {
@@ -893,9 +924,12 @@ size_t linear_ksp_scratch_bytes(int64_t N_in) { return static_cast<size_t>(N_in 
 // dy's rows; scratch: linear_ksp_scratch_bytes, 256-byte aligned
 int linear_ksp_launch(const float* dy, const float* rowmax, const float* w, int64_t M, float* dx, void* scratch, hipStream_t st) {
   constexpr int S = 4;
+  static_assert(S % 2 == 0, "the staging tile lies over the plane set the last segment did not use");
+  constexpr size_t kLds = 2 * kPPlanesBytes + kPInvBytes;
+  static_assert(kPStageBytes <= kPPlanesBytes, "the staging tile fits one set of planes");
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_linear_ksp<S>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                     static_cast<int>(kPLdsBytes));
+                                                     static_cast<int>(kLds));
   if (attr != hipSuccess) return STEMGNN_ERR_HIP;
   float* inv_w = static_cast<float*>(scratch);
   uint4* frag = reinterpret_cast<uint4*>(static_cast<unsigned char*>(scratch) + 1024);
@@ -905,7 +939,7 @@ int linear_ksp_launch(const float* dy, const float* rowmax, const float* w, int6
   int64_t gx = wsp_blocks(kPN);
   if (gx > tiles) gx = tiles;
   g_wsp_calls.fetch_add(1, std::memory_order_relaxed);
-  k_linear_ksp<S><<<static_cast<unsigned>(gx), kPT, kPLdsBytes, st>>>(dy, rowmax, frag, inv_w, M, dx);
+  k_linear_ksp<S><<<static_cast<unsigned>(gx), kPT, kLds, st>>>(dy, rowmax, frag, inv_w, M, dx);
   STEMGNN_LAUNCH_CHECK();
   return STEMGNN_OK;
 }
@@ -922,6 +956,9 @@ int vq_bwd_wsp_launch(const float* g_out, const float* w_out, const float* g_los
   if (gx > tiles) gx = tiles;
   g_wsp_calls.fetch_add(1, std::memory_order_relaxed);
   const WspVq vq{xp, norm, ind, embed, g_loss, coef, static_cast<int>(H), static_cast<int>(K), rowmax};
+  if (rowmax)
+    return launch_wsp<false, true, false, 2>(g_out, w_out, nullptr, N, static_cast<int>(HD), g_xp, nullptr, 0, N, nullptr,
+                                             nullptr, 0, gx, st, vq);
   return launch_wsp<false, true, false, 1>(g_out, w_out, nullptr, N, static_cast<int>(HD), g_xp, nullptr, 0, N, nullptr,
                                            nullptr, 0, gx, st, vq);
 }
