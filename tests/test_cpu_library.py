@@ -176,3 +176,8 @@ def test_bigtile_core_source_never_allocates_or_synchronises():
     build = open(os.path.join(ROOT, "stem_gnn_amd", "build.py")).read()
     assert "hipblas" not in build and "rocblas" not in build
     assert not os.path.exists(os.path.join(ROOT, "stem_gnn_amd", "csrc", "blaslt.hip"))
+    # the pair-format weight-stationary kernels (round 4) take their scratch from the phase's workspace: same rule
+    pair = open(os.path.join(ROOT, "stem_gnn_amd", "csrc", "wspair.hip")).read()
+    for banned in ("hipMalloc", "hipFree", "hipStreamSynchronize", "hipDeviceSynchronize", "hipMemcpy(", "hipEventSynchronize",
+                   "hipblas", "rocblas"):
+        assert banned not in pair, banned

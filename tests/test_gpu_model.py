@@ -269,6 +269,33 @@ def test_vq_vs_oracle_sizes(dev, N, D, H, K, Dc, lean):
             scale = p1.grad.abs().max().item()
             torch.testing.assert_close(p2.grad.cpu(), p1.grad, rtol=1e-3, atol=1e-5 * max(scale, 1.0),
                                        msg=lambda m: f"{n1}: {m}")
+    if N >= 8192 and lean:
+        # the pair-format kernels of the phase (fused backward with row maxima, k_linear_ksp, the assignment) against the
+        # bf16-piece kernels on the same call: the gradient of the input within a few fp32 roundings of the row's sums
+        from stem_gnn_amd import ops
+        from stem_gnn_amd._lib import lib
+        calls = lib.stemgnn_linear_wsp_calls()
+        z1 = z.to(dev).requires_grad_(True)
+        q1, i1, l1, _ = vq(z1)
+        (l1.sum() + (q1 * w.to(dev)).sum()).backward()
+        # the fused backward and project_in's backward-data product (from 8 192 rows; project_in itself and the
+        # assignment join them at 16 384: covered by the N = 16 500 golden case and by test_gpu_kernels.py)
+        assert lib.stemgnn_linear_wsp_calls() - calls >= 2
+        was = ops.linear_set_pair(0)
+        try:
+            calls = lib.stemgnn_linear_wsp_calls()
+            z0 = z.to(dev).requires_grad_(True)
+            q0, i0, l0, _ = vq(z0)
+            (l0.sum() + (q0 * w.to(dev)).sum()).backward()
+            assert lib.stemgnn_linear_wsp_calls() == calls
+        finally:
+            ops.linear_set_pair(was)
+        same = (i1 == i0).all(dim=-1) if i1.dim() > 1 else (i1 == i0)
+        assert float((~same).float().mean()) < 1e-3
+        g1, g0 = z1.grad[same], z0.grad[same]
+        row_l1 = g0.abs().sum(dim=1, keepdim=True).clamp_min(1e-30)
+        assert float(((g1 - g0).abs() / row_l1).max()) < 2e-6
+        torch.testing.assert_close(l1, l0, rtol=1e-5, atol=1e-6)
 
 
 def test_vq_tie_breaks_to_lowest_index(dev):
