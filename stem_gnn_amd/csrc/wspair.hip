@@ -297,17 +297,24 @@ k_linear_wsp(const float* __restrict__ x, const float* __restrict__ w, const flo
     // ---- epilogue: factors, bias (+ the leading operand's part), through the staging tile, out as 512-byte rows
     float rf[2][16];
     row_factors(rf);
+    if (HEAD && head_pending) {  // block-uniform, a block's first tile only: the leading operand's part joins the
+      // accumulators in THEIR scale (the factors are powers of two: the division and the later product are exact)
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          acc[tm][r] += tile[(tm * 32 + 4 * hi + (r & 3) + 8 * (r >> 2)) * kPLdT + nl] / (rf[tm][r] * inv_w);
+      head_pending = false;
+    }
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int rs = tm * 32 + 4 * hi + (r & 3) + 8 * (r >> 2);
-        float v = acc[tm][r] * (rf[tm][r] * inv_w) + bias_v;
-        if (HEAD && head_pending) v += tile[rs * kPLdT + nl];
+        const float v = acc[tm][r] * (rf[tm][r] * inv_w) + bias_v;
         if (CLS != 1) tile[rs * kPLdT + nl] = v;
         acc[tm][r] = v;
       }
-    if (HEAD) head_pending = false;
     if (VQB) {  // the xp rows: requested once the accumulators have left for the staging tile (registers)
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

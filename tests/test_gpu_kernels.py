@@ -1030,7 +1030,8 @@ def test_weight_stationary_product_returns_the_tile_kernels_bits(dev, m, k2, n, 
         assert calls == int(fwd_taken) + int(d0 is not None), (calls, fwd_taken)
         # fp32 resolution of a row's product sum: |x| |w| summed over the contraction
         den = (a.abs() @ w.abs().t() + (a2.abs() @ w2.abs().t() if k2 else 0) + b.abs())[:sr]
-        assert float(((y1[:sr] - y0[:sr]).abs() / den).max()) < 8 * 2.0 ** -24
+        # (against fp64: 8 roundings of the row's product sum; against the tile kernel, which has its own: 12)
+        assert float(((y1[:sr] - y0[:sr]).abs() / den).max()) < 12 * 2.0 ** -24
         assert float(((y1[:sr].double() - ref[:sr]).abs() / den.double()).max()) < 8 * 2.0 ** -24
         if d0 is not None:
             dy = torch.randn(m, n, device=dev, generator=torch.Generator(device=dev).manual_seed(5))
