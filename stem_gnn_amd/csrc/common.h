@@ -266,7 +266,8 @@ bool linear_ksp_ok(int64_t M, int64_t N_in, int64_t K_out);
 size_t linear_ksp_scratch_bytes(int64_t N_in);
 int linear_ksp_launch(const float* dy, const float* rowmax, const float* w, int64_t M, float* dx, void* scratch, hipStream_t st);
 
-// ... and the code assignment (K = Dc = 128; eligibility and outputs as vq_assign_ws_launch)
+bool vq_assign_takes_own_sqnorm(int64_t N, int64_t H, int64_t Dc, int64_t K);  // csrc/vq.hip
+// ... and the code assignment (K = Dc = 128; eligibility and outputs as vq_assign_ws_launch; `esq` is not read)
 int vq_assign_wsp_launch(const float* xp, int64_t N, int64_t H, const float* embed, const float* esq, float* norm,
                          int64_t* ind, float* sq_partial, unsigned int* counter, double sq_scale, float* sq_out,
                          hipStream_t st);

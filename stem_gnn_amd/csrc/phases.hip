@@ -333,7 +333,8 @@ int stemgnn_vq_fwd(const stemgnn_vq_params* p, const float* z, int64_t N, int tr
   // project_in (vq.py:881)
   STEMGNN_TRY(stemgnn_linear_fwd(z, p->w_in, D, nullptr, nullptr, 0, p->b_in, N, HD, s.xp, nullptr, nullptr, -1, stream));
   // codebook-side tables: |e|^2 per code and the projected code rows table[h][k] = W_out[:, h-block] embed[h][k]
-  STEMGNN_TRY(stemgnn_code_sqnorm(p->embed, H * K, Dc, s.esq, stream));
+  // (the pair-format assignment kernel takes the codes' squared norms from the rows it cuts: one launch less)
+  if (!vq_assign_takes_own_sqnorm(N, H, Dc, K)) STEMGNN_TRY(stemgnn_code_sqnorm(p->embed, H * K, Dc, s.esq, stream));
   STEMGNN_TRY(stemgnn_small_gemm(p->embed, Dc, 1, K * Dc, p->w_out, 1, HD, Dc, s.table, D, 1, K * D, K, D, Dc, H, stream));
   // l2norm + similarity + arg-max + commitment sum (vq.py:891, 650-657, 1007-1009), nothing of size [N, H*Dc] written
   const bool commit = training && p->commitment_weight > 0.f;

@@ -720,6 +720,13 @@ inline int64_t row_blocks(int64_t N) { return (N + kRowsPerBlock - 1) / kRowsPer
 }  // namespace
 }  // namespace stemgnn
 
+namespace stemgnn {
+// the lean assignment will run on k_vq_assign_wsp (same predicate as in vq_assign_impl below), which needs no `esq`
+bool vq_assign_takes_own_sqnorm(int64_t N, int64_t H, int64_t Dc, int64_t K) {
+  return stemgnn_linear_set_mode(-1) >= 1 && stemgnn_linear_set_ws(-1) > 0 && vq_assign_ws_ok(N, H, Dc, K) && linear_pair_on();
+}
+}  // namespace stemgnn
+
 using namespace stemgnn;
 
 extern "C" {

@@ -58,7 +58,8 @@ std::atomic<int64_t> g_wsp_calls{0};
 // 16 ks + 8 hi .. + 7 of every 16-wide step -- the lane pair (hi = 0, 1) holds the whole weight row, whose largest
 // magnitude scales it.  Returns the inverse factor.  BT: the weight is [K][N] (column n read with stride N).
 template <bool BT>
-__device__ __forceinline__ float weight_fragments(const float* __restrict__ w, int N, int n, int hi, f16x8 (&bw)[8][2]) {
+__device__ __forceinline__ float weight_fragments(const float* __restrict__ w, int N, int n, int hi, f16x8 (&bw)[8][2],
+                                                  float* ssq = nullptr /* the weight row's sum of squares, if wanted */) {
   float4 q[16];
 #pragma unroll
   for (int ks = 0; ks < 8; ++ks) {
@@ -77,6 +78,12 @@ __device__ __forceinline__ float weight_fragments(const float* __restrict__ w, i
 #pragma unroll
   for (int i = 0; i < 16; ++i) mx = max_abs4(mx, q[i]);
   mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  if (ssq) {
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sq += q[i].x * q[i].x + q[i].y * q[i].y + q[i].z * q[i].z + q[i].w * q[i].w;
+    *ssq = sq + __shfl_xor(sq, 32, 64);
+  }
   float sc, inv;
   pair_scale(mx, sc, inv);
 #pragma unroll
@@ -510,11 +517,11 @@ namespace {
 // fp32 here, vq.py:623,634).  Row norms from the fp32 values as they are cut.  Outputs as k_vq_assign's lean form.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr size_t kAqBest = 4 * kPM * sizeof(float), kAqCode = 4 * kPM * sizeof(int);
-constexpr size_t kAqLdsBytes = kPPlanesBytes + kAqBest + kAqCode + 2 * 2 * kPM * sizeof(float) + kPN * sizeof(float);
+constexpr size_t kAqLdsBytes = kPPlanesBytes + kAqBest + kAqCode + 2 * 2 * kPM * sizeof(float) + 2 * kPN * sizeof(float);
 
 __global__ void __launch_bounds__(kPT, 2)
 k_vq_assign_wsp(const float* __restrict__ xp, int64_t N, int H, const float* __restrict__ embed,
-                const float* __restrict__ esq, float* __restrict__ norm_out, int64_t* __restrict__ ind_out,
+                float* __restrict__ norm_out, int64_t* __restrict__ ind_out,
                 float* __restrict__ sq_partial, unsigned int* counter, double sq_scale, float* __restrict__ sq_out) {
   constexpr int K = 128;
   constexpr float kNormEps = 1e-12f;  // F.normalize eps
@@ -524,6 +531,7 @@ k_vq_assign_wsp(const float* __restrict__ xp, int64_t N, int H, const float* __r
   int* const s_code = reinterpret_cast<int*>(smem + kPPlanesBytes + kAqBest);           // [4 waves][64 rows]
   float* const s_row = reinterpret_cast<float*>(smem + kPPlanesBytes + kAqBest + kAqCode);  // [parity][inv | ssq][64]
   float* const s_cf = s_row + 2 * 2 * kPM;                                              // [128] code factors
+  float* const s_esq = s_cf + kPN;                                                      // [128] squared code norms
 
   const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
   const int hi = lane >> 5, lj = lane & 31;
@@ -551,8 +559,9 @@ k_vq_assign_wsp(const float* __restrict__ xp, int64_t N, int H, const float* __r
   __builtin_amdgcn_sched_barrier(0);
   f16x8 bw[8][2];
   {
-    const float inv_c = weight_fragments<false>(emb, K, 32 * wn + lj, hi, bw);
-    if (hi == 0) s_cf[32 * wn + lj] = inv_c;
+    float code_sq;  // |e|^2 of this lane pair's code: the block's own copy of what k_code_sqnorm computes (one launch less)
+    const float inv_c = weight_fragments<false>(emb, K, 32 * wn + lj, hi, bw, &code_sq);
+    if (hi == 0) { s_cf[32 * wn + lj] = inv_c; s_esq[32 * wn + lj] = code_sq; }
   }
   __syncthreads();
   float cf[16];  // factors of this lane's 16 codes 32 wn + 4 hi + (r & 3) + 8 (r >> 2)
@@ -662,7 +671,7 @@ k_vq_assign_wsp(const float* __restrict__ xp, int64_t N, int H, const float* __r
       const int64_t m = m0 + row < N ? m0 + row : N - 1;  // a row past N is a copy of row N - 1: the same values again
       ind_out[m * H + h] = static_cast<int64_t>(bi);
       norm_out[m * H + h] = nrm;
-      if (m0 + row < N) sq_acc += esq[static_cast<int64_t>(h) * K + bi] + xn2 * xn2 - 2.0f * best * inv;
+      if (m0 + row < N) sq_acc += s_esq[bi] + xn2 * xn2 - 2.0f * best * inv;
     }
     par ^= 1;  // the next tile's cut writes the other set of row factors while slow waves still read this one
   };
@@ -715,8 +724,9 @@ int vq_assign_wsp_launch(const float* xp, int64_t N, int64_t H, const float* emb
   if (gx < 1) gx = 1;
   g_wsp_calls.fetch_add(1, std::memory_order_relaxed);
   dim3 grid(static_cast<unsigned>(gx), static_cast<unsigned>(H));
-  k_vq_assign_wsp<<<grid, kPT, kAqLdsBytes, st>>>(xp, N, static_cast<int>(H), embed, esq, norm, ind, sq_partial, counter,
-                                                  sq_scale, sq_out);
+  (void)esq;  // the kernel takes the codes' squared norms from the rows it cuts
+  k_vq_assign_wsp<<<grid, kPT, kAqLdsBytes, st>>>(xp, N, static_cast<int>(H), embed, norm, ind, sq_partial, counter, sq_scale,
+                                                  sq_out);
   STEMGNN_LAUNCH_CHECK();
   return STEMGNN_OK;
 }
