@@ -744,20 +744,22 @@ namespace {
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kKspFragU4 = 4 * 16 * 64;  // uint4 per segment: 4 waves x (8 k steps x 2 planes) x 64 lanes
 
+// grid (segments, 4): block (seg, wn) cuts the fragments of wave wn's 32 weight columns for segment seg
 __global__ void __launch_bounds__(kPT)
 k_ksp_weight_frags(const float* __restrict__ w /*[K][128]*/, int K, uint4* __restrict__ frag, float* __restrict__ inv_w) {
-  __shared__ float s_part[8][kPN];
-  __shared__ float s_scale[kPN];
-  const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6, hi = lane >> 5, lj = lane & 31;
-  const int seg = blockIdx.x;
-  {  // largest magnitude of every weight column over the whole contraction (every segment's block computes all of them)
-    const int c4 = 4 * (tid & 31), rg = tid >> 5;
+  __shared__ float s_part[32][32];
+  __shared__ float s_scale[32];
+  const int tid = threadIdx.x;
+  const int seg = blockIdx.x, wn = blockIdx.y;
+  {  // largest magnitude of the block's 32 weight columns over the WHOLE contraction: 8 lanes per row, 32 rows per pass,
+    // sixteen rows in flight per thread
+    const int c4 = 32 * wn + 4 * (tid & 7), rg = tid >> 3;
     float4 mx = zero4();
-    for (int k = rg; k < K; k += 8 * 16) {  // sixteen rows in flight per thread (one at a time: 64 memory latencies)
+    for (int k = rg; k < K; k += 32 * 16) {
       float4 v[16];
 #pragma unroll
       for (int u = 0; u < 16; ++u) {
-        const int kk = k + 8 * u < K ? k + 8 * u : rg;  // a short last batch re-reads the thread's first row
+        const int kk = k + 32 * u < K ? k + 32 * u : rg;  // a short last batch re-reads the thread's first row
         v[u] = ld4(w + static_cast<int64_t>(kk) * kPN + c4);
       }
 #pragma unroll
@@ -765,21 +767,23 @@ k_ksp_weight_frags(const float* __restrict__ w /*[K][128]*/, int K, uint4* __res
         mx = make_float4(fmaxf(mx.x, fabsf(v[u].x)), fmaxf(mx.y, fabsf(v[u].y)), fmaxf(mx.z, fabsf(v[u].z)),
                          fmaxf(mx.w, fabsf(v[u].w)));
     }
-    st4(&s_part[rg][c4], mx);
+    st4(&s_part[rg][4 * (tid & 7)], mx);
     __syncthreads();
-    if (tid < kPN) {
+    if (tid < 32) {
       float m = 0.f;
 #pragma unroll
-      for (int g = 0; g < 8; ++g) m = fmaxf(m, s_part[g][tid]);
+      for (int g = 0; g < 32; ++g) m = fmaxf(m, s_part[g][tid]);
       float sc, inv;
       pair_scale(m, sc, inv);
       s_scale[tid] = sc;
-      if (seg == 0) inv_w[tid] = inv;
+      if (seg == 0) inv_w[32 * wn + tid] = inv;
     }
     __syncthreads();
   }
+  if (tid >= 64) return;  // one wave cuts the 32 columns' fragments of this segment
+  const int lane = tid, hi = lane >> 5, lj = lane & 31;
   const int n = 32 * wn + lj;
-  const float sc = s_scale[n];
+  const float sc = s_scale[lj];
   const float* p = w + (static_cast<int64_t>(seg) * kPK + 8 * hi) * kPN + n;
 #pragma unroll
   for (int ks = 0; ks < 8; ++ks) {
@@ -950,7 +954,7 @@ int linear_ksp_launch(const float* dy, const float* rowmax, const float* w, int6
   if (attr != hipSuccess) return STEMGNN_ERR_HIP;
   float* inv_w = static_cast<float*>(scratch);
   uint4* frag = reinterpret_cast<uint4*>(static_cast<unsigned char*>(scratch) + 1024);
-  k_ksp_weight_frags<<<S, kPT, 0, st>>>(w, S * kPK, frag, inv_w);
+  k_ksp_weight_frags<<<dim3(S, 4), kPT, 0, st>>>(w, S * kPK, frag, inv_w);
   STEMGNN_LAUNCH_CHECK();
   const int64_t tiles = (M + kPM - 1) / kPM;
   int64_t gx = wsp_blocks(kPN);
