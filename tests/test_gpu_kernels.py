@@ -1044,6 +1044,41 @@ def test_weight_stationary_product_returns_the_tile_kernels_bits(dev, m, k2, n, 
     torch.testing.assert_close(p1.sum(0)[1].double(), (ref * ref).sum(0), rtol=1e-4, atol=2e-2)
 
 
+def test_pair_weight_stationary_product_with_non_finite_and_extreme_rows(dev):
+    """Rows the power-of-two row factor has to survive (csrc/wspair.hip: pair_scale): a NaN, an Inf, a row of zeros, a
+    row of denormal-sized values, a row near FLT_MAX and one huge element among tiny ones.  Non-finite rows come back
+    non-finite in exactly those rows (as the tile kernel returns them), every other row is fp32-accurate -- the factor
+    is clamped to 2^+-110, so the tiny row's product does not overflow and the huge row's does not vanish."""
+    from stem_gnn_amd import ops
+    from stem_gnn_amd._lib import lib
+    torch.manual_seed(3)
+    m, n, k = 20_000, 128, 128
+    x = torch.randn(m, k, device=dev)
+    w = torch.randn(n, k, device=dev) * 0.1
+    b = torch.randn(n, device=dev)
+    x[5, 7] = float("nan")
+    x[6, 9] = float("inf")
+    x[7] = 0
+    x[8] = torch.randn(k, device=dev) * 1e-39           # denormals
+    x[9] = torch.randn(k, device=dev) * 1e-30
+    x[10] = torch.randn(k, device=dev).clamp(-3, 3) * 1e36
+    x[11] = torch.randn(k, device=dev) * 1e-12
+    x[11, 3] = 5e5                                       # one element 2^58 above the rest of its row
+    calls = lib.stemgnn_linear_wsp_calls()
+    y = ops.linear_fwd(x, w, None, None, b, False)[0]
+    assert lib.stemgnn_linear_wsp_calls() == calls + 1
+    bad = ~torch.isfinite(y).all(dim=1)
+    assert bad.nonzero().flatten().tolist() == [5, 6]
+    ref = x.double() @ w.double().t() + b.double()
+    good = ~bad
+    den = (x.abs().double() @ w.abs().double().t() + b.abs().double())[good]
+    assert float(((y[good].double() - ref[good]).abs() / den).max()) < 8 * 2.0 ** -24
+    assert torch.equal(y[7], b)
+    # the outlier row: the small elements are kept to 2^-39 of the row's largest (the format's second error term)
+    err11 = (y[11].double() - ref[11]).abs()
+    assert float(err11.max()) <= 8 * 2.0 ** -24 * float(den[11 - 2].max()) + 4 * 2.0 ** -39 * 5e5 * float(w.abs().sum(1).max())
+
+
 @pytest.mark.parametrize("m,n,k", [(1024, 128, 128), (11000, 128, 256), (33, 96, 48), (1, 32, 16), (5000, 256, 128)])
 def test_few_row_product_returns_the_tile_kernels_bits(dev, m, n, k):
     """stemgnn_linear_few_rows (one wave per 32 x 32 tile, operands straight from global memory) against the tile
