@@ -22,6 +22,14 @@
 // walk: the block multiplies the aggregate's tile with lin_l's fragments in a prologue (own row factors), leaves the
 // scaled result in the staging tile and adds it in that tile's epilogue; lin_l's 64 registers are dead before lin_r's
 // are loaded.
+//
+// In this file, all on the same skeleton (DESIGN.md section 3 "K3-pair" has the measurements):
+//   k_linear_wsp<STATS, BT, HEAD, EPI>   the product; EPI = 1 / 2: the quantiser's backward as its epilogue (project_out's
+//                                        backward-data product never leaves LDS; 2: also the row maxima of its output)
+//   k_vq_assign_wsp                      the code assignment at K = Dc = 128 (arg-max from the accumulators)
+//   k_ksp_weight_frags, k_linear_ksp<4>  project_in's backward-data product, 512 -> 128: four segments of contraction,
+//                                        the weight's fragments cut once per launch and reloaded per segment from L2
+// Nothing here allocates, frees or synchronises; scratch comes from the calling phase's workspace.
 #include "common.h"
 
 #include <atomic>
