@@ -1493,10 +1493,24 @@ class WeightedSumFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        gt = torch.empty(ctx.n, dtype=torch.float32, device=g.device)
-        check(lib.stemgnn_weighted_sum_bwd(ctx.w, ctx.n, _p(g.reshape(1).contiguous()), _p(gt), _stream()),
-              "weighted_sum_bwd")
+        if g.data_ptr() in UNIT_GRADIENTS:
+            # the seed of loss.backward() is a registered constant 1.0 (pretrain._ones_like_loss): the terms' gradients
+            # are the weights themselves -- a cached device tensor, no launch
+            key = (g.device, tuple(ctx.w))
+            gt = _WEIGHT_GRADS.get(key)
+            if gt is None:
+                gt = _WEIGHT_GRADS[key] = torch.tensor(list(ctx.w), dtype=torch.float32, device=g.device)
+        else:
+            gt = torch.empty(ctx.n, dtype=torch.float32, device=g.device)
+            check(lib.stemgnn_weighted_sum_bwd(ctx.w, ctx.n, _p(g.reshape(1).contiguous()), _p(gt), _stream()),
+                  "weighted_sum_bwd")
         return (None, *[gt[i].reshape(shape) for i, shape in enumerate(ctx.shapes)])
+
+
+# data pointers of device tensors that hold the constant 1.0 and are only ever used as the seed gradient of a backward
+# pass (registered by their owner, never written again); weight vectors of WeightedSumFn as device tensors
+UNIT_GRADIENTS = set()
+_WEIGHT_GRADS = {}
 
 
 def _grad_table(grads):

@@ -116,6 +116,7 @@ def _ones_like_loss(loss):
     t = _ONES.get(key)
     if t is None:
         t = _ONES[key] = torch.ones_like(loss)
+        ops.UNIT_GRADIENTS.add(t.data_ptr())  # lets the weighted loss sum hand out its weights without a launch
     return t
 
 
