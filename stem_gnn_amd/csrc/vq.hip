@@ -370,8 +370,17 @@ __global__ void __launch_bounds__(kBlock) k_segment_colsum(const float* __restri
   const int c = threadIdx.x & 63, s = threadIdx.x >> 6;
   const int d = blockIdx.x * 64 + c;
   float a = 0.f;
-  if (d < D)
-    for (int k = s; k < K; k += 4) a += sums[static_cast<int64_t>(k) * D + d];
+  if (d < D) {
+    int k = s;
+    for (; k + 28 < K; k += 32) {  // eight rows in flight (one at a time: a chain of K / 4 latencies), same order of sums
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = sums[static_cast<int64_t>(k + 4 * u) * D + d];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a += v[u];
+    }
+    for (; k < K; k += 4) a += sums[static_cast<int64_t>(k) * D + d];
+  }
   red[s][c] = a;
   __syncthreads();
   if (s == 0 && d < D) db[d] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
