@@ -166,6 +166,63 @@ def test_pretrain_step_on_a_real_c4_batch_matches_oracle(dev, c4_graph):
         torch.testing.assert_close(p2.detach().cpu(), p1.detach(), rtol=1e-3, atol=3e-4, msg=lambda m: f"{n1}: {m}")
 
 
+@pytest.mark.gpu
+def test_loss_curve_of_the_pair_kernels_follows_the_bf16_piece_kernels_on_a_c4_batch(dev, c4_graph):
+    """north_star: "loss curve matching reference to 1e-4".  The two-step oracle test above pins the step; this one runs
+    EIGHT optimiser steps on the benchmark's batch shape twice from the same state and the same draws -- dense products,
+    code assignment and the quantiser's backward in the pair format (two fp16 pieces, three matrix passes: the default)
+    and from three bf16 pieces (six passes: the tile kernel's arithmetic) -- and compares every loss term of every step
+    to 1e-4 and the parameters after the last."""
+    import copy
+    import torch.nn as nn
+    from stem_gnn_amd import ops
+    from stem_gnn_amd._lib import lib
+    from stem_gnn_amd.data.sampler import HipNeighborSampler
+    from stem_gnn_amd.graph import EdgeTypeAttr
+    from stem_gnn_amd.model.encoder import Encoder, InnerProductDecoder
+    from stem_gnn_amd.model.pt_model import PretrainModel
+    from stem_gnn_amd.model.vq import VectorQuantize
+    from stem_gnn_amd.pretrain import default_params, pretrain_step
+    g = c4_graph
+    D, L, H, K, bs = 128, 2, 4, 128, 1024
+    smp = HipNeighborSampler(g.edge_index, g.xe, g.num_nodes, g.x, g.node_text_feat, g.edge_text_feat, [10, 10], seed=11)
+    b = smp.sample(torch.randperm(g.num_nodes, device=dev)[:bs])
+    x = ops.gather_rows(g.node_text_feat, b.x.contiguous())
+    torch.manual_seed(1)
+    enc = Encoder(D, D, nn.ReLU, L, backbone="sage", normalize="batch", dropout=0.15)
+    vq = VectorQuantize(dim=D, codebook_size=K, codebook_dim=D, heads=H, separate_codebook_per_head=True, decay=0.8,
+                        commitment_weight=10, use_cosine_sim=True, orthogonal_reg_weight=1, orthogonal_reg_max_codes=32,
+                        kmeans_init=False, ema_update=False)
+    base = PretrainModel(enc, vq, nn.Linear(D, D), InnerProductDecoder(D, D), nn.Linear(2 * D, D))
+    params = default_params()
+    curves, finals, calls = {}, {}, {}
+    for pair in (1, 0):
+        was = ops.linear_set_pair(pair)
+        try:
+            m = copy.deepcopy(base).to(dev)
+            opt = torch.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=1e-5)
+            ops.manual_seed(77)
+            torch.manual_seed(5)  # the orthogonal regulariser's code subset
+            c0 = lib.stemgnn_linear_wsp_calls()
+            curve = []
+            for _ in range(8):
+                loss, losses, _ = pretrain_step(m, opt, None, params, x, b.graph, EdgeTypeAttr(g.edge_text_feat, b.xe), bs,
+                                                record_draws=False)
+                curve.append(torch.cat([loss.reshape(1)] + [losses[k].reshape(1) for k in sorted(losses)]))
+            curves[pair] = torch.stack(curve).cpu()
+            finals[pair] = {n: p.detach().cpu() for n, p in m.named_parameters()}
+            calls[pair] = lib.stemgnn_linear_wsp_calls() - c0
+        finally:
+            ops.linear_set_pair(was)
+    assert calls[1] >= 8 * 10 and calls[0] == 0  # the pair kernels carried the first run, none of them the second
+    assert bool(torch.isfinite(curves[1]).all()) and float(curves[1][-1, 0]) < float(curves[1][0, 0])  # it learns
+    torch.testing.assert_close(curves[1], curves[0], rtol=1e-4, atol=1e-6)
+    for n in finals[1]:
+        if "lin_l.bias" in n:
+            continue  # exactly-zero true gradient in front of BatchNorm: rounding noise through Adam
+        torch.testing.assert_close(finals[1][n], finals[0][n], rtol=2e-3, atol=2e-4, msg=lambda msg: f"{n}: {msg}")
+
+
 def test_c2_full_batch_step_matches_oracle(dev):
     """BASELINE config 2 as a whole step (round-3 review, parity hole (a)): N = 100 000 nodes, E = 1 000 000 directed
     entries, D = 128, H = 4, K = 128, FULL batch (bs = N: the feature-reconstruction and teacher terms run over every
